@@ -1,0 +1,144 @@
+/*
+ * hgs_rasterizer.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the one native dependency on the hot path of
+ * apple/ml-hugs: the module `diff_gaussian_rasterization`, imported at
+ *   /root/reference/hugs/renderer/gs_renderer.py:11-14
+ * and used only at
+ *   /root/reference/hugs/renderer/gs_renderer.py:126-152.
+ * Upstream exposes three C++/pybind entry points from its `_C` extension
+ * (rasterize_gaussians, rasterize_gaussians_backward, mark_visible); the
+ * three hgs_* entry points below replace them one for one with a plain C ABI:
+ * raw device pointers + sizes, no torch types.  The Python side
+ * (ml-hugs_amd/diff_gaussian_rasterization) binds them with ctypes.
+ *
+ * Ownership: every pointer is a device pointer borrowed for the duration of the call.
+ * The library allocates nothing that outlives a call: per-call scratch (geometry, binning and
+ * image state) is obtained through the caller's allocation callback so that it lives in
+ * caller-owned memory (torch uint8 tensors kept by the autograd ctx until backward).
+ * All work is enqueued on `stream` (a hipStream_t); forward performs ONE host
+ * synchronisation on that stream (to learn N and size the binning buffer).
+ * All floating point is fp32, contiguous.
+ */
+#ifndef HGS_RASTERIZER_H
+#define HGS_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGS_ABI_VERSION 1
+
+/* scratch buffer ids passed to the allocation callback */
+enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
+
+/* error codes (negative return values) */
+enum {
+    HGS_OK = 0,
+    HGS_ERR_INVALID_ARGUMENT = -1,
+    HGS_ERR_ALLOC = -2,
+    HGS_ERR_HIP = -3,
+    HGS_ERR_NO_DEVICE = -4
+};
+
+/* Returns a device pointer to at least `bytes` bytes, 256-byte aligned, or NULL. */
+typedef void *(*hgs_alloc_fn)(void *ctx, int buffer_id, size_t bytes);
+
+/* Mirrors GaussianRasterizationSettings as filled at gs_renderer.py:126-139
+ * (image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
+ * sh_degree, campos, prefiltered, debug). bg/viewmatrix/projmatrix/campos are DEVICE pointers
+ * (they are CUDA tensors in the reference's settings tuple). Matrices: row-vector convention,
+ * flat [4*r + c]. */
+typedef struct hgs_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float *bg;         /* [3] */
+    float scale_modifier;
+    const float *viewmatrix; /* [16] */
+    const float *projmatrix; /* [16] */
+    int32_t sh_degree;       /* active degree D, 0..3 */
+    const float *campos;     /* [3] */
+    int32_t prefiltered;
+    int32_t debug;           /* !=0: synchronise + check after every stage */
+} hgs_settings;
+
+/* Inputs/outputs of the forward pass == kwargs of GaussianRasterizer.forward at
+ * gs_renderer.py:144-152 plus the two outputs (rendered_image, radii). */
+typedef struct hgs_forward_args {
+    hgs_settings s;
+    int32_t P;                   /* number of Gaussians */
+    int32_t M;                   /* SH coefficients stored per Gaussian (shs is [P,M,3]); 0 if shs NULL */
+    const float *means3D;        /* [P,3] */
+    const float *shs;            /* [P,M,3] or NULL */
+    const float *colors_precomp; /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+    const float *opacities;      /* [P] */
+    const float *scales;         /* [P,3] or NULL */
+    const float *rotations;      /* [P,4] (w,x,y,z), not normalised, or NULL */
+    const float *cov3D_precomp;  /* [P,6] or NULL (exactly one of (scales,rotations) / cov3D_precomp) */
+    float *out_color;            /* [3,H,W], written for every pixel when P > 0 */
+    int32_t *radii;              /* [P] */
+} hgs_forward_args;
+
+/* Scratch handed back by forward and required by backward. */
+typedef struct hgs_forward_state {
+    void *geom;    size_t geom_bytes;
+    void *binning; size_t binning_bytes;
+    void *image;   size_t image_bytes;
+    int64_t num_rendered; /* N = sum of tiles touched */
+} hgs_forward_state;
+
+/* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */
+int64_t hgs_rasterize_forward(const hgs_forward_args *args, hgs_alloc_fn alloc, void *alloc_ctx,
+                              hgs_forward_state *state_out, void *stream);
+
+/* Replaces _C.rasterize_gaussians_backward. All dL_* outputs must be ZERO-INITIALISED by the
+ * caller (the library accumulates into dL_dmeans2D/dL_dconic/dL_dopacity/dL_dcolors with float
+ * atomics and overwrites the rest for visible Gaussians only). */
+typedef struct hgs_backward_args {
+    hgs_forward_args fwd;       /* same inputs as forward (out_color unused; radii = forward's output) */
+    hgs_forward_state state;    /* as returned by forward */
+    const float *dL_dout_color; /* [3,H,W] */
+    float *dL_dmeans2D;         /* [P,3]  (x,y NDC-scaled; z stays 0) */
+    float *dL_dconic;           /* [P,4]  scratch (slots x,y,.,w) */
+    float *dL_dopacity;         /* [P] */
+    float *dL_dcolors;          /* [P,3]  dL/d(colors_precomp) or dL/d(SH->RGB result) */
+    float *dL_dmeans3D;         /* [P,3] */
+    float *dL_dcov3D;           /* [P,6] */
+    float *dL_dsh;              /* [P,M,3] or NULL */
+    float *dL_dscales;          /* [P,3] */
+    float *dL_drotations;       /* [P,4] */
+} hgs_backward_args;
+
+int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);
+
+/* Replaces _C.mark_visible: present[i] = (z_view(means3D[i]) > 0.2). */
+int32_t hgs_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present,
+                         void *stream);
+
+/* Message for the last negative return value on the calling thread. */
+const char *hgs_last_error(void);
+
+int32_t hgs_abi_version(void);
+
+/* Scratch sizes (so a caller may pre-allocate) */
+size_t hgs_geom_bytes(int32_t P);
+size_t hgs_image_bytes(int32_t image_height, int32_t image_width);
+size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
+
+/* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
+ * Names: geom: "splats","tiles_touched","offsets"; binning: "keys","values";
+ * image: "final_T","n_contrib","ranges". Returns (size_t)-1 for an unknown name.
+ * For "keys"/"values" the offset is of the SORTED list and depends on the last forward's N
+ * and image size. */
+size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int32_t image_height,
+                          int32_t image_width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_RASTERIZER_H */

@@ -1,0 +1,310 @@
+// Tile binning: prefix scan (K2), key emission (K3), stable LSD radix sort (K4), tile ranges (K5).
+// Algorithm: SURVEY.md Appendix A.4.  Everything here is integer work and is compared bit-for-bit
+// with the CPU oracle.  Wave64 ballots / popcounts do the per-digit ranking; no CUB/rocPRIM.
+#include "hgs_common.h"
+
+namespace hgs {
+
+// ---------------------------------------------------------------------------------------------
+// wave / block scan helpers (wave = 64 lanes)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// inclusive scan over a 256-thread block of one value per thread; returns the inclusive value and the
+// block total through `total`. `wsum` is a 4-entry LDS array.
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wsum, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t s = wsum[k];
+        if (k < w) base += s;
+    }
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return inc + base;
+}
+
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;  // 1024 elements per block
+
+__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ block_sums, int n)
+{
+    __shared__ uint32_t wsum[4];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t total;
+    block_inclusive_scan(s, wsum, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums[0..m) in place
+__global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* __restrict__ block_sums, int m)
+{
+    __shared__ uint32_t wsum[4];
+    uint32_t carry = 0;
+    for (int base = 0; base < m; base += 256) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < m ? block_sums[i] : 0;
+        uint32_t total;
+        uint32_t inc = block_inclusive_scan(v, wsum, total);
+        if (i < m) block_sums[i] = carry + inc - v;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ block_sums,
+                                                         uint32_t* __restrict__ out, int n)
+{
+    __shared__ uint32_t wsum[4];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t inc = block_inclusive_scan(s, wsum, total);
+    uint32_t run = block_sums[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+}
+
+void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, st, in, tmp, n);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, tmp, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, tmp, out, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: one thread per Gaussian writes its (tile | depth bits, index) pairs, y outer, x inner.
+__global__ void __launch_bounds__(256)
+emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ offsets,
+                 uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
+    const int radius = __float_as_int(tail.z);
+    if (radius <= 0) return;
+    const float4 head = reinterpret_cast<const float4*>(splats + i)[0];
+    const float px = head.x, py = head.y, radf = (float)radius;
+    // identical expressions to the preprocess kernel => identical rectangle
+    int minx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
+    int maxx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
+    int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
+    int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
+    uint32_t off = i == 0 ? 0u : offsets[i - 1];
+    const uint64_t dbits = (uint64_t)__float_as_uint(tail.y);
+    for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) {
+            uint64_t key = ((uint64_t)(uint32_t)(ty * cam.gx + tx) << 32) | dbits;
+            keys[off] = key;
+            values[off] = (uint32_t)i;
+            ++off;
+        }
+}
+
+void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* offsets, uint64_t* keys,
+                      uint32_t* values, hipStream_t st)
+{
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, cam, splats, offsets, keys, values);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: LSD radix sort, digits of <= 9 bits, three kernels per pass:
+//   upsweep   per-block digit histogram -> hist[digit][block], global digit totals
+//   scan      one workgroup per digit: exclusive scan of its row + base of all smaller digits
+//   downsweep stable scatter: rank = global base + earlier waves + earlier rounds + lower lanes
+// Block = 256 threads = 4 waves; wave w owns a contiguous run of 16 rounds x 64 keys, so the
+// (wave, round, lane) order is the input order and the sort is stable.
+
+struct SortPlan {
+    int passes;
+    int bits[8];
+    int shift[8];
+};
+static SortPlan make_plan(int num_bits)
+{
+    SortPlan p;
+    if (num_bits < 1) num_bits = 1;
+    p.passes = (num_bits + 8) / 9;
+    int base = num_bits / p.passes, extra = num_bits % p.passes, sh = 0;
+    for (int i = 0; i < p.passes; ++i) {
+        p.bits[i] = base + (i < extra ? 1 : 0);
+        p.shift[i] = sh;
+        sh += p.bits[i];
+    }
+    return p;
+}
+int sort_input_buffer(int num_bits) { return make_plan(num_bits).passes & 1; }
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_upsweep_kernel(const uint64_t* __restrict__ keys, int64_t N, int shift, int nbits, uint32_t* __restrict__ hist,
+                    uint32_t* __restrict__ totals, int nblocks)
+{
+    __shared__ uint32_t h[SORT_MAX_BINS];
+    const int nbins = 1 << nbits;
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) h[d] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const uint32_t mask = (uint32_t)nbins - 1u;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        int64_t i = base + (int64_t)r * SORT_THREADS + threadIdx.x;
+        if (i < N) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) {
+        uint32_t c = h[d];
+        hist[(size_t)d * nblocks + blockIdx.x] = c;
+        if (c) atomicAdd(&totals[d], c);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sort_scan_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, int nblocks)
+{
+    __shared__ uint32_t wsum[4];
+    const int d = blockIdx.x;
+    // base = sum of totals of smaller digits
+    uint32_t part = 0;
+    for (int k = threadIdx.x; k < d; k += 256) part += totals[k];
+    uint32_t base;
+    block_inclusive_scan(part, wsum, base);
+    uint32_t* row = hist + (size_t)d * nblocks;
+    uint32_t carry = base;
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        int b = b0 + threadIdx.x;
+        uint32_t v = b < nblocks ? row[b] : 0;
+        uint32_t total;
+        uint32_t inc = block_inclusive_scan(v, wsum, total);
+        if (b < nblocks) row[b] = carry + inc - v;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_downsweep_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t N, int shift,
+                      int nbits, const uint32_t* __restrict__ hist, int nblocks)
+{
+    __shared__ uint32_t cnt[4][SORT_MAX_BINS];
+    __shared__ uint32_t gbase[SORT_MAX_BINS];
+    const int nbins = 1 << nbits;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int d = threadIdx.x; d < 4 * SORT_MAX_BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) gbase[d] = hist[(size_t)d * nblocks + blockIdx.x];
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * (SORT_ITEMS * 64);
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t key[SORT_ITEMS];
+    uint32_t loc[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool valid = i < N;
+        key[r] = valid ? keys_in[i] : ~0ull;
+        const uint32_t digit = (uint32_t)(key[r] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt);
+        uint32_t pre = 0;
+        if (valid) pre = cnt[w][digit];
+        // in-order LDS within the wave: every peer has read `pre` before the leader's update lands
+        if (valid && before == 0) cnt[w][digit] = pre + (uint32_t)__popcll(peers);
+        loc[r] = pre + before;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) {
+        uint32_t run = gbase[d];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t c = cnt[k][d];
+            cnt[k][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        if (i < N) {
+            const uint32_t digit = (uint32_t)(key[r] >> shift) & mask;
+            const uint32_t pos = cnt[w][digit] + loc[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = vals_in[i];
+        }
+    }
+}
+
+void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
+                       uint32_t* totals, int64_t N, int num_bits, hipStream_t st)
+{
+    if (N <= 0) return;
+    SortPlan p = make_plan(num_bits);
+    const int nblocks = (int)((N + SORT_TILE - 1) / SORT_TILE);
+    (void)hipMemsetAsync(totals, 0, sizeof(uint32_t) * SORT_MAX_BINS * 8, st);
+    uint64_t *kin = (p.passes & 1) ? keys_b : keys_a, *kout = (p.passes & 1) ? keys_a : keys_b;
+    uint32_t *vin = (p.passes & 1) ? vals_b : vals_a, *vout = (p.passes & 1) ? vals_a : vals_b;
+    for (int i = 0; i < p.passes; ++i) {
+        uint32_t* tot = totals + (size_t)i * SORT_MAX_BINS;
+        hipLaunchKernelGGL(sort_upsweep_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, N, p.shift[i], p.bits[i],
+                           hist, tot, nblocks);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1 << p.bits[i]), dim3(256), 0, st, hist, tot, nblocks);
+        hipLaunchKernelGGL(sort_downsweep_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N,
+                           p.shift[i], p.bits[i], hist, nblocks);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5
+__global__ void __launch_bounds__(256)
+tile_ranges_kernel(const uint64_t* __restrict__ keys, int64_t N, uint2* __restrict__ ranges)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
+    if (i == N - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+}
+
+void launch_tile_ranges(const uint64_t* keys, int64_t N, uint2* ranges, int num_tiles, hipStream_t st)
+{
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st);
+    if (N <= 0) return;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, keys, N, ranges);
+}
+
+}  // namespace hgs

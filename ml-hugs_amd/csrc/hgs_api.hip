@@ -1,0 +1,212 @@
+// C ABI entry points (include/hgs_rasterizer.h): argument validation, scratch layout, stage sequencing.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "hgs_common.h"
+
+using namespace hgs;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(HGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+// debug=True in the reference's settings means: synchronise and check after every stage
+#define STAGE_CHECK(debug, st, name)                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = hipGetLastError();                                                               \
+        if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(st);                                  \
+        if (e_ != hipSuccess) return fail(HGS_ERR_HIP, "stage %s: %s", name, hipGetErrorString(e_));     \
+    } while (0)
+
+int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
+{
+    int b = 0;
+    while (b < 32 && (1ull << b) < (uint64_t)n) ++b;
+    return b < 1 ? 1 : b;
+}
+
+int make_camera(const hgs_forward_args& a, Camera& cam)
+{
+    const hgs_settings& s = a.s;
+    if (a.P < 0) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be >= 0");
+    if (s.image_height <= 0 || s.image_width <= 0) return fail(HGS_ERR_INVALID_ARGUMENT, "image size must be positive");
+    if (a.P > 0 && !a.means3D) return fail(HGS_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
+    if (!s.bg || !s.viewmatrix || !s.projmatrix || !s.campos)
+        return fail(HGS_ERR_INVALID_ARGUMENT, "bg, viewmatrix, projmatrix and campos are required device pointers");
+    if (a.P > 0) {
+        if ((a.shs != nullptr) == (a.colors_precomp != nullptr))
+            return fail(HGS_ERR_INVALID_ARGUMENT, "Please provide excatly one of either SHs or precomputed colors!");
+        const bool sr = a.scales != nullptr && a.rotations != nullptr;
+        if (sr == (a.cov3D_precomp != nullptr) || ((a.scales != nullptr) != (a.rotations != nullptr)))
+            return fail(HGS_ERR_INVALID_ARGUMENT,
+                        "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        if (!a.opacities) return fail(HGS_ERR_INVALID_ARGUMENT, "opacities is required");
+        if (a.shs) {
+            if (s.sh_degree < 0 || s.sh_degree > 3) return fail(HGS_ERR_INVALID_ARGUMENT, "sh_degree must be in 0..3");
+            if (a.M < (s.sh_degree + 1) * (s.sh_degree + 1))
+                return fail(HGS_ERR_INVALID_ARGUMENT, "shs holds %d coefficients, degree %d needs %d", a.M, s.sh_degree,
+                            (s.sh_degree + 1) * (s.sh_degree + 1));
+        }
+    }
+    cam.W = s.image_width, cam.H = s.image_height;
+    cam.gx = (cam.W + TILE - 1) / TILE, cam.gy = (cam.H + TILE - 1) / TILE;
+    cam.tanfovx = s.tanfovx, cam.tanfovy = s.tanfovy;
+    cam.fx = (float)cam.W / (2.0f * s.tanfovx);
+    cam.fy = (float)cam.H / (2.0f * s.tanfovy);
+    cam.mod = s.scale_modifier;
+    cam.D = s.sh_degree, cam.M = a.M;
+    return HGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hgs_last_error(void) { return g_err; }
+int32_t hgs_abi_version(void) { return HGS_ABI_VERSION; }
+
+size_t hgs_geom_bytes(int32_t P) { return GeomLayout(P < 1 ? 1 : P).total; }
+size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
+size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
+
+size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int32_t W)
+{
+    GeomLayout g(P < 1 ? 1 : P);
+    ImageLayout im(H, W);
+    BinningLayout b(N);
+    if (!strcmp(name, "splats")) return g.splats;
+    if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
+    if (!strcmp(name, "offsets")) return g.offsets;
+    if (!strcmp(name, "keys")) return b.keys;
+    if (!strcmp(name, "values")) return b.values;
+    if (!strcmp(name, "final_T")) return im.final_T;
+    if (!strcmp(name, "n_contrib")) return im.n_contrib;
+    if (!strcmp(name, "ranges")) return im.ranges;
+    return (size_t)-1;
+}
+
+int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, void* alloc_ctx,
+                              hgs_forward_state* state, void* stream)
+{
+    if (!args || !alloc || !state) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
+    const hgs_forward_args& a = *args;
+    hipStream_t st = (hipStream_t)stream;
+    Camera cam;
+    if (int rc = make_camera(a, cam)) return rc;
+    memset(state, 0, sizeof *state);
+    if (a.P == 0) return 0;  // nothing is launched: out_color keeps the caller's zeros (no background)
+    if (!a.out_color || !a.radii) return fail(HGS_ERR_INVALID_ARGUMENT, "out_color and radii are required");
+    const bool dbg = a.s.debug != 0;
+
+    GeomLayout gl(a.P);
+    ImageLayout il(cam.H, cam.W);
+    char* geom = (char*)alloc(alloc_ctx, HGS_BUF_GEOM, gl.total);
+    char* image = (char*)alloc(alloc_ctx, HGS_BUF_IMAGE, il.total);
+    if (!geom || !image) return fail(HGS_ERR_ALLOC, "scratch allocation failed (geom %zu B, image %zu B)", gl.total, il.total);
+    state->geom = geom, state->geom_bytes = gl.total;
+    state->image = image, state->image_bytes = il.total;
+
+    Splat* splats = (Splat*)(geom + gl.splats);
+    uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
+    uint32_t* offsets = (uint32_t*)(geom + gl.offsets);
+    uint32_t* scan_tmp = (uint32_t*)(geom + gl.scan_tmp);
+
+    launch_preprocess(a, cam, splats, tiles_touched, st);
+    STAGE_CHECK(dbg, st, "preprocess");
+    launch_scan_inclusive(tiles_touched, offsets, scan_tmp, a.P, st);
+    STAGE_CHECK(dbg, st, "scan");
+
+    // the one host synchronisation of the forward pass: N sizes the binning buffer
+    uint32_t n32 = 0;
+    HIP_TRY(hipMemcpyAsync(&n32, offsets + (a.P - 1), sizeof n32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t N = (int64_t)n32;
+    state->num_rendered = N;
+
+    BinningLayout bl(N);
+    char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
+    if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
+    state->binning = bin, state->binning_bytes = bl.total;
+    uint64_t *keys_a = (uint64_t*)(bin + bl.keys), *keys_b = (uint64_t*)(bin + bl.keys_alt);
+    uint32_t *vals_a = (uint32_t*)(bin + bl.values), *vals_b = (uint32_t*)(bin + bl.values_alt);
+    uint2* ranges = (uint2*)(image + il.ranges);
+    const int num_tiles = cam.gx * cam.gy;
+
+    if (N > 0) {
+        const int num_bits = 32 + bits_for((uint32_t)num_tiles);
+        const bool in_b = sort_input_buffer(num_bits) != 0;
+        launch_emit_keys(a.P, cam, splats, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st);
+        STAGE_CHECK(dbg, st, "emit_keys");
+        launch_sort_pairs(keys_a, keys_b, vals_a, vals_b, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
+                          num_bits, st);
+        STAGE_CHECK(dbg, st, "sort");
+    }
+    launch_tile_ranges(keys_a, N, ranges, num_tiles, st);
+    STAGE_CHECK(dbg, st, "tile_ranges");
+    launch_blend_forward(cam, ranges, vals_a, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
+                         (uint32_t*)(image + il.n_contrib), st);
+    STAGE_CHECK(dbg, st, "blend_forward");
+    return N;
+}
+
+int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
+{
+    if (!args) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
+    const hgs_backward_args& a = *args;
+    const hgs_forward_args& f = a.fwd;
+    hipStream_t st = (hipStream_t)stream;
+    Camera cam;
+    if (int rc = make_camera(f, cam)) return rc;
+    if (f.P == 0) return HGS_OK;
+    if (!a.state.geom || !a.state.image || !a.state.binning)
+        return fail(HGS_ERR_INVALID_ARGUMENT, "forward state is missing");
+    if (!a.dL_dout_color || !a.dL_dmeans2D || !a.dL_dconic || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmeans3D ||
+        !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
+        return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");
+    const bool dbg = f.s.debug != 0;
+    GeomLayout gl(f.P);
+    ImageLayout il(cam.H, cam.W);
+    BinningLayout bl(a.state.num_rendered);
+    if (a.state.geom_bytes < gl.total || a.state.image_bytes < il.total || a.state.binning_bytes < bl.total)
+        return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size");
+    const char* geom = (const char*)a.state.geom;
+    const char* image = (const char*)a.state.image;
+    const char* bin = (const char*)a.state.binning;
+    const Splat* splats = (const Splat*)(geom + gl.splats);
+
+    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint32_t*)(bin + bl.values), splats, f.s.bg,
+                          (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
+                          a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolors, st);
+    STAGE_CHECK(dbg, st, "blend_backward");
+    launch_preprocess_backward(a, cam, splats, st);
+    STAGE_CHECK(dbg, st, "preprocess_backward");
+    return HGS_OK;
+}
+
+int32_t hgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream)
+{
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(HGS_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (P == 0) return HGS_OK;
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HGS_ERR_HIP, "mark_visible: %s", hipGetErrorString(e));
+    return HGS_OK;
+}
+
+}  // extern "C"

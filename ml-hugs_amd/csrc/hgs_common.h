@@ -1,0 +1,105 @@
+// Shared declarations for the HIP rasterizer (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hgs_rasterizer.h"
+
+namespace hgs {
+
+constexpr int TILE = 16;        // 16x16 pixel tiles
+constexpr int WAVE = 64;        // CDNA wavefront
+constexpr float NEAR_Z = 0.2f;  // near cull
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_STOP = 0.0001f;
+
+// Per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
+// 48 bytes, 16-byte aligned: three dwordx4 (scalar or vector) loads.
+struct alignas(16) Splat {
+    float x, y;        // pixel-space mean
+    float ca, cb, cc;  // conic (inverse 2D covariance): xx, xy, yy
+    float opacity;
+    float r, g, b;     // view-dependent colour after +0.5 / clamp
+    float depth;       // view-space z; its raw bits are the low half of the sort key
+    int32_t radius;    // 0 => culled
+    uint32_t clamped;  // bit c set => colour channel c was clamped at 0
+};
+static_assert(sizeof(Splat) == 48, "Splat layout");
+
+struct Camera {  // small by-value kernel argument
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy, mod;
+    int D, M;
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
+struct GeomLayout {
+    size_t splats, tiles_touched, offsets, scan_tmp, total;
+    explicit GeomLayout(int P) {
+        size_t o = 0;
+        splats = o;        o = align_up(o + sizeof(Splat) * (size_t)P);
+        tiles_touched = o; o = align_up(o + 4 * (size_t)P);
+        offsets = o;       o = align_up(o + 4 * (size_t)P);
+        scan_tmp = o;      o = align_up(o + 4 * ((size_t)P / 1024 + 2) + 64);
+        total = o;
+    }
+};
+struct ImageLayout {
+    size_t final_T, n_contrib, ranges, total;
+    ImageLayout(int H, int W) {
+        size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
+        size_t o = 0;
+        final_T = o;   o = align_up(o + 4 * S);
+        n_contrib = o; o = align_up(o + 4 * S);
+        ranges = o;    o = align_up(o + 8 * T);
+        total = o;
+    }
+};
+constexpr int SORT_ITEMS = 16;                     // keys per thread per block
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_TILE = SORT_ITEMS * SORT_THREADS;  // 4096 keys per block
+constexpr int SORT_MAX_BINS = 512;                 // up to 9-bit digits
+struct BinningLayout {
+    size_t keys, keys_alt, values, values_alt, hist, totals, total;
+    size_t nblocks;
+    explicit BinningLayout(int64_t N) {
+        size_t n = (size_t)(N < 1 ? 1 : N);
+        nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+        size_t o = 0;
+        keys = o;       o = align_up(o + 8 * n);
+        keys_alt = o;   o = align_up(o + 8 * n);
+        values = o;     o = align_up(o + 4 * n + 64);  // +64: the blend kernels fetch list entries 4 at a time
+        values_alt = o; o = align_up(o + 4 * n + 64);
+        hist = o;       o = align_up(o + 4 * (size_t)SORT_MAX_BINS * nblocks);
+        totals = o;     o = align_up(o + 4 * (size_t)SORT_MAX_BINS * 8);
+        total = o;
+    }
+};
+
+// kernels / launchers (defined in the .hip files)
+void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
+                       hipStream_t st);
+void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
+void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
+
+void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st);
+void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* offsets, uint64_t* keys,
+                      uint32_t* values, hipStream_t st);
+// sorts N (key,value) pairs on key bits [0,num_bits); result ends in (keys_a, vals_a).
+// returns which buffer the UNSORTED input must be placed in: 0 => (keys_a, vals_a), 1 => (keys_b, vals_b)
+int sort_input_buffer(int num_bits);
+void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
+                       uint32_t* totals, int64_t N, int num_bits, hipStream_t st);
+void launch_tile_ranges(const uint64_t* keys, int64_t N, uint2* ranges, int num_tiles, hipStream_t st);
+
+void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
+                          const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st);
+void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
+                           const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                           hipStream_t st);
+
+}  // namespace hgs

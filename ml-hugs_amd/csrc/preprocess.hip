@@ -1,0 +1,435 @@
+// Per-Gaussian kernels: forward projection (K1), fused per-Gaussian backward (K8+K9), markVisible (K10).
+// Algorithm: SURVEY.md Appendix A.2 / A.3 / A.5 (the arithmetic the reference obtains from
+// diff_gaussian_rasterization at /root/reference/hugs/renderer/gs_renderer.py:144-152).
+//
+// This translation unit is compiled with -ffp-contract=off: radius, tile rectangle, tiles_touched and
+// the depth bits are integer functions of fp32 arithmetic and must round exactly as written (they are
+// compared bit-for-bit against the CPU oracle).  Division and sqrt are IEEE (correctly rounded).
+#include "hgs_common.h"
+
+namespace hgs {
+
+__device__ __forceinline__ void sh_basis(int D, float x, float y, float z, float* B)
+{
+    B[0] = (float)0.28209479177387814;
+    if (D > 0) {
+        const float c1 = (float)0.4886025119029199;
+        B[1] = -c1 * y;
+        B[2] = c1 * z;
+        B[3] = -c1 * x;
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = (float)1.0925484305920792 * xy;
+            B[5] = (float)-1.0925484305920792 * yz;
+            B[6] = (float)0.31539156525252005 * (2.0f * zz - xx - yy);
+            B[7] = (float)-1.0925484305920792 * xz;
+            B[8] = (float)0.5462742152960396 * (xx - yy);
+            if (D > 2) {
+                B[9] = (float)-0.5900435899266435 * y * (3.0f * xx - yy);
+                B[10] = (float)2.890611442640554 * xy * z;
+                B[11] = (float)-0.4570457994644658 * y * (4.0f * zz - xx - yy);
+                B[12] = (float)0.3731763325901154 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                B[13] = (float)-0.4570457994644658 * x * (4.0f * zz - xx - yy);
+                B[14] = (float)1.445305721320277 * z * (xx - yy);
+                B[15] = (float)-0.5900435899266435 * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ sc, float mod,
+                                                     const float* __restrict__ q, float* S)
+{
+    float s0 = mod * sc[0], s1 = mod * sc[1], s2 = mod * sc[2];
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
+    float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
+    float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+    float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
+    float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
+    float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
+    S[0] = M00 * M00 + M01 * M01 + M02 * M02;
+    S[1] = M00 * M10 + M01 * M11 + M02 * M12;
+    S[2] = M00 * M20 + M01 * M21 + M02 * M22;
+    S[3] = M10 * M10 + M11 * M11 + M12 * M12;
+    S[4] = M10 * M20 + M11 * M21 + M12 * M22;
+    S[5] = M20 * M20 + M21 * M21 + M22 * M22;
+}
+
+struct Ewa {
+    float tx, ty, tz;
+    bool x_in, y_in;
+    float T00, T01, T02, T10, T11, T12;
+    float a, b, c;
+};
+
+// EWA projection of Sigma3D to screen space (A.2 step 4); shared by forward and backward.
+__device__ __forceinline__ void ewa_project(const float* pv, const Camera& cam, const float* __restrict__ V,
+                                            const float* S, Ewa& e)
+{
+    float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+    e.x_in = !(txtz < -limx || txtz > limx);
+    e.y_in = !(tytz < -limy || tytz > limy);
+    e.tx = fminf(limx, fmaxf(-limx, txtz)) * pv[2];
+    e.ty = fminf(limy, fmaxf(-limy, tytz)) * pv[2];
+    e.tz = pv[2];
+    float J00 = cam.fx / e.tz;
+    float J02 = -(cam.fx * e.tx) / (e.tz * e.tz);
+    float J11 = cam.fy / e.tz;
+    float J12 = -(cam.fy * e.ty) / (e.tz * e.tz);
+    e.T00 = J00 * V[0] + J02 * V[2];
+    e.T01 = J00 * V[4] + J02 * V[6];
+    e.T02 = J00 * V[8] + J02 * V[10];
+    e.T10 = J11 * V[1] + J12 * V[2];
+    e.T11 = J11 * V[5] + J12 * V[6];
+    e.T12 = J11 * V[9] + J12 * V[10];
+    float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
+    float u01 = S[1] * e.T00 + S[3] * e.T01 + S[4] * e.T02;
+    float u02 = S[2] * e.T00 + S[4] * e.T01 + S[5] * e.T02;
+    float u10 = S[0] * e.T10 + S[1] * e.T11 + S[2] * e.T12;
+    float u11 = S[1] * e.T10 + S[3] * e.T11 + S[4] * e.T12;
+    float u12 = S[2] * e.T10 + S[4] * e.T11 + S[5] * e.T12;
+    e.a = (e.T00 * u00 + e.T01 * u01 + e.T02 * u02) + 0.3f;
+    e.b = e.T00 * u10 + e.T01 * u11 + e.T02 * u12;
+    e.c = (e.T10 * u10 + e.T11 * u11 + e.T12 * u12) + 0.3f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one thread per Gaussian.
+__global__ void __launch_bounds__(256)
+preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                  const float* __restrict__ scales, const float* __restrict__ rots,
+                  const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
+                  const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
+                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+
+    Splat out;
+    out.x = out.y = out.ca = out.cb = out.cc = out.opacity = out.r = out.g = out.b = out.depth = 0.0f;
+    out.radius = 0;
+    out.clamped = 0;
+    uint32_t touched = 0;
+
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    float pv[3];
+    pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
+    pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
+    pv[2] = V[2] * x + V[6] * y + V[10] * z + V[14];
+    bool alive = pv[2] > NEAR_Z;  // NaN culls
+    if (alive) {
+        float hx = F[0] * x + F[4] * y + F[8] * z + F[12];
+        float hy = F[1] * x + F[5] * y + F[9] * z + F[13];
+        float hw = F[3] * x + F[7] * y + F[11] * z + F[15];
+        float pw = 1.0f / (hw + 0.0000001f);
+        float ndcx = hx * pw, ndcy = hy * pw;
+
+        float S[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            cov3d_from_scale_rot(scales + 3 * (size_t)i, cam.mod, rots + 4 * (size_t)i, S);
+        }
+        Ewa e;
+        ewa_project(pv, cam, V, S, e);
+        float det = e.a * e.c - e.b * e.b;
+        alive = !(det == 0.0f || det != det);
+        if (alive) {
+            float det_inv = 1.0f / det;
+            float mid = 0.5f * (e.a + e.c);
+            float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            float l1 = mid + sq, l2 = mid - sq;
+            float radf = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+            float px = ((ndcx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+            float py = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+            float fminx = fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
+            float fmaxx = fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
+            float fminy = fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
+            float fmaxy = fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
+            // non-finite centre or radius: culled (NaN compares false)
+            bool finite = (fabsf(px) <= 3.0e38f) && (fabsf(py) <= 3.0e38f) && (radf <= 1.0e9f);
+            int minx = (int)fminx, maxx = (int)fmaxx, miny = (int)fminy, maxy = (int)fmaxy;
+            alive = finite && maxx > minx && maxy > miny;
+            if (alive) {
+                out.x = px;
+                out.y = py;
+                out.ca = e.c * det_inv;
+                out.cb = -e.b * det_inv;
+                out.cc = e.a * det_inv;
+                out.opacity = opacities[i];
+                out.depth = pv[2];
+                out.radius = (int32_t)radf;
+                touched = (uint32_t)((maxx - minx) * (maxy - miny));
+                if (shs) {
+                    float dx = x - campos[0], dy = y - campos[1], dz = z - campos[2];
+                    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len, dy = dy / len, dz = dz / len;
+                    float B[16];
+                    sh_basis(cam.D, dx, dy, dz, B);
+                    const float* sh = shs + (size_t)i * cam.M * 3;
+                    const int K = (cam.D + 1) * (cam.D + 1);
+                    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+                    for (int k = 0; k < K; ++k) {
+                        acc0 += B[k] * sh[3 * k];
+                        acc1 += B[k] * sh[3 * k + 1];
+                        acc2 += B[k] * sh[3 * k + 2];
+                    }
+                    acc0 += 0.5f, acc1 += 0.5f, acc2 += 0.5f;
+                    out.clamped = (acc0 < 0.0f ? 1u : 0u) | (acc1 < 0.0f ? 2u : 0u) | (acc2 < 0.0f ? 4u : 0u);
+                    out.r = fmaxf(acc0, 0.0f), out.g = fmaxf(acc1, 0.0f), out.b = fmaxf(acc2, 0.0f);
+                } else {
+                    out.r = colors_precomp[3 * (size_t)i], out.g = colors_precomp[3 * (size_t)i + 1];
+                    out.b = colors_precomp[3 * (size_t)i + 2];
+                }
+            }
+        }
+    }
+    if (!alive) {
+        out.x = out.y = out.ca = out.cb = out.cc = out.opacity = out.depth = 0.0f;
+        out.radius = 0;
+    }
+    float4* dst = reinterpret_cast<float4*>(splats + i);
+    dst[0] = make_float4(out.x, out.y, out.ca, out.cb);
+    dst[1] = make_float4(out.cc, out.opacity, out.r, out.g);
+    dst[2] = make_float4(out.b, out.depth, __int_as_float(out.radius), __uint_as_float(out.clamped));
+    tiles_touched[i] = touched;
+    radii[i] = out.radius;
+}
+
+void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
+                       hipStream_t st)
+{
+    int blocks = (a.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
+                       a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
+                       a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8+K9 fused: one thread per Gaussian, only radius > 0 does work.  Outputs are pre-zeroed by the caller.
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                           const float* __restrict__ scales, const float* __restrict__ rots,
+                           const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
+                           const float* __restrict__ F, const float* __restrict__ campos,
+                           const Splat* __restrict__ splats, const float* __restrict__ dL_dmean2D,
+                           const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolors,
+                           float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dsh,
+                           float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                           float* __restrict__ dL_dcov3D)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
+    if (__float_as_int(tail.z) <= 0) return;
+    const uint32_t clamped = __float_as_uint(tail.w);
+
+    const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+    float pv[3];
+    pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
+    pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
+    pv[2] = V[2] * x + V[6] * y + V[10] * z + V[14];
+    float S[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * (size_t)i + k];
+    } else {
+        cov3d_from_scale_rot(scales + 3 * (size_t)i, cam.mod, rots + 4 * (size_t)i, S);
+    }
+    Ewa e;
+    ewa_project(pv, cam, V, S, e);
+    const float a = e.a, b = e.b, c = e.c;
+    const float4 gcon = reinterpret_cast<const float4*>(dL_dconic)[i];
+    const float gxx = gcon.x, gxy = gcon.y, gyy = gcon.w;
+    const float denom = a * c - b * b;
+    const float d2inv = 1.0f / (denom * denom + 0.0000001f);
+    float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
+    float dS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (d2inv != 0.0f) {
+        dL_da = d2inv * (-c * c * gxx + 2.0f * b * c * gxy + (denom - a * c) * gyy);
+        dL_dc = d2inv * (-a * a * gyy + 2.0f * a * b * gxy + (denom - a * c) * gxx);
+        dL_db = d2inv * 2.0f * (b * c * gxx - (denom + 2.0f * b * b) * gxy + a * b * gyy);
+        dS[0] = e.T00 * e.T00 * dL_da + e.T00 * e.T10 * dL_db + e.T10 * e.T10 * dL_dc;
+        dS[3] = e.T01 * e.T01 * dL_da + e.T01 * e.T11 * dL_db + e.T11 * e.T11 * dL_dc;
+        dS[5] = e.T02 * e.T02 * dL_da + e.T02 * e.T12 * dL_db + e.T12 * e.T12 * dL_dc;
+        dS[1] = 2.0f * e.T00 * e.T01 * dL_da + (e.T00 * e.T11 + e.T01 * e.T10) * dL_db + 2.0f * e.T10 * e.T11 * dL_dc;
+        dS[2] = 2.0f * e.T00 * e.T02 * dL_da + (e.T00 * e.T12 + e.T02 * e.T10) * dL_db + 2.0f * e.T10 * e.T12 * dL_dc;
+        dS[4] = 2.0f * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2.0f * e.T11 * e.T12 * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+
+    // dL/dT (2x3) -> dL/dJ -> dL/dt (view-space mean), with the frustum-clamp masks (A.6 quirk 2)
+    float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
+    float u01 = S[1] * e.T00 + S[3] * e.T01 + S[4] * e.T02;
+    float u02 = S[2] * e.T00 + S[4] * e.T01 + S[5] * e.T02;
+    float u10 = S[0] * e.T10 + S[1] * e.T11 + S[2] * e.T12;
+    float u11 = S[1] * e.T10 + S[3] * e.T11 + S[4] * e.T12;
+    float u12 = S[2] * e.T10 + S[4] * e.T11 + S[5] * e.T12;
+    float dT00 = 2.0f * u00 * dL_da + u10 * dL_db, dT01 = 2.0f * u01 * dL_da + u11 * dL_db;
+    float dT02 = 2.0f * u02 * dL_da + u12 * dL_db;
+    float dT10 = 2.0f * u10 * dL_dc + u00 * dL_db, dT11 = 2.0f * u11 * dL_dc + u01 * dL_db;
+    float dT12 = 2.0f * u12 * dL_dc + u02 * dL_db;
+    float dJ00 = V[0] * dT00 + V[4] * dT01 + V[8] * dT02;
+    float dJ02 = V[2] * dT00 + V[6] * dT01 + V[10] * dT02;
+    float dJ11 = V[1] * dT10 + V[5] * dT11 + V[9] * dT12;
+    float dJ12 = V[2] * dT10 + V[6] * dT11 + V[10] * dT12;
+    float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dtx = (e.x_in ? 1.0f : 0.0f) * (-cam.fx * tz2 * dJ02);
+    float dty = (e.y_in ? 1.0f : 0.0f) * (-cam.fy * tz2 * dJ12);
+    float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.0f * cam.fx * e.tx) * tz3 * dJ02 +
+                (2.0f * cam.fy * e.ty) * tz3 * dJ12;
+    float dm0 = V[0] * dtx + V[1] * dty + V[2] * dtz;
+    float dm1 = V[4] * dtx + V[5] * dty + V[6] * dtz;
+    float dm2 = V[8] * dtx + V[9] * dty + V[10] * dtz;
+
+    // mean2D (NDC-scaled) -> mean
+    {
+        float hx = F[0] * x + F[4] * y + F[8] * z + F[12];
+        float hy = F[1] * x + F[5] * y + F[9] * z + F[13];
+        float hw = F[3] * x + F[7] * y + F[11] * z + F[15];
+        float mw = 1.0f / (hw + 0.0000001f);
+        float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+        float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
+        dm0 += (F[0] * mw - F[3] * mul1) * g2x + (F[1] * mw - F[3] * mul2) * g2y;
+        dm1 += (F[4] * mw - F[7] * mul1) * g2x + (F[5] * mw - F[7] * mul2) * g2y;
+        dm2 += (F[8] * mw - F[11] * mul1) * g2x + (F[9] * mw - F[11] * mul2) * g2y;
+    }
+
+    // SH backward
+    if (shs) {
+        float dr0 = (clamped & 1u) ? 0.0f : dL_dcolors[3 * (size_t)i];
+        float dr1 = (clamped & 2u) ? 0.0f : dL_dcolors[3 * (size_t)i + 1];
+        float dr2 = (clamped & 4u) ? 0.0f : dL_dcolors[3 * (size_t)i + 2];
+        float vx = x - campos[0], vy = y - campos[1], vz = z - campos[2];
+        float len = sqrtf(vx * vx + vy * vy + vz * vz);
+        float X = vx / len, Y = vy / len, Z = vz / len;
+        const int D = cam.D;
+        const float* sh = shs + (size_t)i * cam.M * 3;
+        float* dsh = dL_dsh + (size_t)i * cam.M * 3;
+        float B[16];
+        sh_basis(D, X, Y, Z, B);
+        const int K = (D + 1) * (D + 1);
+        for (int k = 0; k < K; ++k) {
+            dsh[3 * k] = B[k] * dr0;
+            dsh[3 * k + 1] = B[k] * dr1;
+            dsh[3 * k + 2] = B[k] * dr2;
+        }
+        float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+#define SHW(k) (sh[3 * (k)] * dr0 + sh[3 * (k) + 1] * dr1 + sh[3 * (k) + 2] * dr2)
+        if (D > 0) {
+            const float c1 = (float)0.4886025119029199;
+            ddy += -c1 * SHW(1);
+            ddz += c1 * SHW(2);
+            ddx += -c1 * SHW(3);
+            if (D > 1) {
+                const float c20 = (float)1.0925484305920792, c21 = (float)-1.0925484305920792,
+                            c22 = (float)0.31539156525252005, c23 = (float)-1.0925484305920792,
+                            c24 = (float)0.5462742152960396;
+                float xx = X * X, yy = Y * Y, zz = Z * Z;
+                float w4 = SHW(4), w5 = SHW(5), w6 = SHW(6), w7 = SHW(7), w8 = SHW(8);
+                ddx += c20 * Y * w4 + c22 * -2.0f * X * w6 + c23 * Z * w7 + c24 * 2.0f * X * w8;
+                ddy += c20 * X * w4 + c21 * Z * w5 + c22 * -2.0f * Y * w6 + c24 * -2.0f * Y * w8;
+                ddz += c21 * Y * w5 + c22 * 4.0f * Z * w6 + c23 * X * w7;
+                if (D > 2) {
+                    const float c30 = (float)-0.5900435899266435, c31 = (float)2.890611442640554,
+                                c32 = (float)-0.4570457994644658, c33 = (float)0.3731763325901154,
+                                c34 = (float)-0.4570457994644658, c35 = (float)1.445305721320277,
+                                c36 = (float)-0.5900435899266435;
+                    float w9 = SHW(9), w10 = SHW(10), w11 = SHW(11), w12 = SHW(12), w13 = SHW(13), w14 = SHW(14),
+                          w15 = SHW(15);
+                    ddx += c30 * 6.0f * X * Y * w9 + c31 * Y * Z * w10 + c32 * -2.0f * X * Y * w11 +
+                           c33 * -6.0f * X * Z * w12 + c34 * (4.0f * zz - 3.0f * xx - yy) * w13 +
+                           c35 * 2.0f * X * Z * w14 + c36 * (3.0f * xx - 3.0f * yy) * w15;
+                    ddy += c30 * (3.0f * xx - 3.0f * yy) * w9 + c31 * X * Z * w10 +
+                           c32 * (4.0f * zz - xx - 3.0f * yy) * w11 + c33 * -6.0f * Y * Z * w12 +
+                           c34 * -2.0f * X * Y * w13 + c35 * -2.0f * Y * Z * w14 + c36 * -6.0f * X * Y * w15;
+                    ddz += c31 * X * Y * w10 + c32 * 8.0f * Y * Z * w11 +
+                           c33 * (6.0f * zz - 3.0f * xx - 3.0f * yy) * w12 + c34 * 8.0f * X * Z * w13 +
+                           c35 * (xx - yy) * w14;
+                }
+            }
+        }
+#undef SHW
+        float s2 = vx * vx + vy * vy + vz * vz;
+        float inv32 = 1.0f / sqrtf(s2 * s2 * s2);
+        dm0 += ((s2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+        dm1 += (-vx * vy * ddx + (s2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+        dm2 += (-vx * vz * ddx - vy * vz * ddy + (s2 - vz * vz) * ddz) * inv32;
+    }
+    dL_dmeans3D[3 * (size_t)i] = dm0;
+    dL_dmeans3D[3 * (size_t)i + 1] = dm1;
+    dL_dmeans3D[3 * (size_t)i + 2] = dm2;
+
+    // Sigma3D -> scale, quaternion (quaternion gradient w.r.t. the UN-normalised q)
+    if (!cov3D_precomp) {
+        const float mod = cam.mod;
+        const float r = rots[4 * (size_t)i], qx = rots[4 * (size_t)i + 1], qy = rots[4 * (size_t)i + 2],
+                    qz = rots[4 * (size_t)i + 3];
+        const float s[3] = {mod * scales[3 * (size_t)i], mod * scales[3 * (size_t)i + 1],
+                            mod * scales[3 * (size_t)i + 2]};
+        const float R[3][3] = {
+            {1.0f - 2.0f * (qy * qy + qz * qz), 2.0f * (qx * qy - r * qz), 2.0f * (qx * qz + r * qy)},
+            {2.0f * (qx * qy + r * qz), 1.0f - 2.0f * (qx * qx + qz * qz), 2.0f * (qy * qz - r * qx)},
+            {2.0f * (qx * qz - r * qy), 2.0f * (qy * qz + r * qx), 1.0f - 2.0f * (qx * qx + qy * qy)}};
+        const float Gs[3][3] = {{dS[0], 0.5f * dS[1], 0.5f * dS[2]},
+                                {0.5f * dS[1], dS[3], 0.5f * dS[4]},
+                                {0.5f * dS[2], 0.5f * dS[4], dS[5]}};
+        float dR[3][3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            float dMc[3];
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) acc += Gs[ii][kk] * (R[kk][jj] * s[jj]);
+                dMc[ii] = 2.0f * acc;
+            }
+            float ds = R[0][jj] * dMc[0] + R[1][jj] * dMc[1] + R[2][jj] * dMc[2];
+            dL_dscale[3 * (size_t)i + jj] = mod * ds;
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) dR[ii][jj] = s[jj] * dMc[ii];
+        }
+        float4 dq;
+        dq.x = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        dq.y = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - r * dR[1][2] +
+                       qz * dR[2][0] + r * dR[2][1] - 2.0f * qx * dR[2][2]);
+        dq.z = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+                       r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+        dq.w = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] +
+                       qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        reinterpret_cast<float4*>(dL_drot)[i] = dq;
+    }
+}
+
+void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st)
+{
+    const hgs_forward_args& f = a.fwd;
+    int blocks = (f.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, f.P, cam, f.means3D, f.shs,
+                       f.scales, f.rotations, f.cov3D_precomp, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
+                       a.dL_dmeans2D, a.dL_dconic, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
+                       a.dL_drotations, a.dL_dcov3D);
+}
+
+// K10
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ V,
+                                    uint8_t* __restrict__ present)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float z = V[2] * means3D[3 * (size_t)i] + V[6] * means3D[3 * (size_t)i + 1] + V[10] * means3D[3 * (size_t)i + 2] + V[14];
+    present[i] = z > NEAR_Z ? 1 : 0;
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, V, present);
+}
+
+}  // namespace hgs

@@ -1,0 +1,365 @@
+"""Drop-in replacement for the `diff_gaussian_rasterization` module the reference imports at
+/root/reference/hugs/renderer/gs_renderer.py:11-14 and uses at :126-152.
+
+Same two public names, same field order / kwargs / return values / error behaviour as the
+2023 upstream API the reference was written against (12-field settings tuple, 2-tuple return):
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings).forward(means3D, means2D, opacities, shs=None,
+        colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None) -> (color, radii)
+    GaussianRasterizer.markVisible(positions) -> bool[P]
+
+All arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI of
+include/hgs_rasterizer.h (libhgs_rasterizer.so, bound here with ctypes).  There is NO CPU or
+PyTorch fallback: if the library is missing or a tensor is not on the GPU this module raises.
+PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+import ctypes as C
+import os
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "library_path"]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
+_ABI_VERSION = 1
+
+
+def library_path():
+    return _LIB_PATH
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes mirror of include/hgs_rasterizer.h
+class _Settings(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("bg", C.c_void_p), ("scale_modifier", C.c_float),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("sh_degree", C.c_int32),
+                ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+
+
+class _ForwardArgs(C.Structure):
+    _fields_ = [("s", _Settings), ("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p),
+                ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
+                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+                ("out_color", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class _ForwardState(C.Structure):
+    _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
+                ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
+                ("num_rendered", C.c_int64)]
+
+
+class _BackwardArgs(C.Structure):
+    _fields_ = [("fwd", _ForwardArgs), ("state", _ForwardState), ("dL_dout_color", C.c_void_p),
+                ("dL_dmeans2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p)]
+
+
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+_lib = None
+
+
+def _load():
+    """Load the HIP library; fail loudly (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"diff_gaussian_rasterization (MI355X): {_LIB_PATH} not found. Build it with "
+            "`make -C ml-hugs_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    lib.hgs_abi_version.restype = C.c_int32
+    if lib.hgs_abi_version() != _ABI_VERSION:
+        raise RuntimeError("libhgs_rasterizer.so ABI version mismatch; rebuild it")
+    lib.hgs_rasterize_forward.restype = C.c_int64
+    lib.hgs_rasterize_forward.argtypes = [C.POINTER(_ForwardArgs), _ALLOC_FN, C.c_void_p,
+                                          C.POINTER(_ForwardState), C.c_void_p]
+    lib.hgs_rasterize_backward.restype = C.c_int32
+    lib.hgs_rasterize_backward.argtypes = [C.POINTER(_BackwardArgs), C.c_void_p]
+    lib.hgs_mark_visible.restype = C.c_int32
+    lib.hgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hgs_last_error.restype = C.c_char_p
+    for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_scratch_offset):
+        fn.restype = C.c_size_t
+    lib.hgs_geom_bytes.argtypes = [C.c_int32]
+    lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+    _lib = lib
+    return lib
+
+
+def _raise_last(lib, what):
+    raise RuntimeError(f"{what}: {lib.hgs_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _f32c(t):
+    """contiguous fp32 (upstream calls .contiguous() on every input); None / empty -> None"""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"diff_gaussian_rasterization (MI355X): `{name}` must live on the GPU "
+                           "(HIP device); there is no CPU fallback")
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _fill_settings(s, rs, keep):
+    dev = keep["device"]
+    bg, vm, pm, cp = (_f32c(x.to(dev)) for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
+    keep["settings_tensors"] = (bg, vm, pm, cp)
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    s.bg, s.viewmatrix, s.projmatrix, s.campos = bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
+    s.scale_modifier = float(rs.scale_modifier)
+    s.sh_degree = int(rs.sh_degree)
+    s.prefiltered = int(bool(rs.prefiltered))
+    s.debug = int(bool(rs.debug))
+
+
+def _fill_forward(a, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, keep):
+    _fill_settings(a.s, rs, keep)
+    a.P = int(means3D.shape[0])
+    a.M = int(sh.shape[1]) if sh is not None else 0
+    a.means3D, a.shs, a.colors_precomp = _ptr(means3D), _ptr(sh), _ptr(colors_precomp)
+    a.opacities, a.scales, a.rotations = _ptr(opacities), _ptr(scales), _ptr(rotations)
+    a.cov3D_precomp = _ptr(cov3D_precomp)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        lib = _load()
+        _require_gpu(means3D, "means3D")
+        dev = means3D.device
+        rs = raster_settings
+        means3D = _f32c(means3D) if means3D.numel() else means3D.float().reshape(0, 3)
+        if means3D.ndim != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        sh, colors_precomp, opacities = _f32c(sh), _f32c(colors_precomp), _f32c(opacities)
+        scales, rotations, cov3Ds_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+
+        # P == 0: nothing is launched and colour stays zero (no background) -- upstream behaviour
+        color = torch.zeros(3, H, W, dtype=torch.float32, device=dev) if P == 0 else \
+            torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+
+        keep = {"device": dev}
+        bufs = {}
+
+        def _alloc(_ctx, which, nbytes):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            bufs[which] = t
+            return t.data_ptr()
+
+        cb = _ALLOC_FN(_alloc)
+        args, state = _ForwardArgs(), _ForwardState()
+        _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
+        args.out_color, args.radii = color.data_ptr(), _ptr(radii)
+        with torch.cuda.device(dev):
+            n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), _stream_ptr(dev))
+        if n < 0:
+            _raise_last(lib, "rasterize_gaussians")
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(n)
+        ctx.state = (state.geom_bytes, state.binning_bytes, state.image_bytes)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(means3D,
+                              sh if sh is not None else empty,
+                              colors_precomp if colors_precomp is not None else empty,
+                              opacities if opacities is not None else empty,
+                              scales if scales is not None else empty,
+                              rotations if rotations is not None else empty,
+                              cov3Ds_precomp if cov3Ds_precomp is not None else empty,
+                              radii, bufs.get(0, empty), bufs.get(1, empty), bufs.get(2, empty))
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        lib = _load()
+        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
+         image) = ctx.saved_tensors
+        rs = ctx.raster_settings
+        dev = means3D.device
+        P = means3D.shape[0]
+        M = sh.shape[1] if sh.numel() else 0
+        none_if_empty = lambda t: t if t.numel() else None
+
+        # one zero-filled slab carved into the nine gradient tensors (one memset instead of nine)
+        sizes = [3 * P, 4 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += (s + 63) // 64 * 64
+        slab = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
+        view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
+        g_means2D, g_conic, g_opacity = view(0, P, 3), view(1, P, 2, 2), view(2, P, 1)
+        g_colors, g_means3D, g_cov3D = view(3, P, 3), view(4, P, 3), view(5, P, 6)
+        g_sh, g_scales, g_rot = view(6, P, M, 3), view(7, P, 3), view(8, P, 4)
+
+        if P > 0:
+            keep = {"device": dev}
+            a = _BackwardArgs()
+            _fill_forward(a.fwd, rs, means3D, none_if_empty(sh), none_if_empty(colors_precomp),
+                          none_if_empty(opacities), none_if_empty(scales), none_if_empty(rotations),
+                          none_if_empty(cov3Ds_precomp), keep)
+            a.fwd.radii = _ptr(radii)
+            a.state.geom, a.state.binning, a.state.image = _ptr(geom), _ptr(binning), _ptr(image)
+            a.state.geom_bytes, a.state.binning_bytes, a.state.image_bytes = ctx.state
+            a.state.num_rendered = ctx.num_rendered
+            grad_out_color = _f32c(grad_out_color)
+            a.dL_dout_color = grad_out_color.data_ptr()
+            a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity = g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity.data_ptr()
+            a.dL_dcolors, a.dL_dmeans3D, a.dL_dcov3D = g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr()
+            a.dL_dsh = g_sh.data_ptr() if M else None
+            a.dL_dscales, a.dL_drotations = g_scales.data_ptr(), g_rot.data_ptr()
+            with torch.cuda.device(dev):
+                rc = lib.hgs_rasterize_backward(C.byref(a), _stream_ptr(dev))
+            if rc < 0:
+                _raise_last(lib, "rasterize_gaussians_backward")
+
+        # order of forward's inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+        # cov3Ds_precomp, raster_settings
+        return (g_means3D, g_means2D,
+                g_sh if sh.numel() else None,
+                g_colors if colors_precomp.numel() else None,
+                g_opacity,
+                g_scales if scales.numel() else None,
+                g_rot if rotations.numel() else None,
+                g_cov3D if cov3Ds_precomp.numel() else None,
+                None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: view-space z > 0.2 (upstream's frustum pre-filter; unused by the reference)."""
+        lib = _load()
+        _require_gpu(positions, "positions")
+        with torch.no_grad():
+            pos = _f32c(positions)
+            P = 0 if pos is None else pos.shape[0]
+            present = torch.zeros(P, dtype=torch.bool, device=positions.device)
+            if P:
+                vm = _f32c(self.raster_settings.viewmatrix.to(positions.device))
+                with torch.cuda.device(positions.device):
+                    rc = lib.hgs_mark_visible(P, pos.data_ptr(), vm.data_ptr(), present.data_ptr(),
+                                              _stream_ptr(positions.device))
+                if rc < 0:
+                    _raise_last(lib, "mark_visible")
+        return present
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, raster_settings)
+
+
+# ---------------------------------------------------------------------------------------------
+# introspection used by the stage-level parity tests (not part of the reference API)
+def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_precomp=None, scales=None,
+                         rotations=None, cov3D_precomp=None):
+    """Run forward and return (color, radii, dict of raw scratch sub-arrays as torch tensors)."""
+    lib = _load()
+    rs = raster_settings
+    e = torch.empty(0, device=means3D.device)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    holder = {}
+
+    class _Probe(_RasterizeGaussians):
+        pass
+
+    m3 = means3D.detach().requires_grad_(True)
+    color, radii = _RasterizeGaussians.apply(m3, means2D, shs if shs is not None else e,
+                                             colors_precomp if colors_precomp is not None else e, opacities,
+                                             scales if scales is not None else e,
+                                             rotations if rotations is not None else e,
+                                             cov3D_precomp if cov3D_precomp is not None else e, rs)
+    saved = color.grad_fn.saved_tensors
+    geom, binning, image = saved[8], saved[9], saved[10]
+    P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+    N = color.grad_fn.num_rendered
+    off = lambda name: lib.hgs_scratch_offset(name.encode(), P, N, H, W)
+    T = ((H + 15) // 16) * ((W + 15) // 16)
+
+    def sub(buf, name, nbytes, dtype):
+        o = off(name)
+        return buf[o:o + nbytes].view(dtype)
+
+    if P > 0:
+        holder["splats"] = sub(geom, "splats", 48 * P, torch.float32).view(P, 12)
+        holder["tiles_touched"] = sub(geom, "tiles_touched", 4 * P, torch.int32)
+        holder["offsets"] = sub(geom, "offsets", 4 * P, torch.int32)
+        holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
+        holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W)
+        holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
+        holder["keys"] = sub(binning, "keys", 8 * N, torch.int64)
+        holder["values"] = sub(binning, "values", 4 * N, torch.int32)
+    holder["N"] = N
+    return color.detach(), radii, holder

@@ -46,6 +46,7 @@ typedef REAL real;
 
 static inline real rmin(real a, real b) { return a < b ? a : b; }
 static inline real rmax(real a, real b) { return a > b ? a : b; }
+static inline real rabs_(real a) { return a < 0 ? -a : a; }
 static inline real rsqrt_(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
 static inline real rexp_(real x) { return sizeof(real) == 4 ? (real)expf((float)x) : (real)exp((double)x); }
 static inline real rceil_(real x) { return sizeof(real) == 4 ? (real)ceilf((float)x) : (real)ceil((double)x); }
@@ -231,7 +232,9 @@ void oracle_preprocess(int P, int M, int D, int H, int W, real tanfovx, real tan
         real fmaxx = rmin((real)gx, rmax(R_(0), (px + radf + R_(15)) / R_(16)));
         real fminy = rmin((real)gy, rmax(R_(0), (py - radf) / R_(16)));
         real fmaxy = rmin((real)gy, rmax(R_(0), (py + radf + R_(15)) / R_(16)));
-        if (!(fminx == fminx) || !(fmaxx == fmaxx) || !(fminy == fminy) || !(fmaxy == fmaxy)) continue;
+        /* non-finite centre or radius: culled (defined behaviour for inputs where upstream's
+           float->int conversion would be undefined) */
+        if (!(rabs_(px) <= R_(3.0e38)) || !(rabs_(py) <= R_(3.0e38)) || !(radf <= R_(1.0e9))) continue;
         int minx = (int)fminx, maxx = (int)fmaxx, miny = (int)fminy, maxy = (int)fmaxy;
         if (maxx <= minx || maxy <= miny) continue;
 

@@ -1,0 +1,93 @@
+"""Seeded test scenes shared by the CPU and GPU tests (inputs only; no expected values)."""
+import math
+
+import numpy as np
+
+from hugs_amd import synthetic as syn
+
+
+def look_at_w2c(eye, target=(0, 0, 0), up=(0, -1, 0)):
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(up, f)
+    r /= np.linalg.norm(r)
+    u = np.cross(f, r)
+    R = np.stack([r, u, f], 0)
+    w2c = np.eye(4)
+    w2c[:3, :3] = R
+    w2c[:3, 3] = -R @ eye
+    return w2c
+
+
+def make_scene(P, H, W, seed=0, D=3, M=16, sigma_px=6.0, focal_frac=0.6, bg=(1.0, 1.0, 1.0), nonunit_quat=True,
+               rotated_camera=False, colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0,
+               opaque=False, wide=False, with_culled=True):
+    """Returns a dict of numpy arrays + camera dict. Gaussians are generated in the camera frame of an
+    identity-pose camera and then moved to world space when `rotated_camera` is set."""
+    rng = np.random.default_rng(1000 + seed)
+    cam0 = syn.pinhole_camera(H, W, focal_frac=focal_frac)
+    g = syn.scene_gaussians(P, cam0, seed=seed, sh_coeffs=M, sigma_px=sigma_px, nonunit_quat=nonunit_quat, ref_P=max(P, 1))
+    means = g["means3D"].astype(np.float64)
+    if P and wide:  # push some means outside the +-1.3 tanfov frustum clamp, keep them big enough to reach the image
+        k = max(1, P // 5)
+        idx = rng.choice(P, k, replace=False)
+        means[idx, 0] *= rng.uniform(1.3, 1.8, k)
+        g["scales"][idx] *= 6.0
+    if P and with_culled:  # a few behind / too near the camera
+        k = max(1, P // 10)
+        idx = rng.choice(P, k, replace=False)
+        means[idx, 2] = rng.uniform(-2.0, 0.2, k)
+    if P and opaque:
+        g["opacities"][:] = rng.uniform(0.9, 1.0, (P, 1))
+    cam = cam0
+    if rotated_camera:
+        w2c = look_at_w2c(eye=(1.5, -0.8, -3.0), target=(0.2, 0.1, 6.0))
+        c2w = np.linalg.inv(w2c)
+        means = (c2w[:3, :3] @ means.T).T + c2w[:3, 3]
+        cam = syn.camera_from_w2c(w2c, cam0["fovx"], cam0["fovy"], H, W)
+    out = dict(g)
+    out["means3D"] = means.astype(np.float32)
+    out.update(cam=cam, H=H, W=W, D=D, M=M, bg=np.asarray(bg, np.float32), scale_modifier=scale_modifier,
+               tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5))
+    if colors_precomp:
+        out["colors_precomp"] = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+        out["shs"] = None
+    else:
+        out["colors_precomp"] = None
+    if cov3D_precomp:
+        from oracle import hgs_oracle as ho
+        out["cov3D_precomp"] = ho.cov3d(out["scales"], out["rotations"], 1.0) if P else np.zeros((0, 6), np.float32)
+        out["scales"] = None
+        out["rotations"] = None
+    else:
+        out["cov3D_precomp"] = None
+    out["dL_dpix"] = rng.standard_normal((3, H, W)).astype(np.float32)
+    return out
+
+
+def oracle_inputs(sc, dtype=np.float32):
+    from oracle import hgs_oracle as ho
+    cam = sc["cam"]
+    return ho.Inputs(sc["means3D"], sc["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                     cam["camera_center"], sc["tanfovx"], sc["tanfovy"], sc["H"], sc["W"], sc["bg"], shs=sc["shs"],
+                     colors_precomp=sc["colors_precomp"], scales=sc["scales"], rotations=sc["rotations"],
+                     cov3D_precomp=sc["cov3D_precomp"], sh_degree=sc["D"], scale_modifier=sc["scale_modifier"],
+                     dtype=dtype)
+
+
+# name -> kwargs; small enough for the fp32 C oracle to finish instantly
+CASES = {
+    "basic_d3": dict(P=300, H=96, W=128, seed=0, D=3),
+    "rotcam_d2": dict(P=400, H=80, W=112, seed=1, D=2, rotated_camera=True),
+    "deg0_M16": dict(P=256, H=64, W=64, seed=2, D=0),
+    "deg1_ragged": dict(P=333, H=70, W=100, seed=3, D=1),           # image not a multiple of 16
+    "precomp_rgb": dict(P=200, H=64, W=96, seed=4, colors_precomp=True),
+    "precomp_cov": dict(P=200, H=64, W=96, seed=5, D=3, cov3D_precomp=True),
+    "opaque_earlystop": dict(P=600, H=64, W=64, seed=6, D=0, opaque=True, sigma_px=10.0),
+    "wide_clamp": dict(P=300, H=96, W=96, seed=7, D=3, wide=True),
+    "scale_mod": dict(P=200, H=64, W=64, seed=8, D=3, scale_modifier=0.5),
+    "black_bg_unitq": dict(P=200, H=48, W=80, seed=9, D=3, bg=(0.0, 0.0, 0.0), nonunit_quat=False),
+    "single": dict(P=1, H=32, W=32, seed=10, D=3, with_culled=False, sigma_px=8.0),
+    "big_splats": dict(P=64, H=128, W=128, seed=11, D=3, sigma_px=40.0),
+}

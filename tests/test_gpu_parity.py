@@ -1,0 +1,248 @@
+"""GPU parity tests proper: the HIP path, called through the drop-in Python API (which goes through the
+C ABI of include/hgs_rasterizer.h), against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star "bit-exact for tile/key indexing"):
+  * integers -- radii, tiles_touched, offsets, N, sorted (key,value) list, tile ranges -- EXACT
+  * per-Gaussian fp32 projection outputs (pixel xy, depth, conic, colour) -- bit-exact (same op order,
+    IEEE div/sqrt, no contraction)
+  * blend: the only arithmetic difference vs the oracle is the GPU's exp; a pixel whose alpha sits
+    within an ulp of a threshold (1/255, T<1e-4) may take the other branch, so:
+      colour / final_T: |d| <= 1e-4 on >= 99.98 % of pixels, every pixel within 2/255; mean |d| <= 2e-6
+      n_contrib: equal on >= 99.98 % of pixels
+  * gradients: relative L2 error <= 1e-3 per tensor (float atomics: summation order varies)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hgs_oracle as ho
+from scenes import CASES, make_scene, oracle_inputs
+
+pytestmark = pytest.mark.gpu
+
+COLOR_TOL, COLOR_OUTLIER_TOL, COLOR_INLIER_FRAC, COLOR_MEAN_TOL = 1e-4, 2.0 / 255.0, 0.9998, 2e-6
+GRAD_REL_TOL = 1e-3
+
+
+def to_dev(a, device, grad=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return t.requires_grad_(True) if grad else t
+
+
+def gpu_settings(sc, device, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    cam = sc["cam"]
+    return GaussianRasterizationSettings(
+        image_height=sc["H"], image_width=sc["W"], tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"],
+        bg=to_dev(sc["bg"], device), scale_modifier=sc["scale_modifier"],
+        viewmatrix=to_dev(cam["world_view_transform"], device), projmatrix=to_dev(cam["full_proj_transform"], device),
+        sh_degree=sc["D"], campos=to_dev(cam["camera_center"], device), prefiltered=False, debug=debug)
+
+
+def gpu_tensors(sc, device, grad=True):
+    t = {k: to_dev(sc[k], device, grad) for k in ("means3D", "opacities", "shs", "colors_precomp", "scales",
+                                                   "rotations", "cov3D_precomp")}
+    t["means2D"] = torch.zeros(sc["means3D"].shape, dtype=torch.float32, device=device, requires_grad=True)
+    return t
+
+
+def run_gpu(sc, device, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    t = gpu_tensors(sc, device)
+    rast = GaussianRasterizer(gpu_settings(sc, device, debug))
+    color, radii = rast(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"],
+                        colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"],
+                        cov3D_precomp=t["cov3D_precomp"])
+    return t, color, radii
+
+
+def check_image(gpu, ref, what):
+    d = np.abs(gpu.astype(np.float64) - ref.astype(np.float64))
+    assert d.max() <= COLOR_OUTLIER_TOL, f"{what}: max |d| = {d.max():.3e}"
+    frac = float((d <= COLOR_TOL).mean())
+    assert frac >= COLOR_INLIER_FRAC or (d > COLOR_TOL).sum() <= 2, f"{what}: only {frac:.6f} within {COLOR_TOL}"
+    assert d.mean() <= COLOR_MEAN_TOL, f"{what}: mean |d| = {d.mean():.3e}"
+
+
+def rel_l2(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    n = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / n if n > 0 else np.linalg.norm(a)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_stages_and_image(name, device):
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(**CASES[name])
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            colors_precomp=t["colors_precomp"], scales=t["scales"],
+                                            rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+    torch.cuda.synchronize()
+    P = inp.P
+    # ---- K1: integers exact, fp32 outputs bit-exact
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    assert np.array_equal(st["tiles_touched"].cpu().numpy().view(np.uint32), ref["tiles_touched"])
+    sp = st["splats"].cpu().numpy()
+    vis = ref["radii"] > 0
+    assert np.array_equal(sp[:, 10].view(np.int32), ref["radii"])
+    for col, (refarr, label) in {0: (ref["xy"][:, 0], "x"), 1: (ref["xy"][:, 1], "y"),
+                                 2: (ref["conic_opacity"][:, 0], "conic.x"), 3: (ref["conic_opacity"][:, 1], "conic.y"),
+                                 4: (ref["conic_opacity"][:, 2], "conic.z"), 5: (ref["conic_opacity"][:, 3], "opacity"),
+                                 6: (ref["rgb"][:, 0], "r"), 7: (ref["rgb"][:, 1], "g"), 8: (ref["rgb"][:, 2], "b"),
+                                 9: (ref["depths"], "depth")}.items():
+        a, b = sp[vis, col].view(np.uint32), np.ascontiguousarray(refarr[vis]).view(np.uint32)
+        assert np.array_equal(a, b), f"{name}: splat field {label} not bit-exact ({(a != b).sum()} of {vis.sum()})"
+    clamp_bits = ref["clamped"][:, 0] | (ref["clamped"][:, 1] << 1) | (ref["clamped"][:, 2] << 2)
+    assert np.array_equal(sp[vis, 11].view(np.uint32), clamp_bits[vis].astype(np.uint32))
+    # ---- K2..K5 exact
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["offsets"].cpu().numpy().view(np.uint32), ref["offsets"])
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    # ---- K6
+    check_image(color.cpu().numpy(), ref["color"], f"{name} colour")
+    check_image(st["final_T"].cpu().numpy(), ref["final_T"], f"{name} final_T")
+    nc = st["n_contrib"].cpu().numpy().view(np.uint32)
+    mism = (nc != ref["n_contrib"]).sum()
+    assert mism <= max(2, (1 - COLOR_INLIER_FRAC) * nc.size), f"{name}: n_contrib differs on {mism} pixels"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_backward_gradients(name, device):
+    sc = make_scene(**CASES[name])
+    inp = oracle_inputs(sc)
+    ref_f = ho.forward(inp)
+    ref_g = ho.backward(inp, ref_f, sc["dL_dpix"])
+    t, color, radii = run_gpu(sc, device)
+    color.backward(to_dev(sc["dL_dpix"], device))
+    torch.cuda.synchronize()
+    pairs = [("means3D", t["means3D"].grad, ref_g["means3D"]), ("means2D", t["means2D"].grad, ref_g["means2D"]),
+             ("opacities", t["opacities"].grad, ref_g["opacities"])]
+    if sc["shs"] is not None:
+        pairs.append(("shs", t["shs"].grad, ref_g["shs"]))
+    else:
+        pairs.append(("colors_precomp", t["colors_precomp"].grad, ref_g["colors"]))
+    if sc["cov3D_precomp"] is None:
+        pairs += [("scales", t["scales"].grad, ref_g["scales"]), ("rotations", t["rotations"].grad, ref_g["rotations"])]
+    else:
+        pairs.append(("cov3D_precomp", t["cov3D_precomp"].grad, ref_g["cov3D"]))
+    for label, g, r in pairs:
+        assert g is not None, f"{name}: no gradient for {label}"
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all(), f"{name}: non-finite gradient in {label}"
+        err = rel_l2(g.reshape(r.shape), r)
+        assert err <= GRAD_REL_TOL, f"{name}: grad {label} rel L2 err {err:.3e}"
+    # screen-space gradient: z component identically zero (A.6 quirk 6)
+    assert float(t["means2D"].grad[:, 2].abs().max()) == 0.0
+
+
+def test_empty_input_gives_zero_image_not_background(device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(P=0, H=32, W=48, seed=0, with_culled=False)
+    t = gpu_tensors(sc, device)
+    color, radii = GaussianRasterizer(gpu_settings(sc, device))(
+        means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+        rotations=t["rotations"])
+    assert color.shape == (3, 32, 48) and radii.shape == (0,) and radii.dtype == torch.int32
+    assert float(color.abs().max()) == 0.0  # A.6 quirk 8: zeros, NOT the (white) background
+    color.sum().backward()
+    assert t["means3D"].grad.shape == (0, 3)
+
+
+def test_all_culled_gives_background(device):
+    sc = make_scene(P=50, H=32, W=32, seed=3, with_culled=False)
+    sc["means3D"][:, 2] = -1.0
+    ref = ho.forward(oracle_inputs(sc))
+    assert ref["N"] == 0
+    t, color, radii = run_gpu(sc, device)
+    assert int(radii.abs().sum()) == 0
+    assert np.array_equal(color.detach().cpu().numpy(), ref["color"])
+    color.sum().backward()
+    assert float(t["means3D"].grad.abs().max()) == 0.0
+
+
+def test_forward_is_deterministic_and_debug_mode_matches(device):
+    sc = make_scene(**CASES["basic_d3"])
+    _, c1, r1 = run_gpu(sc, device)
+    _, c2, r2 = run_gpu(sc, device, debug=True)
+    assert torch.equal(c1, c2) and torch.equal(r1, r2)
+
+
+def test_api_errors(device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(**CASES["single"])
+    t = gpu_tensors(sc, device)
+    rast = GaussianRasterizer(gpu_settings(sc, device))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], scales=t["scales"],
+             rotations=t["rotations"])
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rast(means3D=t["means3D"].cpu(), means2D=t["means2D"].cpu(), opacities=t["opacities"].cpu(),
+             shs=t["shs"].cpu(), scales=t["scales"].cpu(), rotations=t["rotations"].cpu())
+
+
+def test_mark_visible(device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(**CASES["rotcam_d2"])
+    vis = GaussianRasterizer(gpu_settings(sc, device)).markVisible(to_dev(sc["means3D"], device))
+    ref = ho.mark_visible(sc["means3D"], sc["cam"]["world_view_transform"])
+    assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), ref)
+
+
+def test_depth_ties_resolve_by_gaussian_index(device):
+    """Same tile, identical depth bits: order must be ascending Gaussian index (stable sort)."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(P=64, H=48, W=48, seed=12, D=0, with_culled=False, sigma_px=12.0)
+    sc["means3D"][:, 2] = 5.0  # all at exactly the same depth
+    ref = ho.forward(oracle_inputs(sc))
+    t = gpu_tensors(sc, device, grad=False)
+    _, _, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                    scales=t["scales"], rotations=t["rotations"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    v, r = ref["values"], ref["ranges"]
+    for s, e in r:
+        assert np.all(np.diff(v[s:e].astype(np.int64)) > 0)
+
+
+def test_renderer_adapter_contract(device):
+    """The dict the trainer consumes: keys, shapes, dtypes, grad sink."""
+    from hugs_amd.renderer import render_human_scene
+    sc_h = make_scene(P=70, H=64, W=64, seed=20, D=0, with_culled=False)
+    sc_s = make_scene(P=50, H=64, W=64, seed=21, D=0, with_culled=False)
+
+    def model_out(sc):
+        return {"xyz": to_dev(sc["means3D"], device, True), "shs": to_dev(sc["shs"], device, True),
+                "opacity": to_dev(sc["opacities"], device, True), "scales": to_dev(sc["scales"], device, True),
+                "rotq": to_dev(sc["rotations"], device, True), "active_sh_degree": 0}
+
+    data = {k: (to_dev(v, device) if isinstance(v, np.ndarray) else v) for k, v in sc_h["cam"].items()}
+    h, s = model_out(sc_h), model_out(sc_s)
+    pkg = render_human_scene(data, h, s, bg_color=torch.ones(3, device=device),
+                             human_bg_color=torch.zeros(3, device=device), render_mode="human_scene",
+                             render_human_separate=True)
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "human_img",
+                        "human_visibility_filter", "human_radii", "scene_visibility_filter", "scene_radii"}
+    assert pkg["render"].shape == (3, 64, 64) and pkg["render"].dtype == torch.float32
+    assert float(pkg["render"].min()) >= 0.0 and float(pkg["render"].max()) <= 1.0
+    assert pkg["viewspace_points"].shape == (120, 3) and pkg["radii"].dtype == torch.int32
+    assert pkg["visibility_filter"].dtype == torch.bool and pkg["visibility_filter"].shape == (120,)
+    assert pkg["human_radii"].shape == (70,) and pkg["scene_radii"].shape == (50,)
+    assert torch.equal(pkg["scene_radii"], pkg["radii"][70:])
+    (pkg["render"].sum() + pkg["human_img"].sum()).backward()
+    assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (120, 3)
+    assert h["xyz"].grad is not None and s["xyz"].grad is not None
+    for mode, keys in (("human", {"human_visibility_filter", "human_radii"}),
+                       ("scene", {"scene_visibility_filter", "scene_radii"})):
+        p2 = render_human_scene(data, h, s, bg_color=None if mode == "scene" else torch.ones(3, device=device),
+                                render_mode=mode)
+        assert keys <= set(p2)
+    with pytest.raises(ValueError):
+        render_human_scene(data, h, s, bg_color=None, render_mode="bogus")

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rasterizer forward+backward FPS at 1080p, and the HBM roofline of its dominant kernel.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: 200k scene Gaussians, [P,16,3] SH at degree 3, 1920x1080, white
+background, seeded synthetic inputs already resident in HBM.  One step = one call of the
+drop-in GaussianRasterizer (forward) + autograd backward with a fixed dL/dcolor, i.e. the work the
+reference does at gs_renderer.py:144-152 and again inside loss.backward() (gs_trainer.py:287).
+With N GPUs every rank renders its own camera of the same Gaussian set (frames are independent: weak
+scaling); the only communication is the metric gather.  Rank 0 prints ONE JSON line on stdout.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def alg_bytes(P, Pv, N, S, T, K, M=16):
+    """Algorithmic bytes: whole fwd+bwd frame, and the blend-backward kernel alone."""
+    frame = P * (108 + 12 * K + 12 * M) + Pv * (226 + 12 * K) + 124 * N + 40 * S + 24 * T
+    blend_bwd = 8 * T + 40 * N + 20 * S + 36 * Pv
+    blend_fwd = 8 * T + 40 * N + 20 * S
+    return frame, blend_bwd, blend_fwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=200_000)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, profile_enable,
+                                             profile_read)
+    from hugs_amd import sharding, synthetic as syn
+
+    P, H, W, D = args.gaussians, args.height, args.width, args.sh_degree
+    cam0 = syn.pinhole_camera(H, W)
+    g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0)
+    # frame r of the batch: the same scene seen from a slightly yawed camera (frame 0 = identity pose)
+    yaw = math.radians(1.5) * rank
+    w2c = np.eye(4)
+    w2c[0, 0], w2c[0, 2], w2c[2, 0], w2c[2, 2] = math.cos(yaw), math.sin(yaw), -math.sin(yaw), math.cos(yaw)
+    cam = syn.camera_from_w2c(w2c, cam0["fovx"], cam0["fovy"], H, W)
+    dL = syn.pixel_grad(H, W)
+
+    dev = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
+    t = {k: dev(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    sharding.broadcast_gaussians([v.data for v in t.values()])  # replicas of rank 0's Gaussians
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+    dLd = dev(dL)
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5),
+        bg=torch.ones(3, device=device), scale_modifier=1.0, viewmatrix=dev(cam["world_view_transform"]),
+        projmatrix=dev(cam["full_proj_transform"]), sh_degree=D, campos=dev(cam["camera_center"]),
+        prefiltered=False, debug=False)
+    leaves = list(t.values()) + [means2D]
+
+    def step():
+        rast = GaussianRasterizer(raster_settings=settings)  # a new module per call, as the reference does
+        color, radii = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                            scales=t["scales"], rotations=t["rotations"])
+        if not args.forward_only:
+            color.backward(dLd)
+            for x in leaves:
+                x.grad = None
+        return color, radii
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    dominant = "blend_forward" if args.forward_only else "blend_backward"
+    profile_enable((dominant,))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        color, radii = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = profile_read()
+    profile_enable(())
+    elapsed = sharding.max_over_ranks(elapsed, device)
+
+    # exact integers of this frame (shared with the oracle): N and the visible count
+    N = color.grad_fn.num_rendered if color.grad_fn is not None else None
+    Pv = int((radii > 0).sum())
+    if N is None:
+        from diff_gaussian_rasterization import _debug_forward_state
+        N = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
+                                 scales=t["scales"].detach(), rotations=t["rotations"].detach())[2]["N"]
+    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv)]], world, device=device)
+
+    # per-stage breakdown in a separate, untimed pass (every stage bracketed by events)
+    profile_enable()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    stages = {k: round(v[0] / v[1], 4) for k, v in profile_read().items()}
+    profile_enable(())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    K = (D + 1) ** 2
+    S, T = H * W, ((H + 15) // 16) * ((W + 15) // 16)
+    frame_B, bwd_B, fwd_B = alg_bytes(P, Pv, N, S, T, K)
+    dom_ms = prof[dominant][0] / prof[dominant][1]
+    dom_B = fwd_B if args.forward_only else bwd_B
+    achieved = dom_B / (dom_ms * 1e-3) / 1e9
+    fps = world * args.steps / elapsed
+    out = {
+        "metric": "rasterizer fwd+bwd FPS @1080p vs #Gaussians; achieved HBM GB/s vs peak",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
+                               f"{'forward only' if args.forward_only else 'forward+backward'} through "
+                               "GaussianRasterizer (drop-in API), one camera per GPU",
+                   "gaussians": P, "visible": Pv, "num_rendered_N": int(N), "tiles": T,
+                   "N_per_frame_all_ranks": [int(x) for x in frames[:, 0].tolist()]},
+        "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                     "traffic": None, "algorithmic_bytes_per_launch": int(dom_B),
+                     "avg_launch_ms": round(dom_ms, 4), "launches_timed": prof[dominant][1],
+                     "note": "this kernel is VALU/atomic-bound, not HBM-bound (DESIGN.md); see pixel_splat_evals_per_s"},
+        "whole_frame": {"algorithmic_bytes": int(frame_B), "GB_per_s": round(frame_B * fps / world / 1e9, 2),
+                        "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5)},
+        "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
+        "stages_ms": stages,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
+    """The oracle (a CPU port of the same algorithm -- the reference has no CPU path) timed on
+    this box's host cores on a bounded sample of the same workload. Baseline only."""
+    from oracle import hgs_oracle as ho
+    cores = os.cpu_count() or 1
+    ho.set_threads(cores)
+    inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                    cam["camera_center"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), H, W,
+                    np.ones(3, np.float32), shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        f = ho.forward(inp)
+        if with_backward:
+            ho.backward(inp, f, dL)
+        n += 1
+        el = time.perf_counter() - t0
+        if el + el / n > budget_s or n >= 8:
+            break
+    log(f"[cpu_baseline] {n} frame(s) in {el:.2f} s on {cores} threads")
+    return {"value": round(n / el, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full frame(s) of the same workload ({'fwd+bwd' if with_backward else 'fwd'}), "
+                      "C oracle (oracle/hgs_oracle.c, fp32, OpenMP over tiles)"}
+
+
+if __name__ == "__main__":
+    main()

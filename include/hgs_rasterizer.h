@@ -130,6 +130,20 @@ size_t hgs_geom_bytes(int32_t P);
 size_t hgs_image_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 
+/* Per-stage device timing with HIP events recorded on the launch stream (the
+ * reference has no profiling hooks; this is the build's own).  `stage_mask` has bit k set to time
+ * stage k; 0 disables (default).  hgs_profile_read synchronises the recorded events of that stage,
+ * adds them up since the last reset and returns the number of timed launches through *launches. */
+enum {
+    HGS_STAGE_PREPROCESS = 0, HGS_STAGE_SCAN = 1, HGS_STAGE_EMIT_KEYS = 2, HGS_STAGE_SORT = 3,
+    HGS_STAGE_TILE_RANGES = 4, HGS_STAGE_BLEND_FORWARD = 5, HGS_STAGE_BLEND_BACKWARD = 6,
+    HGS_STAGE_PREPROCESS_BACKWARD = 7, HGS_NUM_STAGES = 8
+};
+void hgs_profile_enable(uint32_t stage_mask);
+int32_t hgs_profile_read(int32_t stage, double *total_ms, int64_t *launches);
+void hgs_profile_reset(void);
+const char *hgs_stage_name(int32_t stage);
+
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
  * Names: geom: "splats","tiles_touched","offsets"; binning: "keys","values";
  * image: "final_T","n_contrib","ranges". Returns (size_t)-1 for an unknown name.

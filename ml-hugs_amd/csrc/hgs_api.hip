@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "hgs_common.h"
 
@@ -33,6 +35,58 @@ int fail(int code, const char* fmt, ...)
         if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(st);                                  \
         if (e_ != hipSuccess) return fail(HGS_ERR_HIP, "stage %s: %s", name, hipGetErrorString(e_));     \
     } while (0)
+
+// ---- optional per-stage timing (hipEvent pairs on the launch stream) ----
+struct ProfState {
+    std::mutex mu;
+    uint32_t mask = 0;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[HGS_NUM_STAGES] = {0};
+    int64_t launches[HGS_NUM_STAGES] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain()
+    {
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                total_ms[p.stage] += ms;
+                launches[p.stage] += 1;
+            }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+} g_prof;
+
+struct ProfScope {
+    int stage; hipStream_t st; hipEvent_t a = nullptr;
+    ProfScope(int stage_, hipStream_t st_) : stage(stage_), st(st_)
+    {
+        if (g_prof.mask & (1u << stage)) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            a = g_prof.get();
+            (void)hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope()
+    {
+        if (a) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            hipEvent_t b = g_prof.get();
+            (void)hipEventRecord(b, st);
+            g_prof.pending.push_back({stage, a, b});
+        }
+    }
+};
 
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
 {
@@ -81,6 +135,33 @@ extern "C" {
 const char* hgs_last_error(void) { return g_err; }
 int32_t hgs_abi_version(void) { return HGS_ABI_VERSION; }
 
+void hgs_profile_enable(uint32_t stage_mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.mask = stage_mask;
+}
+void hgs_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    for (int i = 0; i < HGS_NUM_STAGES; ++i) g_prof.total_ms[i] = 0, g_prof.launches[i] = 0;
+}
+int32_t hgs_profile_read(int32_t stage, double* total_ms, int64_t* launches)
+{
+    if (stage < 0 || stage >= HGS_NUM_STAGES) return fail(HGS_ERR_INVALID_ARGUMENT, "bad stage %d", stage);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    if (total_ms) *total_ms = g_prof.total_ms[stage];
+    if (launches) *launches = g_prof.launches[stage];
+    return HGS_OK;
+}
+const char* hgs_stage_name(int32_t stage)
+{
+    static const char* names[HGS_NUM_STAGES] = {"preprocess", "scan", "emit_keys", "sort", "tile_ranges",
+                                                "blend_forward", "blend_backward", "preprocess_backward"};
+    return stage >= 0 && stage < HGS_NUM_STAGES ? names[stage] : "?";
+}
+
 size_t hgs_geom_bytes(int32_t P) { return GeomLayout(P < 1 ? 1 : P).total; }
 size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
@@ -127,9 +208,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t* offsets = (uint32_t*)(geom + gl.offsets);
     uint32_t* scan_tmp = (uint32_t*)(geom + gl.scan_tmp);
 
-    launch_preprocess(a, cam, splats, tiles_touched, st);
+    { ProfScope ps(HGS_STAGE_PREPROCESS, st); launch_preprocess(a, cam, splats, tiles_touched, st); }
     STAGE_CHECK(dbg, st, "preprocess");
-    launch_scan_inclusive(tiles_touched, offsets, scan_tmp, a.P, st);
+    { ProfScope ps(HGS_STAGE_SCAN, st); launch_scan_inclusive(tiles_touched, offsets, scan_tmp, a.P, st); }
     STAGE_CHECK(dbg, st, "scan");
 
     // the one host synchronisation of the forward pass: N sizes the binning buffer
@@ -151,16 +232,16 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (N > 0) {
         const int num_bits = 32 + bits_for((uint32_t)num_tiles);
         const bool in_b = sort_input_buffer(num_bits) != 0;
-        launch_emit_keys(a.P, cam, splats, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st);
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit_keys(a.P, cam, splats, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st); }
         STAGE_CHECK(dbg, st, "emit_keys");
-        launch_sort_pairs(keys_a, keys_b, vals_a, vals_b, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
-                          num_bits, st);
+        { ProfScope ps(HGS_STAGE_SORT, st); launch_sort_pairs(keys_a, keys_b, vals_a, vals_b, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
+                          num_bits, st); }
         STAGE_CHECK(dbg, st, "sort");
     }
-    launch_tile_ranges(keys_a, N, ranges, num_tiles, st);
+    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, N, ranges, num_tiles, st); }
     STAGE_CHECK(dbg, st, "tile_ranges");
-    launch_blend_forward(cam, ranges, vals_a, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
-                         (uint32_t*)(image + il.n_contrib), st);
+    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, vals_a, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
+                         (uint32_t*)(image + il.n_contrib), st); }
     STAGE_CHECK(dbg, st, "blend_forward");
     return N;
 }
@@ -190,11 +271,12 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const char* bin = (const char*)a.state.binning;
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
+    { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
     launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint32_t*)(bin + bl.values), splats, f.s.bg,
                           (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
-                          a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolors, st);
+                          a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolors, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
-    launch_preprocess_backward(a, cam, splats, st);
+    { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");
     return HGS_OK;
 }

@@ -93,8 +93,41 @@ def _load():
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+    lib.hgs_profile_enable.argtypes = [C.c_uint32]
+    lib.hgs_profile_enable.restype = None
+    lib.hgs_profile_reset.restype = None
+    lib.hgs_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.hgs_profile_read.restype = C.c_int32
+    lib.hgs_stage_name.argtypes = [C.c_int32]
+    lib.hgs_stage_name.restype = C.c_char_p
     _lib = lib
     return lib
+
+
+STAGES = ("preprocess", "scan", "emit_keys", "sort", "tile_ranges", "blend_forward", "blend_backward",
+          "preprocess_backward")
+
+
+def profile_enable(stages=STAGES):
+    """Time the named stages with HIP events on the launch stream (empty tuple disables)."""
+    lib = _load()
+    mask = 0
+    for s in stages:
+        mask |= 1 << STAGES.index(s)
+    lib.hgs_profile_reset()
+    lib.hgs_profile_enable(mask)
+
+
+def profile_read():
+    """{stage: (total_ms, launches)} since the last profile_enable(); synchronises the events."""
+    lib = _load()
+    out = {}
+    for i, s in enumerate(STAGES):
+        ms, n = C.c_double(0), C.c_int64(0)
+        lib.hgs_profile_read(i, C.byref(ms), C.byref(n))
+        if n.value:
+            out[s] = (ms.value, n.value)
+    return out
 
 
 def _raise_last(lib, what):

@@ -96,17 +96,18 @@ typedef struct hgs_forward_state {
 int64_t hgs_rasterize_forward(const hgs_forward_args *args, hgs_alloc_fn alloc, void *alloc_ctx,
                               hgs_forward_state *state_out, void *stream);
 
-/* Replaces _C.rasterize_gaussians_backward. All dL_* outputs must be ZERO-INITIALISED by the
- * caller (the library accumulates into dL_dmeans2D/dL_dconic/dL_dopacity/dL_dcolors with float
- * atomics and overwrites the rest for visible Gaussians only). */
+/* Replaces _C.rasterize_gaussians_backward.  `grad_accum` ([P,12] floats: dL/d{mean2D.x, mean2D.y,
+ * conic xx, xy, yy, opacity, r, g, b}, 3 pad) is scratch that must be ZERO-INITIALISED by the caller: the
+ * blend-backward kernel accumulates into it with float atomics.  Every dL_* output is fully overwritten
+ * (zeros for culled Gaussians and for SH coefficients above the active degree); no pre-zeroing needed. */
 typedef struct hgs_backward_args {
     hgs_forward_args fwd;       /* same inputs as forward (out_color unused; radii = forward's output) */
     hgs_forward_state state;    /* as returned by forward */
     const float *dL_dout_color; /* [3,H,W] */
-    float *dL_dmeans2D;         /* [P,3]  (x,y NDC-scaled; z stays 0) */
-    float *dL_dconic;           /* [P,4]  scratch (slots x,y,.,w) */
+    float *grad_accum;          /* [P,12] scratch, zero on entry */
+    float *dL_dmeans2D;         /* [P,3]  (x,y NDC-scaled; z = 0) */
     float *dL_dopacity;         /* [P] */
-    float *dL_dcolors;          /* [P,3]  dL/d(colors_precomp) or dL/d(SH->RGB result) */
+    float *dL_dcolors;          /* [P,3]  dL/d(colors_precomp) (= dL/d(SH->RGB result) when shs are used) */
     float *dL_dmeans3D;         /* [P,3] */
     float *dL_dcov3D;           /* [P,6] */
     float *dL_dsh;              /* [P,M,3] or NULL */
@@ -145,10 +146,11 @@ void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);
 
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
- * Names: geom: "splats","tiles_touched","offsets"; binning: "keys","values";
+ * Names: geom: "splats","tiles_touched","offsets"; binning: "keys","values","bitmaps";
  * image: "final_T","n_contrib","ranges". Returns (size_t)-1 for an unknown name.
  * For "keys"/"values" the offset is of the SORTED list and depends on the last forward's N
  * and image size. */
+/* NB: a sorted `values` entry is (quad coverage mask << 28) | Gaussian index. */
 size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int32_t image_height,
                           int32_t image_width);
 

@@ -100,32 +100,106 @@ void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: one thread per Gaussian writes its (tile | depth bits, index) pairs, y outer, x inner.
+// K3: key emission, wave-balanced, plus a per-entry quad coverage mask.
+//
+// A wave owns 64 consecutive Gaussians; their tile counts are prefix-summed in registers and the wave's
+// output slots are dealt to lanes 64 at a time (each slot finds its Gaussian by a 6-step search over the
+// wave's prefix sums), so a single huge splat no longer serialises one lane and writes are coalesced.
+// Order inside a Gaussian is y outer, x inner (A.4), so (key,value) slots are exactly the oracle's.
+//
+// The value's top 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on
+// some pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never
+// missing): the blend kernels skip a (wave, splat) pair whose bit is clear without touching a VGPR.
+// max over the pixel-centre rectangle [x0,x0+7] x [y0,y0+7] of  A dx^2 + B dx dy + C dy^2  (concave)
+__device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, float B, float C, float x0, float y0)
+{
+    const float dxl = sx - (x0 + 7.0f), dxh = sx - x0, dyl = sy - (y0 + 7.0f), dyh = sy - y0;
+    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;  // centre inside the quad
+    const float hA = -0.5f / A, hC = -0.5f / C;  // vertex of the 1-D restriction: d* = -B d_other / (2 A|C)
+    float best = -3.0e38f;
+    {
+        float dy = fminf(dyh, fmaxf(dyl, B * dxl * hC));
+        best = fmaxf(best, A * dxl * dxl + (B * dxl + C * dy) * dy);
+        dy = fminf(dyh, fmaxf(dyl, B * dxh * hC));
+        best = fmaxf(best, A * dxh * dxh + (B * dxh + C * dy) * dy);
+        float dx = fminf(dxh, fmaxf(dxl, B * dyl * hA));
+        best = fmaxf(best, C * dyl * dyl + (B * dyl + A * dx) * dx);
+        dx = fminf(dxh, fmaxf(dxl, B * dyh * hA));
+        best = fmaxf(best, C * dyh * dyh + (B * dyh + A * dx) * dx);
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(256)
 emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ offsets,
                  uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
-    const int radius = __float_as_int(tail.z);
-    if (radius <= 0) return;
-    const float4 head = reinterpret_cast<const float4*>(splats + i)[0];
-    const float px = head.x, py = head.y, radf = (float)radius;
-    // identical expressions to the preprocess kernel => identical rectangle
-    int minx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
-    int maxx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
-    int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
-    int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
-    uint32_t off = i == 0 ? 0u : offsets[i - 1];
-    const uint64_t dbits = (uint64_t)__float_as_uint(tail.y);
-    for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
-            uint64_t key = ((uint64_t)(uint32_t)(ty * cam.gx + tx) << 32) | dbits;
-            keys[off] = key;
-            values[off] = (uint32_t)i;
-            ++off;
+    __shared__ float4 stage[4][64][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g0 = (blockIdx.x * 4 + w) * 64;
+    if (g0 >= P) return;  // whole wave
+    const int g = g0 + lane;
+
+    uint32_t cnt = 0;
+    float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = make_float4(-1.f, 3.0e38f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (g < P) {
+        const float4 tail = reinterpret_cast<const float4*>(splats + g)[2];
+        const int radius = __float_as_int(tail.z);
+        if (radius > 0) {
+            const float4 head = reinterpret_cast<const float4*>(splats + g)[0];
+            const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
+            const float px = head.x, py = head.y, radf = (float)radius;
+            // identical expressions to the preprocess kernel => identical rectangle
+            const int minx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
+            const int maxx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
+            const int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
+            const int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
+            cnt = (uint32_t)((maxx - minx) * (maxy - miny));
+            // contributes iff opacity * exp(power) >= 1/255  <=>  power >= -(ln 255 + ln opacity); 0.05 of slack
+            // covers the blend kernels' rounding (and makes the mask a strict superset)
+            const float thr = -(5.5412635f + __logf(mid.y)) - 0.05f;
+            r0 = make_float4(px, py, head.z, head.w);
+            r1 = make_float4(mid.x, thr, tail.y, 0.f);
+            r2 = make_float4(__int_as_float(minx), __int_as_float(miny), __int_as_float(maxx - minx), 0.f);
         }
+    }
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    r1.w = __uint_as_float(incl - cnt);
+    stage[w][lane][0] = r0, stage[w][lane][1] = r1, stage[w][lane][2] = r2;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t wave_base = g0 == 0 ? 0u : offsets[g0 - 1];
+
+    for (uint32_t s0 = 0; s0 < total; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        // owner = smallest lane whose inclusive count exceeds s (all lanes take part in the shuffles)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t v = (uint32_t)__shfl((int)incl, lo + step - 1, 64);
+            if (v <= s) lo += step;
+        }
+        if (s < total) {
+            const float4 a = stage[w][lo][0], b = stage[w][lo][1], c = stage[w][lo][2];
+            const uint32_t k = s - __float_as_uint(b.w);
+            const uint32_t wdt = (uint32_t)__float_as_int(c.z);
+            const uint32_t ry = k / wdt, rx = k - ry * wdt;
+            const int tx = __float_as_int(c.x) + (int)rx, ty = __float_as_int(c.y) + (int)ry;
+            const float A = a.z, B = a.w, C = b.x, thr = b.y;
+            uint32_t mask = 0xFu;
+            if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
+                mask = 0;
+                const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
+                        mask |= 1u << q;
+            }
+            const uint64_t key = ((uint64_t)(uint32_t)(ty * cam.gx + tx) << 32) | (uint64_t)__float_as_uint(b.z);
+            keys[wave_base + s] = key;
+            values[wave_base + s] = (mask << GID_BITS) | (uint32_t)(g0 + lo);
+        }
+    }
 }
 
 void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* offsets, uint64_t* keys,
@@ -289,22 +363,35 @@ void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5
+// K5: tile ranges + the four per-quad bitmaps over the sorted list (one ballot per quad per 64 entries).
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(const uint64_t* __restrict__ keys, int64_t N, uint2* __restrict__ ranges)
+tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
+                   uint2* __restrict__ ranges, uint64_t* __restrict__ bitmaps, size_t bitmap_words)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
-    if (i == N - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = 0;
+    if (i < N) {
+        const uint32_t t = (uint32_t)(keys[i] >> 32);
+        if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
+        if (i == N - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+        v = values[i];
+    }
+    const size_t word = (size_t)(i >> 6);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t m = __ballot((v >> (GID_BITS + q)) & 1u);
+        if ((threadIdx.x & 63) == 0 && word < bitmap_words) bitmaps[(size_t)q * bitmap_words + word] = m;
+    }
 }
 
-void launch_tile_ranges(const uint64_t* keys, int64_t N, uint2* ranges, int num_tiles, hipStream_t st)
+void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
+                        uint64_t* bitmaps, size_t bitmap_words, hipStream_t st)
 {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st);
-    if (N <= 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, keys, N, ranges);
+    // the grid covers every bitmap word (also the zero words past N that the blend kernels may prefetch)
+    const int64_t threads = (int64_t)bitmap_words * 64;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, keys, values, N, ranges,
+                       bitmaps, bitmap_words);
 }
 
 }  // namespace hgs

@@ -1,18 +1,25 @@
 // Per-tile alpha blending: forward (K6) and pixel-side backward (K7).  SURVEY.md A.4 / A.5.
 //
 // CDNA4 design (not the CUDA shape):
-//  * A 16x16 tile is one 256-thread workgroup = 4 independent wave64s, each owning an 8x8 pixel
-//    quad.  There is NO LDS staging and NO barrier: the splat record of list entry j is the same
-//    for every lane, so it is fetched through the scalar data cache (s_load_dwordx4 from the
-//    constant address space) straight into SGPRs and used as a scalar operand of the VALU math.
-//  * Early-out is per wave (64 pixels), not per 256-pixel tile.
-//  * Backward: the 9 per-splat partial sums of a wave are combined with a butterfly
-//    transpose-reduce (quad_perm / row_shl / row_shr / row_ror DPP + two cross-row shuffles) that
-//    leaves 8 of the totals in 8 different lanes, so one global_atomic_add_f32 instruction retires
-//    8 of the 9 accumulations; wave-splats that no pixel touches are skipped with one ballot.
+//  * A 16x16 tile is one 256-thread workgroup = 4 independent wave64s, each owning an 8x8 pixel quad.
+//    There is NO LDS staging and NO barrier: the splat record of a list entry is the same for every lane,
+//    so it is fetched through the scalar data cache (s_load_dwordx8 from the constant address space)
+//    straight into SGPRs and used as a scalar operand of the VALU math.
+//  * Each quad has a bitmap over the sorted list (built by the tile-ranges kernel from the coverage masks
+//    the emission kernel computed).  A wave walks only the set bits of its bitmap with scalar bit scans
+//    (s_ff1 / s_flbit), so list entries that cannot touch its 64 pixels cost no vector instruction at all
+//    -- in the 200k / 1080p workload that is ~60 % of all (wave, splat) pairs.
+//  * The walk is software pipelined: the list value of entry n+2 and the record of entry n+1 are in
+//    flight while entry n is blended out of SGPRs (scalar loads return out of order, so the single
+//    lgkmcnt(0) sits at the top of the iteration, before the next record load is issued).
+//  * The per-pixel update is fully predicated (v_cndmask), early-out is per wave (64 pixels).
+//  * Backward: the 9 per-splat partial sums of a wave are combined with a butterfly transpose-reduce
+//    (quad_perm / row_shl / row_shr / row_ror DPP + two cross-row shuffles) that leaves the totals in 9
+//    different lanes, which then issue ONE global_atomic_add_f32 instruction into a [P][12] accumulator
+//    record (contiguous 36 bytes per Gaussian).
 //
-// Compiled with -ffp-contract=off; the FMAs below are explicit so forward and backward evaluate
-// alpha with the identical instruction sequence (backward must re-take forward's skip decisions).
+// Compiled with -ffp-contract=off; the FMAs below are explicit so forward and backward evaluate alpha
+// with the identical instruction sequence (backward must re-take forward's skip decisions).
 #include "hgs_common.h"
 
 namespace hgs {
@@ -20,7 +27,9 @@ namespace hgs {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) v4f* const_f4p;
+typedef const __attribute__((address_space(4))) float* const_f32p;
 typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
+typedef const __attribute__((address_space(4))) uint64_t* const_u64p;
 typedef const __attribute__((address_space(4))) v2u* const_u2p;
 
 struct SplatRec {  // wave-uniform (lives in SGPRs)
@@ -29,13 +38,13 @@ struct SplatRec {  // wave-uniform (lives in SGPRs)
 
 __device__ __forceinline__ SplatRec load_rec(const Splat* splats, uint32_t gid)
 {
-    const_f4p p = (const_f4p)(splats + gid);
+    // 32-bit byte offset (P * 48 < 2^32 is checked by the API): one s_mul_i32 + base+offset scalar loads
+    const_f4p p = (const_f4p)((const char*)splats + gid * 48u);
     const v4f h0 = p[0], h1 = p[1];
-    float b = ((const __attribute__((address_space(4))) float*)p)[8];
+    const float b = ((const_f32p)p)[8];
     SplatRec s;
     s.x = h0.x, s.y = h0.y;
-    // half-conic form: power = A dx^2 + B dx dy + C dy^2  (exact power-of-two rescale of the conic)
-    s.A = -0.5f * h0.z, s.B = -h0.w, s.C = -0.5f * h1.x;
+    s.A = h0.z, s.B = h0.w, s.C = h1.x;  // half-conic form: power = A dx^2 + B dx dy + C dy^2
     s.op = h1.y, s.r = h1.z, s.g = h1.w, s.b = b;
     return s;
 }
@@ -56,15 +65,93 @@ __device__ __forceinline__ int remap_tile(int bid, int num_tiles)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Scalar walk over the set bits of one quad bitmap restricted to list positions [s, e).
+struct BitWalk {
+    const_u64p bm;
+    uint32_t s, e;  // slice of the sorted list
+    uint32_t wd;    // current word
+    uint64_t m;     // unvisited bits of the current word
+
+    __device__ __forceinline__ uint64_t word(uint32_t w) const
+    {
+        uint64_t v = bm[w];
+        if (w == (s >> 6)) v &= ~0ull << (s & 63u);
+        if (w == ((e - 1u) >> 6)) {
+            const uint32_t r = e & 63u;
+            if (r) v &= (1ull << r) - 1ull;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void begin_up(const_u64p bm_, uint32_t s_, uint32_t e_)
+    {
+        bm = bm_, s = s_, e = e_, wd = s_ >> 6;
+        m = word(wd);
+    }
+    __device__ __forceinline__ bool next_up(uint32_t& i)  // ascending
+    {
+        const uint32_t last = (e - 1u) >> 6;
+        while (m == 0ull) {
+            if (wd >= last) return false;
+            ++wd;
+            m = word(wd);
+        }
+        const uint32_t k = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        i = (wd << 6) + k;
+        return true;
+    }
+    __device__ __forceinline__ void begin_down(const_u64p bm_, uint32_t s_, uint32_t e_)
+    {
+        bm = bm_, s = s_, e = e_, wd = (e_ - 1u) >> 6;
+        m = word(wd);
+    }
+    __device__ __forceinline__ bool next_down(uint32_t& i)  // descending
+    {
+        const uint32_t first = s >> 6;
+        while (m == 0ull) {
+            if (wd <= first) return false;
+            --wd;
+            m = word(wd);
+        }
+        const uint32_t k = 63u - (uint32_t)__builtin_clzll(m);
+        m &= ~(1ull << k);
+        i = (wd << 6) + k;
+        return true;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
+// One list entry applied to the wave's 64 pixels, fully predicated (v_cndmask, no exec-mask branches);
+// `pos1` is the entry's 1-based position in the tile list (wave-uniform).
+__device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1, float pxf, float pyf, float& T,
+                                               float& C0, float& C1, float& C2, uint32_t& last, bool& done)
+{
+    const float dx = s.x - pxf, dy = s.y - pyf;
+    const float power = gauss_power(s, dx, dy);
+    const float alpha = fminf(ALPHA_MAX, s.op * __expf(power));
+    const bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+    const float test_T = T * (1.0f - alpha);
+    const bool stop = ok && test_T < T_STOP;
+    const bool upd = ok && !stop;
+    const float wgt = upd ? alpha * T : 0.0f;
+    C0 = __builtin_fmaf(s.r, wgt, C0);
+    C1 = __builtin_fmaf(s.g, wgt, C1);
+    C2 = __builtin_fmaf(s.b, wgt, C2);
+    T = upd ? test_T : T;
+    last = upd ? pos1 : last;
+    done = done || stop;
+}
+
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+                     const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words, const Splat* __restrict__ splats,
+                     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
+                     uint32_t* __restrict__ n_contrib)
 {
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
     const int py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < cam.W && py < cam.H;
@@ -73,41 +160,28 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_
     const_u32p list = (const_u32p)point_list;
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
     bool done = !inside;
 
-    for (uint32_t j0 = range.x; j0 < range.y; j0 += 4) {
-        if (__ballot(!done) == 0ull) break;
-        // four list entries per trip: index loads, then record loads, are issued back to back
-        uint32_t gid[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gid[k] = list[j0 + k];  // list is padded: reading past range.y is safe
-        SplatRec rec[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rec[k] = load_rec(splats, j0 + k < range.y ? gid[k] : gid[0]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (j0 + k < range.y && !done) {
-                const SplatRec& s = rec[k];
-                ++contributor;
-                const float dx = s.x - pxf, dy = s.y - pyf;
-                const float power = gauss_power(s, dx, dy);
-                if (power <= 0.0f) {
-                    const float alpha = fminf(ALPHA_MAX, s.op * __expf(power));
-                    if (alpha >= ALPHA_MIN) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < T_STOP) {
-                            done = true;
-                        } else {
-                            const float wgt = alpha * T;
-                            C0 = __builtin_fmaf(s.r, wgt, C0);
-                            C1 = __builtin_fmaf(s.g, wgt, C1);
-                            C2 = __builtin_fmaf(s.b, wgt, C2);
-                            T = test_T;
-                            last = contributor;
-                        }
-                    }
-                }
+    if (range.y > range.x) {
+        BitWalk it;
+        it.begin_up((const_u64p)bitmaps + (size_t)w * bitmap_words, range.x, range.y);
+        uint32_t i_cur = 0, i_nxt = 0, i_3 = 0;
+        if (it.next_up(i_cur)) {
+            const uint32_t val_cur = list[i_cur];
+            bool v_nxt = it.next_up(i_nxt);
+            uint32_t val_nxt = list[v_nxt ? i_nxt : i_cur];
+            SplatRec rec_cur = load_rec(splats, val_cur & GID_MASK);
+            while (true) {
+                // top of the pipeline: everything issued one iteration ago has had a full blend to land
+                const SplatRec rec_nxt = load_rec(splats, val_nxt & GID_MASK);
+                const bool v_3 = v_nxt && it.next_up(i_3);
+                const uint32_t val_3 = list[v_3 ? i_3 : i_cur];
+                fwd_accumulate(rec_cur, i_cur - range.x + 1u, pxf, pyf, T, C0, C1, C2, last, done);
+                if (!v_nxt || __ballot(!done) == 0ull) break;
+                rec_cur = rec_nxt;
+                i_cur = i_nxt, i_nxt = i_3;
+                v_nxt = v_3, val_nxt = val_3;
             }
         }
     }
@@ -121,15 +195,17 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_
     }
 }
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                          const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st)
+void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
+                          size_t bitmap_words, const Splat* splats, const float* bg, float* out_color, float* final_T,
+                          uint32_t* n_contrib, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, splats,
-                       bg, out_color, final_T, n_contrib);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, bitmaps,
+                       (uint32_t)bitmap_words, splats, bg, out_color, final_T, n_contrib);
 }
 
 // ------------------------------------------------------------------------------------------------
-// DPP helpers
+// DPP helpers.  NB: every DPP move must be evaluated with all 64 lanes active and only then selected;
+// inside a ?: arm the compiler would run it under a partial exec mask and read dead lanes.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
@@ -141,7 +217,7 @@ constexpr int DPP_ROW_SHL4 = 0x104;  // lane i <- lane i+4 (within a row of 16)
 constexpr int DPP_ROW_SHR4 = 0x114;  // lane i <- lane i-4
 constexpr int DPP_ROW_ROR8 = 0x128;  // lane i <- lane i^8 (rotate by half a row)
 
-// pairwise transpose-reduce step: after it, lanes with `hi` clear hold (a + partner's a) and lanes
+// pairwise transpose-reduce step: afterwards lanes with `hi` clear hold (a + partner's a) and lanes
 // with `hi` set hold (b + partner's b); partner = lane ^ XOR within the quad.
 template <int CTRL>
 __device__ __forceinline__ float pair_step(float a, float b, bool hi)
@@ -152,14 +228,15 @@ __device__ __forceinline__ float pair_step(float a, float b, bool hi)
 
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const Splat* __restrict__ splats, const float* __restrict__ bg,
-                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
-                      float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors)
+                      const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words, const Splat* __restrict__ splats,
+                      const float* __restrict__ bg, const float* __restrict__ final_T,
+                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                      float* __restrict__ grad_accum)
 {
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
     const int py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < cam.W && py < cam.H;
@@ -182,119 +259,99 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
+    if (wmax == 0) return;
 
     float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f, last_alpha = 0.0f;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
-    for (uint32_t c = wmax; c >= 1; --c) {  // c = 1-based position in the tile list
-        const uint32_t gid = list[range.x + c - 1];
-        const SplatRec s = load_rec(splats, gid);
+    BitWalk it;
+    it.begin_down((const_u64p)bitmaps + (size_t)w * bitmap_words, range.x, range.x + wmax);
+    uint32_t i_cur = 0, i_nxt = 0, i_3 = 0;
+    if (!it.next_down(i_cur)) return;
+    uint32_t val_cur = list[i_cur];
+    bool v_nxt = it.next_down(i_nxt);
+    uint32_t val_nxt = list[v_nxt ? i_nxt : i_cur];
+    SplatRec s = load_rec(splats, val_cur & GID_MASK);
+    while (true) {
+        const SplatRec rec_nxt = load_rec(splats, val_nxt & GID_MASK);
+        const bool v_3 = v_nxt && it.next_down(i_3);
+        const uint32_t val_3 = list[v_3 ? i_3 : i_cur];
+
+        const uint32_t pos1 = i_cur - range.x + 1u;
         const float dx = s.x - pxf, dy = s.y - pyf;
         const float power = gauss_power(s, dx, dy);
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, s.op * G);
-        const bool act = c <= last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
-        if (__ballot(act) == 0ull) continue;
-
-        float v_mx = 0.0f, v_my = 0.0f, v_cxx = 0.0f, v_cxy = 0.0f, v_cyy = 0.0f, v_op = 0.0f, v_r = 0.0f,
-              v_g = 0.0f, v_b = 0.0f;
-        if (act) {
-            const float one_m = 1.0f - alpha;
-            const float inv = __builtin_amdgcn_rcpf(one_m);
-            T = T * inv;
-            const float dch = alpha * T;
-            ar0 = __builtin_fmaf(last_alpha, lc0, (1.0f - last_alpha) * ar0);
-            ar1 = __builtin_fmaf(last_alpha, lc1, (1.0f - last_alpha) * ar1);
-            ar2 = __builtin_fmaf(last_alpha, lc2, (1.0f - last_alpha) * ar2);
-            lc0 = s.r, lc1 = s.g, lc2 = s.b;
-            float dL_dalpha = (s.r - ar0) * g0;
-            dL_dalpha = __builtin_fmaf(s.g - ar1, g1, dL_dalpha);
-            dL_dalpha = __builtin_fmaf(s.b - ar2, g2, dL_dalpha);
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
-            const float dL_dG = s.op * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            // conic = (-2A, -B, -2C)
-            const float dG_ddelx = 2.0f * gdx * s.A + gdy * s.B;
-            const float dG_ddely = 2.0f * gdy * s.C + gdx * s.B;
-            v_mx = dL_dG * dG_ddelx * ddelx_dx;
-            v_my = dL_dG * dG_ddely * ddely_dy;
-            const float h = -0.5f * dL_dG;
-            v_cxx = h * gdx * dx;
-            v_cxy = h * gdx * dy;
-            v_cyy = h * gdy * dy;
-            v_op = G * dL_dalpha;
-            v_r = dch * g0, v_g = dch * g1, v_b = dch * g2;
-        }
-#ifdef HGS_BWD_SIMPLE_REDUCE
-        {
-            float vals[9] = {v_mx, v_my, v_cxx, v_cxy, v_cyy, v_op, v_r, v_g, v_b};
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) vals[q] += __shfl_xor(vals[q], d, 64);
-            if (lane == 0) {
-                atomicAdd(dL_dmean2D + 3 * (size_t)gid, vals[0]);
-                atomicAdd(dL_dmean2D + 3 * (size_t)gid + 1, vals[1]);
-                atomicAdd(dL_dconic + 4 * (size_t)gid, vals[2]);
-                atomicAdd(dL_dconic + 4 * (size_t)gid + 1, vals[3]);
-                atomicAdd(dL_dconic + 4 * (size_t)gid + 3, vals[4]);
-                atomicAdd(dL_dopacity + gid, vals[5]);
-                atomicAdd(dL_dcolors + 3 * (size_t)gid, vals[6]);
-                atomicAdd(dL_dcolors + 3 * (size_t)gid + 1, vals[7]);
-                atomicAdd(dL_dcolors + 3 * (size_t)gid + 2, vals[8]);
+        const bool act = pos1 <= last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
+        if (__ballot(act) != 0ull) {
+            float v_mx = 0.0f, v_my = 0.0f, v_cxx = 0.0f, v_cxy = 0.0f, v_cyy = 0.0f, v_op = 0.0f, v_r = 0.0f,
+                  v_g = 0.0f, v_b = 0.0f;
+            if (act) {
+                const float one_m = 1.0f - alpha;
+                const float inv = __builtin_amdgcn_rcpf(one_m);
+                T = T * inv;
+                const float dch = alpha * T;
+                ar0 = __builtin_fmaf(last_alpha, lc0, (1.0f - last_alpha) * ar0);
+                ar1 = __builtin_fmaf(last_alpha, lc1, (1.0f - last_alpha) * ar1);
+                ar2 = __builtin_fmaf(last_alpha, lc2, (1.0f - last_alpha) * ar2);
+                lc0 = s.r, lc1 = s.g, lc2 = s.b;
+                float dL_dalpha = (s.r - ar0) * g0;
+                dL_dalpha = __builtin_fmaf(s.g - ar1, g1, dL_dalpha);
+                dL_dalpha = __builtin_fmaf(s.b - ar2, g2, dL_dalpha);
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
+                const float dL_dG = s.op * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                // conic = (-2A, -B, -2C)
+                const float dG_ddelx = 2.0f * gdx * s.A + gdy * s.B;
+                const float dG_ddely = 2.0f * gdy * s.C + gdx * s.B;
+                v_mx = dL_dG * dG_ddelx * ddelx_dx;
+                v_my = dL_dG * dG_ddely * ddely_dy;
+                const float h = -0.5f * dL_dG;
+                v_cxx = h * gdx * dx;
+                v_cxy = h * gdx * dy;
+                v_cyy = h * gdy * dy;
+                v_op = G * dL_dalpha;
+                v_r = dch * g0, v_g = dch * g1, v_b = dch * g2;
             }
-            continue;
+            // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
+            // slot order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own -> lane 8)
+            const float w0 = pair_step<DPP_QUAD_XOR1>(v_mx, v_my, b0);
+            const float w1 = pair_step<DPP_QUAD_XOR1>(v_cxx, v_cxy, b0);
+            const float w2 = pair_step<DPP_QUAD_XOR1>(v_cyy, v_op, b0);
+            const float w3 = pair_step<DPP_QUAD_XOR1>(v_r, v_g, b0);
+            const float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
+            const float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
+            const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
+            float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
+            float vb = v_b + dpp_mov<DPP_QUAD_XOR1>(v_b);
+            vb += dpp_mov<DPP_QUAD_XOR2>(vb);
+            const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
+            vb += b2 ? vb_dn : vb_up;
+            y += dpp_mov<DPP_ROW_ROR8>(y);
+            vb += dpp_mov<DPP_ROW_ROR8>(vb);
+            y += __shfl_xor(y, 16, 64);
+            vb += __shfl_xor(vb, 16, 64);
+            y += __shfl_xor(y, 32, 64);
+            vb += __shfl_xor(vb, 32, 64);
+            // lanes 0..8 add the nine totals into the Gaussian's accumulator record with one atomic instruction
+            if (lane < 9) atomicAdd(grad_accum + (size_t)(val_cur & GID_MASK) * 12u + lane, lane == 8 ? vb : y);
         }
-#endif
-        // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
-        // value order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own)
-        float w0 = pair_step<DPP_QUAD_XOR1>(v_mx, v_my, b0);
-        float w1 = pair_step<DPP_QUAD_XOR1>(v_cxx, v_cxy, b0);
-        float w2 = pair_step<DPP_QUAD_XOR1>(v_cyy, v_op, b0);
-        float w3 = pair_step<DPP_QUAD_XOR1>(v_r, v_g, b0);
-        float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
-        float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
-        // NB: every DPP move is evaluated unconditionally (all 64 lanes active) and only then selected;
-        // inside a ?: arm the compiler would run it under a partial exec mask and read dead lanes.
-        const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
-        float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
-        float vb = v_b + dpp_mov<DPP_QUAD_XOR1>(v_b);
-        vb += dpp_mov<DPP_QUAD_XOR2>(vb);
-        const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
-        vb += b2 ? vb_dn : vb_up;
-        y += dpp_mov<DPP_ROW_ROR8>(y);
-        vb += dpp_mov<DPP_ROW_ROR8>(vb);
-        y += __shfl_xor(y, 16, 64);
-        vb += __shfl_xor(vb, 16, 64);
-        y += __shfl_xor(y, 32, 64);
-        vb += __shfl_xor(vb, 32, 64);
-        // lanes 0..7 scatter the 8 totals, lane 8 the ninth
-        if (lane < 9) {
-            float* dst;
-            switch (lane) {
-                case 0: dst = dL_dmean2D + 3 * (size_t)gid; break;
-                case 1: dst = dL_dmean2D + 3 * (size_t)gid + 1; break;
-                case 2: dst = dL_dconic + 4 * (size_t)gid; break;
-                case 3: dst = dL_dconic + 4 * (size_t)gid + 1; break;
-                case 4: dst = dL_dconic + 4 * (size_t)gid + 3; break;
-                case 5: dst = dL_dopacity + gid; break;
-                case 6: dst = dL_dcolors + 3 * (size_t)gid; break;
-                case 7: dst = dL_dcolors + 3 * (size_t)gid + 1; break;
-                default: dst = dL_dcolors + 3 * (size_t)gid + 2; break;
-            }
-            atomicAdd(dst, lane == 8 ? vb : y);
-        }
+        if (!v_nxt) break;
+        s = rec_nxt;
+        val_cur = val_nxt;
+        i_cur = i_nxt, i_nxt = i_3;
+        v_nxt = v_3, val_nxt = val_3;
     }
 }
 
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                           const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, hipStream_t st)
+void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
+                           size_t bitmap_words, const Splat* splats, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, splats,
-                       bg, final_T, n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors);
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, bitmaps,
+                       (uint32_t)bitmap_words, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
 }  // namespace hgs

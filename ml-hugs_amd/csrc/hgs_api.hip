@@ -99,6 +99,7 @@ int make_camera(const hgs_forward_args& a, Camera& cam)
 {
     const hgs_settings& s = a.s;
     if (a.P < 0) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be >= 0");
+    if ((uint32_t)a.P > GID_MASK / 4u) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be < 2^26 (index packing / 32-bit record offsets)");
     if (s.image_height <= 0 || s.image_width <= 0) return fail(HGS_ERR_INVALID_ARGUMENT, "image size must be positive");
     if (a.P > 0 && !a.means3D) return fail(HGS_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
     if (!s.bg || !s.viewmatrix || !s.projmatrix || !s.campos)
@@ -176,6 +177,7 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     if (!strcmp(name, "offsets")) return g.offsets;
     if (!strcmp(name, "keys")) return b.keys;
     if (!strcmp(name, "values")) return b.values;
+    if (!strcmp(name, "bitmaps")) return b.bitmaps;
     if (!strcmp(name, "final_T")) return im.final_T;
     if (!strcmp(name, "n_contrib")) return im.n_contrib;
     if (!strcmp(name, "ranges")) return im.ranges;
@@ -238,9 +240,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
                           num_bits, st); }
         STAGE_CHECK(dbg, st, "sort");
     }
-    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, N, ranges, num_tiles, st); }
+    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, vals_a, N, ranges, num_tiles, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, st); }
     STAGE_CHECK(dbg, st, "tile_ranges");
-    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, vals_a, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
+    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, vals_a, (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
                          (uint32_t*)(image + il.n_contrib), st); }
     STAGE_CHECK(dbg, st, "blend_forward");
     return N;
@@ -257,7 +259,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     if (f.P == 0) return HGS_OK;
     if (!a.state.geom || !a.state.image || !a.state.binning)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state is missing");
-    if (!a.dL_dout_color || !a.dL_dmeans2D || !a.dL_dconic || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmeans3D ||
+    if (!a.dL_dout_color || !a.dL_dmeans2D || !a.grad_accum || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmeans3D ||
         !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
         return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");
     const bool dbg = f.s.debug != 0;
@@ -272,9 +274,10 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
-    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint32_t*)(bin + bl.values), splats, f.s.bg,
+    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint32_t*)(bin + bl.values),
+                          (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, f.s.bg,
                           (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
-                          a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolors, st); }
+                          a.grad_accum, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");

@@ -14,11 +14,16 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
 
+// Sorted list values: low 28 bits = Gaussian index, top 4 bits = quad coverage mask (bit q: the splat may
+// reach alpha >= 1/255 somewhere in the tile's 8x8 quad q = qx + 2 qy; conservative, see binning.hip).
+constexpr uint32_t GID_BITS = 28;
+constexpr uint32_t GID_MASK = (1u << GID_BITS) - 1u;
+
 // Per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
 // 48 bytes, 16-byte aligned: three dwordx4 (scalar or vector) loads.
 struct alignas(16) Splat {
     float x, y;        // pixel-space mean
-    float ca, cb, cc;  // conic (inverse 2D covariance): xx, xy, yy
+    float ca, cb, cc;  // half-conic (A,B,C) = (-conic.xx/2, -conic.xy, -conic.yy/2): power = A dx^2 + B dx dy + C dy^2
     float opacity;
     float r, g, b;     // view-dependent colour after +0.5 / clamp
     float depth;       // view-space z; its raw bits are the low half of the sort key
@@ -63,8 +68,8 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS * SORT_THREADS;  // 4096 keys per block
 constexpr int SORT_MAX_BINS = 512;                 // up to 9-bit digits
 struct BinningLayout {
-    size_t keys, keys_alt, values, values_alt, hist, totals, total;
-    size_t nblocks;
+    size_t keys, keys_alt, values, values_alt, hist, totals, bitmaps, total;
+    size_t nblocks, bitmap_words;  // bitmap_words = u64 words per quad bitmap
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
         nblocks = (n + SORT_TILE - 1) / SORT_TILE;
@@ -75,6 +80,9 @@ struct BinningLayout {
         values_alt = o; o = align_up(o + 4 * n + 64);
         hist = o;       o = align_up(o + 4 * (size_t)SORT_MAX_BINS * nblocks);
         totals = o;     o = align_up(o + 4 * (size_t)SORT_MAX_BINS * 8);
+        // 4 bitmaps (one per 8x8 quad of a tile) over the sorted list: bit i of bitmap q <=> entry i covers quad q
+        bitmap_words = n / 64 + 4;
+        bitmaps = o;    o = align_up(o + 8 * 4 * bitmap_words);
         total = o;
     }
 };
@@ -93,13 +101,15 @@ void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint3
 int sort_input_buffer(int num_bits);
 void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
                        uint32_t* totals, int64_t N, int num_bits, hipStream_t st);
-void launch_tile_ranges(const uint64_t* keys, int64_t N, uint2* ranges, int num_tiles, hipStream_t st);
+void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
+                        uint64_t* bitmaps, size_t bitmap_words, hipStream_t st);
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                          const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st);
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                           const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
-                           hipStream_t st);
+void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
+                          size_t bitmap_words, const Splat* splats, const float* bg, float* out_color, float* final_T,
+                          uint32_t* n_contrib, hipStream_t st);
+// grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
+void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
+                           size_t bitmap_words, const Splat* splats, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
 
 }  // namespace hgs

@@ -157,9 +157,11 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
             if (alive) {
                 out.x = px;
                 out.y = py;
-                out.ca = e.c * det_inv;
-                out.cb = -e.b * det_inv;
-                out.cc = e.a * det_inv;
+                // stored in half-conic form (A, B, C) = (-conic.x/2, -conic.y, -conic.z/2): exact rescale, so the
+                // blend kernels evaluate power = A dx^2 + B dx dy + C dy^2 without per-splat fix-ups
+                out.ca = -0.5f * (e.c * det_inv);
+                out.cb = -(-e.b * det_inv);
+                out.cc = -0.5f * (e.a * det_inv);
                 out.opacity = opacities[i];
                 out.depth = pv[2];
                 out.radius = (int32_t)radf;
@@ -216,16 +218,34 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
                            const float* __restrict__ scales, const float* __restrict__ rots,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                            const float* __restrict__ F, const float* __restrict__ campos,
-                           const Splat* __restrict__ splats, const float* __restrict__ dL_dmean2D,
-                           const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolors,
-                           float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dsh,
-                           float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                           const Splat* __restrict__ splats, const float* __restrict__ grad_accum,
+                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
+                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
+                           float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                            float* __restrict__ dL_dcov3D)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    // accumulator record written by the blend-backward atomics: mx my cxx cxy | cyy op r g | b - - -
+    const float4 acc0 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i];
+    const float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
+    const float acc_b = grad_accum[12 * (size_t)i + 8];
+    dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+    dL_dopacity[i] = acc1.y;
+    dL_dcolors[3 * (size_t)i] = acc1.z, dL_dcolors[3 * (size_t)i + 1] = acc1.w, dL_dcolors[3 * (size_t)i + 2] = acc_b;
+
     const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
-    if (__float_as_int(tail.z) <= 0) return;
+    if (__float_as_int(tail.z) <= 0) {
+        // every output is fully written by this kernel (the caller does not pre-zero them)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = 0.0f, dL_dscale[3 * (size_t)i + k] = 0.0f;
+        reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+        if (shs)
+            for (int k = 0; k < 3 * cam.M; ++k) dL_dsh[(size_t)i * cam.M * 3 + k] = 0.0f;
+        return;
+    }
     const uint32_t clamped = __float_as_uint(tail.w);
 
     const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
@@ -243,8 +263,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
     Ewa e;
     ewa_project(pv, cam, V, S, e);
     const float a = e.a, b = e.b, c = e.c;
-    const float4 gcon = reinterpret_cast<const float4*>(dL_dconic)[i];
-    const float gxx = gcon.x, gxy = gcon.y, gyy = gcon.w;
+    const float gxx = acc0.z, gxy = acc0.w, gyy = acc1.x;
     const float denom = a * c - b * b;
     const float d2inv = 1.0f / (denom * denom + 0.0000001f);
     float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
@@ -294,7 +313,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         float hw = F[3] * x + F[7] * y + F[11] * z + F[15];
         float mw = 1.0f / (hw + 0.0000001f);
         float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-        float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
+        float g2x = acc0.x, g2y = acc0.y;
         dm0 += (F[0] * mw - F[3] * mul1) * g2x + (F[1] * mw - F[3] * mul2) * g2y;
         dm1 += (F[4] * mw - F[7] * mul1) * g2x + (F[5] * mw - F[7] * mul2) * g2y;
         dm2 += (F[8] * mw - F[11] * mul1) * g2x + (F[9] * mw - F[11] * mul2) * g2y;
@@ -302,9 +321,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
 
     // SH backward
     if (shs) {
-        float dr0 = (clamped & 1u) ? 0.0f : dL_dcolors[3 * (size_t)i];
-        float dr1 = (clamped & 2u) ? 0.0f : dL_dcolors[3 * (size_t)i + 1];
-        float dr2 = (clamped & 4u) ? 0.0f : dL_dcolors[3 * (size_t)i + 2];
+        float dr0 = (clamped & 1u) ? 0.0f : acc1.z;
+        float dr1 = (clamped & 2u) ? 0.0f : acc1.w;
+        float dr2 = (clamped & 4u) ? 0.0f : acc_b;
         float vx = x - campos[0], vy = y - campos[1], vz = z - campos[2];
         float len = sqrtf(vx * vx + vy * vy + vz * vz);
         float X = vx / len, Y = vy / len, Z = vz / len;
@@ -319,6 +338,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
             dsh[3 * k + 1] = B[k] * dr1;
             dsh[3 * k + 2] = B[k] * dr2;
         }
+        for (int k = 3 * K; k < 3 * cam.M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
 #define SHW(k) (sh[3 * (k)] * dr0 + sh[3 * (k) + 1] * dr1 + sh[3 * (k) + 2] * dr2)
         if (D > 0) {
@@ -404,6 +424,10 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         dq.w = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] +
                        qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
         reinterpret_cast<float4*>(dL_drot)[i] = dq;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = 0.0f;
+        reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -413,7 +437,7 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
     int blocks = (f.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, f.P, cam, f.means3D, f.shs,
                        f.scales, f.rotations, f.cov3D_precomp, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
-                       a.dL_dmeans2D, a.dL_dconic, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
+                       a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
                        a.dL_drotations, a.dL_dcov3D);
 }
 

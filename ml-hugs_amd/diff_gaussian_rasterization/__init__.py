@@ -25,7 +25,8 @@ import torch.nn as nn
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "library_path"]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
+# HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
+_LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
 _ABI_VERSION = 1
 
 
@@ -57,7 +58,7 @@ class _ForwardState(C.Structure):
 
 class _BackwardArgs(C.Structure):
     _fields_ = [("fwd", _ForwardArgs), ("state", _ForwardState), ("dL_dout_color", C.c_void_p),
-                ("dL_dmeans2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("grad_accum", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p)]
 
@@ -258,15 +259,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = sh.shape[1] if sh.numel() else 0
         none_if_empty = lambda t: t if t.numel() else None
 
-        # one zero-filled slab carved into the nine gradient tensors (one memset instead of nine)
-        sizes = [3 * P, 4 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
+        # one slab carved into the gradient tensors; only its head (the [P,12] atomic accumulator) needs
+        # zeroing -- the library overwrites every other element
+        sizes = [12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
         offs, total = [], 0
         for s in sizes:
             offs.append(total)
             total += (s + 63) // 64 * 64
-        slab = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
+        slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+        slab[:max(offs[1], 1)].zero_()
         view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
-        g_means2D, g_conic, g_opacity = view(0, P, 3), view(1, P, 2, 2), view(2, P, 1)
+        g_accum, g_means2D, g_opacity = view(0, P, 12), view(1, P, 3), view(2, P, 1)
         g_colors, g_means3D, g_cov3D = view(3, P, 3), view(4, P, 3), view(5, P, 6)
         g_sh, g_scales, g_rot = view(6, P, M, 3), view(7, P, 3), view(8, P, 4)
 
@@ -282,7 +285,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             a.state.num_rendered = ctx.num_rendered
             grad_out_color = _f32c(grad_out_color)
             a.dL_dout_color = grad_out_color.data_ptr()
-            a.dL_dmeans2D, a.dL_dconic, a.dL_dopacity = g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity.data_ptr()
+            a.grad_accum, a.dL_dmeans2D, a.dL_dopacity = g_accum.data_ptr(), g_means2D.data_ptr(), g_opacity.data_ptr()
             a.dL_dcolors, a.dL_dmeans3D, a.dL_dcov3D = g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr()
             a.dL_dsh = g_sh.data_ptr() if M else None
             a.dL_dscales, a.dL_drotations = g_scales.data_ptr(), g_rot.data_ptr()
@@ -364,10 +367,6 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
     e = torch.empty(0, device=means3D.device)
     means2D = torch.zeros_like(means3D, requires_grad=True)
     holder = {}
-
-    class _Probe(_RasterizeGaussians):
-        pass
-
     m3 = means3D.detach().requires_grad_(True)
     color, radii = _RasterizeGaussians.apply(m3, means2D, shs if shs is not None else e,
                                              colors_precomp if colors_precomp is not None else e, opacities,
@@ -393,6 +392,8 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W)
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
         holder["keys"] = sub(binning, "keys", 8 * N, torch.int64)
-        holder["values"] = sub(binning, "values", 4 * N, torch.int32)
+        raw = sub(binning, "values", 4 * N, torch.int32)
+        holder["values"] = raw & 0x0FFFFFFF                 # Gaussian index
+        holder["quad_masks"] = (raw >> 28) & 0xF            # conservative 8x8-quad coverage mask
     holder["N"] = N
     return color.detach(), radii, holder

@@ -90,9 +90,11 @@ def test_forward_stages_and_image(name, device):
     sp = st["splats"].cpu().numpy()
     vis = ref["radii"] > 0
     assert np.array_equal(sp[:, 10].view(np.int32), ref["radii"])
+    # the device record keeps the conic in half-conic form (-x/2, -y, -z/2): an exact power-of-two rescale
+    half = np.float32(-0.5)
     for col, (refarr, label) in {0: (ref["xy"][:, 0], "x"), 1: (ref["xy"][:, 1], "y"),
-                                 2: (ref["conic_opacity"][:, 0], "conic.x"), 3: (ref["conic_opacity"][:, 1], "conic.y"),
-                                 4: (ref["conic_opacity"][:, 2], "conic.z"), 5: (ref["conic_opacity"][:, 3], "opacity"),
+                                 2: (half * ref["conic_opacity"][:, 0], "conic.x"), 3: (-ref["conic_opacity"][:, 1], "conic.y"),
+                                 4: (half * ref["conic_opacity"][:, 2], "conic.z"), 5: (ref["conic_opacity"][:, 3], "opacity"),
                                  6: (ref["rgb"][:, 0], "r"), 7: (ref["rgb"][:, 1], "g"), 8: (ref["rgb"][:, 2], "b"),
                                  9: (ref["depths"], "depth")}.items():
         a, b = sp[vis, col].view(np.uint32), np.ascontiguousarray(refarr[vis]).view(np.uint32)
@@ -246,3 +248,39 @@ def test_renderer_adapter_contract(device):
         assert keys <= set(p2)
     with pytest.raises(ValueError):
         render_human_scene(data, h, s, bg_color=None, render_mode="bogus")
+
+
+@pytest.mark.parametrize("name", ["basic_d3", "rotcam_d2", "big_splats", "opaque_earlystop", "wide_clamp"])
+def test_quad_coverage_masks_are_conservative(name, device):
+    """The 4-bit mask packed above the Gaussian index may only ever OVER-approximate: whenever any pixel of
+    an 8x8 quad receives alpha >= 1/255 from a list entry, that entry's bit for the quad must be set."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(**CASES[name])
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    t = gpu_tensors(sc, device, grad=False)
+    _, _, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                    colors_precomp=t["colors_precomp"], scales=t["scales"],
+                                    rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+    masks = st["quad_masks"].cpu().numpy()
+    gx = (sc["W"] + 15) // 16
+    keys, vals = ref["keys"], ref["values"]
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    xy, co = ref["xy"].astype(np.float64), ref["conic_opacity"].astype(np.float64)
+    ys, xs = np.mgrid[0:16, 0:16]
+    needed_bits, set_bits = 0, 0
+    for j in range(len(vals)):
+        g, tile = int(vals[j]), int(tiles[j])
+        px, py = (tile % gx) * 16 + xs, (tile // gx) * 16 + ys
+        dx, dy = xy[g, 0] - px, xy[g, 1] - py
+        power = -0.5 * (co[g, 0] * dx * dx + co[g, 2] * dy * dy) - co[g, 1] * dx * dy
+        hit = (power <= 0) & (np.minimum(0.99, co[g, 3] * np.exp(power)) >= 1.0 / 255.0) & (px < sc["W"]) & (py < sc["H"])
+        need = 0
+        for q in range(4):
+            if hit[(q >> 1) * 8:(q >> 1) * 8 + 8, (q & 1) * 8:(q & 1) * 8 + 8].any():
+                need |= 1 << q
+        assert (need & ~int(masks[j])) == 0, f"{name}: entry {j} (gaussian {g}, tile {tile}) needs {need:04b}, mask {int(masks[j]):04b}"
+        needed_bits += bin(need).count("1")
+        set_bits += bin(int(masks[j])).count("1")
+    # and it should be tight enough to be useful
+    assert set_bits <= 1.6 * needed_bits + 16, f"{name}: masks too loose ({set_bits} set vs {needed_bits} needed)"

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_substeps.npz by IMPORTING the reference (read-only, from /root/reference)
+in this container and recording inputs + outputs of the few functions that restate sub-steps of the
+rasterizer hot path.  The reference itself never travels: only these vectors do.
+
+    python tests/golden/make_golden.py            # writes tests/golden/reference_substeps.npz
+
+What is recorded (all fp32, seeded):
+  * eval_sh                     hugs/utils/spherical_harmonics.py:61-125   (degrees 0..3)
+  * build_scaling_rotation + strip_symmetric -> Sigma3D 6-vector   hugs/utils/general.py:161-210
+  * get_projection_matrix       hugs/utils/graphics.py:76-96
+  * get_rotating_camera / get_static_camera dicts   hugs/datasets/utils.py:15-53,64-124
+  * psnr                        hugs/utils/image.py:27-29
+  * the boundary transcript of render_human_scene (kwargs / settings / returned keys, shapes, dtypes)
+    captured with a recording stand-in for diff_gaussian_rasterization   hugs/renderer/gs_renderer.py:20-161
+
+The reference hard-codes device="cuda"; there is no GPU here, so torch factory functions are wrapped to
+drop the device argument and Tensor.cuda() becomes the identity.  Missing third-party modules are
+replaced by inert stubs that exist only inside this process.  Nothing is written to /root/reference.
+"""
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_substeps.npz")
+
+STUB_ROOTS = {"cv2", "pytorch3d", "loguru", "omegaconf", "torchvision", "trimesh", "smplx", "lpips", "open3d", "igl",
+              "plyfile", "simple_knn", "joblib", "tqdm", "matplotlib", "imageio", "scipy_stub"}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = types.ModuleType(spec.name)
+        m.__path__ = []
+        m.__getattr__ = lambda attr: mock.MagicMock(name=f"{spec.name}.{attr}")
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def _shim_torch():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for fname in ("zeros", "ones", "eye", "tensor", "empty", "zeros_like", "ones_like", "rand", "randn", "linspace",
+                  "arange", "full"):
+        orig = getattr(torch, fname)
+
+        def wrapped(*a, _orig=orig, **k):
+            if "device" in k:
+                k.pop("device")
+            return _orig(*a, **k)
+
+        setattr(torch, fname, wrapped)
+    orig_to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple(x for x in a if not (isinstance(x, str) and x.startswith("cuda")))
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k.pop("device")
+        return orig_to(self, *a, **k) if (a or k) else self
+
+    torch.Tensor.to = to
+
+
+class _Recorder:
+    """Stand-in for the diff_gaussian_rasterization module that records what crosses the boundary."""
+
+    def __init__(self):
+        self.calls = []
+        mod = types.ModuleType("diff_gaussian_rasterization")
+        rec = self
+
+        from typing import NamedTuple
+
+        class GaussianRasterizationSettings(NamedTuple):
+            image_height: int
+            image_width: int
+            tanfovx: float
+            tanfovy: float
+            bg: torch.Tensor
+            scale_modifier: float
+            viewmatrix: torch.Tensor
+            projmatrix: torch.Tensor
+            sh_degree: int
+            campos: torch.Tensor
+            prefiltered: bool
+            debug: bool
+
+        class GaussianRasterizer(torch.nn.Module):
+            def __init__(self, raster_settings):
+                super().__init__()
+                self.raster_settings = raster_settings
+
+            def forward(self, **kw):
+                s = self.raster_settings
+                rec.calls.append({"settings": s, "kwargs": kw})
+                P = kw["means3D"].shape[0]
+                img = torch.zeros(3, s.image_height, s.image_width) + 0.0 * kw["means3D"].sum() + 0.0 * kw["means2D"].sum()
+                return img, torch.ones(P, dtype=torch.int32)
+
+        mod.GaussianRasterizationSettings = GaussianRasterizationSettings
+        mod.GaussianRasterizer = GaussianRasterizer
+        sys.modules["diff_gaussian_rasterization"] = mod
+
+
+def _desc(v):
+    if isinstance(v, torch.Tensor):
+        return {"type": "tensor", "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
+                "requires_grad": bool(v.requires_grad)}
+    if v is None:
+        return {"type": "none"}
+    return {"type": type(v).__name__, "value": v if isinstance(v, (int, float, bool, str)) else str(v)}
+
+
+def main():
+    assert os.path.isdir(REF), "this script runs only where /root/reference is mounted"
+    sys.meta_path.insert(0, _StubFinder())
+    _shim_torch()
+    recorder = _Recorder()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    out = {}
+
+    # ---- SH evaluation (reference layout is [..., C, coeffs]; ours is [P, coeffs, C]) ----
+    from hugs.utils import spherical_harmonics as rsh
+    P = 257
+    sh = rng.standard_normal((P, 16, 3)).astype(np.float32)
+    dirs = rng.standard_normal((P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    out["sh_coeffs"], out["sh_dirs"] = sh, dirs
+    for deg in range(4):
+        res = rsh.eval_sh(deg, torch.from_numpy(sh).permute(0, 2, 1), torch.from_numpy(dirs), rsh.C0, rsh.C1, rsh.C2,
+                          rsh.C3, rsh.C4)
+        out[f"sh_eval_deg{deg}"] = res.numpy()
+    out["sh_C0"] = np.float32(rsh.C0.item())
+
+    # ---- Sigma3D = (R S)(R S)^T packed (xx,xy,xz,yy,yz,zz); NB build_rotation NORMALISES q ----
+    from hugs.utils import general as rgen
+    s = np.exp(rng.normal(-2, 0.7, (P, 3))).astype(np.float32)
+    q = rng.standard_normal((P, 4)).astype(np.float32)
+    L = rgen.build_scaling_rotation(torch.from_numpy(s), torch.from_numpy(q))
+    cov = rgen.strip_symmetric(L @ L.transpose(1, 2))
+    out["cov_scales"], out["cov_quats_raw"], out["cov_packed"] = s, q, cov.numpy()
+
+    # ---- projection matrix + camera dicts ----
+    from hugs.utils import graphics as rgfx
+    fovs = np.array([[0.4, 0.4], [1.0, 0.6], [1.2, 0.9]], np.float64)
+    out["proj_fovs"] = fovs
+    out["proj_mats"] = np.stack([rgfx.get_projection_matrix(0.01, 100.0, fx, fy).numpy() for fx, fy in fovs])
+    from hugs.datasets import utils as rdu
+    cams = rdu.get_rotating_camera(dist=5.0, img_size=512, nframes=4, device="cpu")
+    for i, c in enumerate(cams):
+        for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+            out[f"rotcam{i}_{k}"] = c[k].numpy().astype(np.float32)
+    out["rotcam_fov"] = np.float64(cams[0]["fovx"])
+    st = rdu.get_static_camera(img_size=256, fov=0.6, device="cpu")
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        out[f"staticcam_{k}"] = st[k].numpy().astype(np.float32)
+
+    # ---- PSNR ----
+    from hugs.utils import image as rimg
+    a = rng.uniform(0, 1, (2, 3, 32, 40)).astype(np.float32)
+    b = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1).astype(np.float32)
+    out["psnr_a"], out["psnr_b"] = a, b
+    out["psnr_val"] = rimg.psnr(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+
+    # ---- boundary transcript ----
+    from hugs.renderer import gs_renderer as rr
+
+    def model(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        return {"xyz": torch.randn(n, 3, generator=g).requires_grad_(True),
+                "shs": torch.randn(n, 16, 3, generator=g).requires_grad_(True),
+                "opacity": torch.rand(n, 1, generator=g).requires_grad_(True),
+                "scales": torch.rand(n, 3, generator=g).requires_grad_(True),
+                "rotq": torch.randn(n, 4, generator=g).requires_grad_(True), "active_sh_degree": 0}
+
+    pkg = rr.render_human_scene(cams[1], model(7, 1), model(5, 2), bg_color=torch.ones(3),
+                                human_bg_color=torch.zeros(3), render_mode="human_scene", render_human_separate=True)
+    (pkg["render"].sum() + pkg["human_img"].sum()).backward()
+    transcript = {"num_calls": len(recorder.calls), "calls": [], "returned": {k: _desc(v) for k, v in pkg.items()},
+                  "viewspace_points_has_grad": pkg["viewspace_points"].grad is not None}
+    for c in recorder.calls:
+        transcript["calls"].append({"settings": {k: _desc(v) for k, v in c["settings"]._asdict().items()},
+                                    "kwargs": {k: _desc(v) for k, v in c["kwargs"].items()}})
+    out["boundary_transcript_json"] = np.frombuffer(json.dumps(transcript, sort_keys=True).encode(), dtype=np.uint8)
+
+    np.savez_compressed(OUT, **out)
+    print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads, exports every function include/hgs_rasterizer.h declares, its ctypes mirror has
+the C compiler's struct layout, and host-side validation errors come back through hgs_last_error().
+No compute call is made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hgs_rasterizer.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hgs_[a-z_0-9]+)\s*\(", src)) - {"hgs_alloc_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
+    names = _declared_functions()
+    assert {"hgs_rasterize_forward", "hgs_rasterize_backward", "hgs_mark_visible", "hgs_last_error"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in the header but not exported"
+    assert lib.hgs_abi_version() == 1
+
+
+def test_ctypes_structs_match_the_c_layout():
+    import diff_gaussian_rasterization as dgr
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "hgs_rasterizer.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(hgs_settings), sizeof(hgs_forward_args), sizeof(hgs_forward_state), sizeof(hgs_backward_args));
+  printf("%zu %zu %zu %zu\n", offsetof(hgs_forward_args, P), offsetof(hgs_forward_args, means3D), offsetof(hgs_forward_args, radii), offsetof(hgs_settings, campos));
+  printf("%zu %zu %zu %zu\n", offsetof(hgs_backward_args, state), offsetof(hgs_backward_args, dL_dout_color), offsetof(hgs_backward_args, grad_accum), offsetof(hgs_backward_args, dL_drotations));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    v = list(map(int, out))
+    S, F, St, B = dgr._Settings, dgr._ForwardArgs, dgr._ForwardState, dgr._BackwardArgs
+    assert v[:4] == [C.sizeof(S), C.sizeof(F), C.sizeof(St), C.sizeof(B)]
+    assert v[4:8] == [F.P.offset, F.means3D.offset, F.radii.offset, S.campos.offset]
+    assert v[8:] == [B.state.offset, B.dL_dout_color.offset, B.grad_accum.offset, B.dL_drotations.offset]
+
+
+def test_scratch_size_queries_and_offsets():
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
+    assert lib.hgs_geom_bytes(1000) >= 1000 * (48 + 8)
+    assert lib.hgs_image_bytes(1080, 1920) >= 1080 * 1920 * 8 + 8160 * 8
+    n = 123456
+    assert lib.hgs_binning_bytes(n, 1080, 1920) >= n * 24
+    off = {k: lib.hgs_scratch_offset(k.encode(), 1000, n, 64, 64) for k in
+           ("splats", "tiles_touched", "offsets", "keys", "values", "bitmaps", "final_T", "n_contrib", "ranges")}
+    assert off["splats"] == 0 and off["keys"] == 0 and off["final_T"] == 0
+    assert off["values"] >= 16 * n and off["bitmaps"] > off["values"]
+    assert lib.hgs_scratch_offset(b"nope", 1, 1, 16, 16) == C.c_size_t(-1).value
+    assert [lib.hgs_stage_name(i).decode() for i in range(8)] == list(dgr.STAGES)
+
+
+def test_argument_validation_reports_through_last_error():
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
+    a, st = dgr._ForwardArgs(), dgr._ForwardState()
+    a.P = 5
+    a.s.image_height, a.s.image_width = 0, 16
+    cb = dgr._ALLOC_FN(lambda ctx, which, n: None)
+    assert lib.hgs_rasterize_forward(C.byref(a), cb, None, C.byref(st), None) == -1
+    assert b"image size" in lib.hgs_last_error()
+    a.s.image_height = 16
+    assert lib.hgs_rasterize_forward(C.byref(a), cb, None, C.byref(st), None) == -1
+    assert b"means3D must have dimensions (num_points, 3)" in lib.hgs_last_error()
+    assert lib.hgs_mark_visible(3, None, None, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback_and_never_touches_the_oracle():
+    """CPU tensors must raise; and nothing under ml-hugs_amd/ may import or link the oracle."""
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3),
+                                      False, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRasterizer(s)(means3D=torch.zeros(2, 3), means2D=torch.zeros(2, 3), opacities=torch.ones(2, 1),
+                              shs=torch.zeros(2, 16, 3), scales=torch.ones(2, 3), rotations=torch.ones(2, 4))
+    pkg = os.path.join(ROOT, "ml-hugs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath or os.sep + "lib" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower().replace("the oracle", "").replace("cpu oracle", "") or \
+                    not re.search(r"^\s*(from|import)\s+oracle|hgs_oracle|#include.*oracle", txt, re.M), os.path.join(dirpath, f)

@@ -11,6 +11,8 @@ Bars (BASELINE.json north_star "bit-exact for tile/key in
       n_contrib: equal on >= 99.98 % of pixels
   * gradients: relative L2 error <= 1e-3 per tensor (float atomics: summation order varies)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -284,3 +286,91 @@ def test_quad_coverage_masks_are_conservative(name, device):
         set_bits += bin(int(masks[j])).count("1")
     # and it should be tight enough to be useful
     assert set_bits <= 1.6 * needed_bits + 16, f"{name}: masks too loose ({set_bits} set vs {needed_bits} needed)"
+
+
+def test_against_committed_golden_vectors(device):
+    """HIP path vs the small oracle vectors committed under tests/golden (pins the checker itself)."""
+    import importlib.util
+    import os
+    from diff_gaussian_rasterization import _debug_forward_state
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(here, "golden", "make_oracle_golden.py"))
+    mog = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mog)
+    gold = np.load(os.path.join(here, "golden", "oracle_cases.npz"))
+    for name, kw in mog.GOLDEN_CASES.items():
+        sc = make_scene(**kw)
+        t = gpu_tensors(sc, device, grad=False)
+        color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                                scales=t["scales"], rotations=t["rotations"])
+        assert np.array_equal(radii.cpu().numpy(), gold[f"{name}_fwd_radii"])
+        assert st["N"] == int(gold[f"{name}_fwd_N"])
+        assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), gold[f"{name}_fwd_keys"])
+        assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), gold[f"{name}_fwd_values"])
+        assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), gold[f"{name}_fwd_ranges"])
+        check_image(color.cpu().numpy(), gold[f"{name}_fwd_color"], f"golden {name} colour")
+        t, color, _ = run_gpu(sc, device)
+        color.backward(to_dev(sc["dL_dpix"], device))
+        for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+            r = gold[f"{name}_grad_{k}"]
+            assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, (name, k)
+
+
+def test_full_size_workload_parity_and_properties(device):
+    """BASELINE.json configs[1] at full size (200k Gaussians, 1920x1080, degree 3): integers exact and image /
+    gradients within the stated tolerances against the oracle, plus size-independent properties --
+    sortedness of the key list, ranges partitioning it, run-to-run forward determinism, and linearity of the
+    backward pass in dL/dcolor."""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _debug_forward_state
+    from hugs_amd import synthetic as syn
+    P, H, W, D = 200_000, 1080, 1920, 3
+    cam = syn.pinhole_camera(H, W)
+    g = syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+    dL = syn.pixel_grad(H, W) * np.float32(3 * H * W)
+    tfx, tfy = math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5)
+    settings = GaussianRasterizationSettings(H, W, tfx, tfy, torch.ones(3, device=device), 1.0,
+                                             to_dev(cam["world_view_transform"], device),
+                                             to_dev(cam["full_proj_transform"], device), D,
+                                             to_dev(cam["camera_center"], device), False, False)
+    t = {k: to_dev(g[k], device, True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+
+    def fwd_bwd(scale):
+        for x in list(t.values()) + [means2D]:
+            x.grad = None
+        color, radii = GaussianRasterizer(settings)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"],
+                                                    shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        color.backward(to_dev(dL * np.float32(scale), device))
+        return color.detach(), radii, {k: v.grad.clone() for k, v in t.items()}, means2D.grad.clone()
+
+    c1, r1, g1, m1 = fwd_bwd(1.0)
+    c2, r2, g2, m2 = fwd_bwd(2.0)
+    assert torch.equal(c1, c2) and torch.equal(r1, r2)  # forward is deterministic
+    for k in g1:  # backward is linear in dL/dcolor (up to atomic summation order)
+        assert float((g2[k] - 2 * g1[k]).norm() / g1[k].norm()) < 1e-4, k
+
+    _, _, st = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
+                                    scales=t["scales"].detach(), rotations=t["rotations"].detach())
+    keys = st["keys"].cpu().numpy().view(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1])
+    rng = st["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert int((rng[:, 1] - rng[:, 0]).sum()) == st["N"] == len(keys)
+
+    inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
+                    cam["camera_center"], tfx, tfy, H, W, np.ones(3, np.float32), shs=g["shs"], scales=g["scales"],
+                    rotations=g["rotations"], sh_degree=D)
+    ho.set_threads(min(os.cpu_count() or 1, 32))
+    ref = ho.forward(inp)
+    assert np.array_equal(r1.cpu().numpy(), ref["radii"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(keys, ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    assert np.array_equal(rng.astype(np.uint32), ref["ranges"])
+    check_image(c1.cpu().numpy(), ref["color"], "C2 colour")
+    refg = ho.backward(inp, ref, dL)
+    for k, rk in (("means3D", "means3D"), ("opacities", "opacities"), ("shs", "shs"), ("scales", "scales"),
+                  ("rotations", "rotations")):
+        r = refg[rk]
+        assert rel_l2(g1[k].cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+    assert rel_l2(m1.cpu().numpy(), refg["means2D"]) <= GRAD_REL_TOL

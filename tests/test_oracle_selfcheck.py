@@ -1,0 +1,121 @@
+"""CPU: the oracle checked against itself -- analytic backward (C) vs autograd through an independent dense torch
+restatement (fp64), fp32 build vs fp64 build, and the committed oracle golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hgs_oracle as ho
+from oracle import torch_oracle as to
+from scenes import make_scene, oracle_inputs
+
+SMALL = {
+    "sh3_rot": dict(P=48, H=40, W=56, seed=0, D=3, rotated_camera=True),
+    "sh2_wide_clamp": dict(P=40, H=48, W=48, seed=1, D=2, wide=True, sigma_px=10.0),
+    "sh0_opaque": dict(P=60, H=32, W=32, seed=2, D=0, opaque=True, sigma_px=9.0),
+    "rgb_mod": dict(P=30, H=33, W=47, seed=3, colors_precomp=True, scale_modifier=0.7, bg=(0.2, 0.5, 0.9)),
+    "cov_precomp": dict(P=30, H=32, W=40, seed=4, D=1, cov3D_precomp=True),
+}
+
+
+def _torch_run(sc):
+    t = lambda a: None if a is None else torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    cam = sc["cam"]
+    ins = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")}
+    ins["means2D"] = torch.zeros(sc["means3D"].shape, dtype=torch.float64, requires_grad=True)
+    c = lambda a: torch.tensor(np.asarray(a, np.float64))
+    col, radii, aux = to.rasterize(ins["means3D"], ins["means2D"], ins["opacities"], c(cam["world_view_transform"]),
+                                   c(cam["full_proj_transform"]), c(cam["camera_center"]), c(sc["bg"]), sc["tanfovx"],
+                                   sc["tanfovy"], sc["H"], sc["W"], shs=ins["shs"], colors_precomp=ins["colors_precomp"],
+                                   scales=ins["scales"], rotations=ins["rotations"], cov3D_precomp=ins["cov3D_precomp"],
+                                   sh_degree=sc["D"], scale_modifier=sc["scale_modifier"])
+    (col * c(sc["dL_dpix"])).sum().backward()
+    return ins, col.detach().numpy(), radii.numpy(), aux
+
+
+@pytest.mark.parametrize("name", list(SMALL))
+def test_analytic_backward_equals_autograd_fp64(name):
+    sc = make_scene(**SMALL[name])
+    inp = oracle_inputs(sc, dtype=np.float64)
+    f = ho.forward(inp)
+    g = ho.backward(inp, f, sc["dL_dpix"])
+    ins, col, radii, aux = _torch_run(sc)
+    assert np.array_equal(radii, f["radii"])
+    assert np.array_equal(aux["n_contrib"].numpy(), f["n_contrib"])
+    np.testing.assert_allclose(col, f["color"], rtol=0, atol=1e-12)
+    pairs = {"means3D": "means3D", "means2D": "means2D", "opacities": "opacities", "shs": "shs",
+             "colors_precomp": "colors", "scales": "scales", "rotations": "rotations", "cov3D_precomp": "cov3D"}
+    for k, gk in pairs.items():
+        if ins.get(k) is None:
+            continue
+        a, b = ins[k].grad.numpy(), g[gk].reshape(ins[k].shape)
+        denom = max(np.linalg.norm(a), 1e-30)
+        # 1e-7 epsilons inside the analytic formulas (1/(den^2+1e-7)) bound the agreement at ~1e-10
+        assert np.linalg.norm(a - b) / denom < 1e-9, (name, k, np.linalg.norm(a - b) / denom)
+
+
+@pytest.mark.parametrize("name", list(SMALL))
+def test_fp32_oracle_tracks_fp64_oracle(name):
+    sc = make_scene(**SMALL[name])
+    f32 = ho.forward(oracle_inputs(sc, np.float32))
+    f64 = ho.forward(oracle_inputs(sc, np.float64))
+    same = f32["radii"] == f64["radii"]
+    assert same.mean() > 0.97  # ceil() of a rounded number may differ for a few
+    if same.all() and np.array_equal(f32["n_contrib"], f64["n_contrib"]):
+        np.testing.assert_allclose(f32["color"], f64["color"], atol=2e-5)
+        g32 = ho.backward(oracle_inputs(sc, np.float32), f32, sc["dL_dpix"])
+        g64 = ho.backward(oracle_inputs(sc, np.float64), f64, sc["dL_dpix"])
+        for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+            n = np.linalg.norm(g64[k])
+            if n > 0:
+                assert np.linalg.norm(g32[k] - g64[k]) / n < 2e-3, (name, k)
+
+
+def test_oracle_reproduces_committed_golden_vectors():
+    import importlib.util
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(here, "golden", "make_oracle_golden.py"))
+    mog = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mog)
+    gold = np.load(os.path.join(here, "golden", "oracle_cases.npz"))
+    ho.set_threads(1)
+    for name, kw in mog.GOLDEN_CASES.items():
+        sc = make_scene(**kw)
+        inp = oracle_inputs(sc)
+        f = ho.forward(inp)
+        g = ho.backward(inp, f, sc["dL_dpix"])
+        for k in mog.FWD_KEYS:
+            ref = gold[f"{name}_fwd_{k}"]
+            if ref.dtype.kind in "iu":
+                assert np.array_equal(f[k], ref), (name, k)
+            else:
+                np.testing.assert_allclose(f[k], ref, rtol=0, atol=1e-6, err_msg=f"{name} {k}")
+        assert int(gold[f"{name}_fwd_N"]) == f["N"]
+        for k in mog.GRAD_KEYS:
+            np.testing.assert_allclose(g[k], gold[f"{name}_grad_{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{name} grad {k}")
+
+
+def test_sort_is_stable_and_ranges_partition_the_list():
+    sc = make_scene(P=200, H=64, W=64, seed=30, D=0, sigma_px=12.0, with_culled=False)
+    sc["means3D"][:, 2] = np.repeat(np.linspace(2, 6, 20), 10).astype(np.float32)  # many exact depth ties
+    f = ho.forward(oracle_inputs(sc), stop_after="binning")
+    keys, vals, rng = f["keys"], f["values"], f["ranges"]
+    assert np.all(np.diff(keys.astype(np.uint64)) >= 0)
+    tie = keys[1:] == keys[:-1]
+    assert tie.any() and np.all(vals[1:][tie] > vals[:-1][tie])  # ties resolve by ascending Gaussian index
+    covered = sum(int(e - s) for s, e in rng)
+    assert covered == f["N"]
+    for t, (s, e) in enumerate(rng):
+        assert np.all((keys[s:e] >> np.uint64(32)) == t)
+
+
+def test_empty_and_all_culled():
+    sc = make_scene(P=0, H=16, W=16, seed=0, with_culled=False)
+    f = ho.forward(oracle_inputs(sc))
+    assert f["N"] == 0 and float(np.abs(f["color"]).max()) == 0.0  # zeros, not background
+    sc = make_scene(P=20, H=16, W=16, seed=0, with_culled=False)
+    sc["means3D"][:, 2] = 0.1
+    f = ho.forward(oracle_inputs(sc))
+    assert f["N"] == 0 and np.allclose(f["color"], 1.0)  # background only

@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* __restrict__ b
     }
 }
 
-__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ block_sums,
-                                                         uint32_t* __restrict__ out, int n)
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ block_sums,
+                                                         uint32_t* out, int n)  // in may alias out
 {
     __shared__ uint32_t wsum[4];
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -363,10 +363,12 @@ void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5: tile ranges + the four per-quad bitmaps over the sorted list (one ballot per quad per 64 entries).
+// K5: tile ranges, the four per-quad bitmaps over the sorted list (one ballot per quad per 64 entries), and --
+// after a prefix sum over the bitmap words' popcounts -- the compacted per-quad lists the blend kernels stream.
 __global__ void __launch_bounds__(256)
 tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
-                   uint2* __restrict__ ranges, uint64_t* __restrict__ bitmaps, size_t bitmap_words)
+                   uint2* __restrict__ ranges, uint64_t* __restrict__ bitmaps, uint32_t* __restrict__ wcount,
+                   size_t bitmap_words)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t v = 0;
@@ -380,18 +382,60 @@ tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint64_t m = __ballot((v >> (GID_BITS + q)) & 1u);
-        if ((threadIdx.x & 63) == 0 && word < bitmap_words) bitmaps[(size_t)q * bitmap_words + word] = m;
+        if ((threadIdx.x & 63) == 0 && word < bitmap_words) {
+            bitmaps[(size_t)q * bitmap_words + word] = m;
+            wcount[(size_t)q * bitmap_words + word] = (uint32_t)__popcll(m);
+        }
+    }
+}
+
+// wprefix holds the INCLUSIVE scan of the word popcounts on entry and the exclusive one on exit.
+__global__ void __launch_bounds__(256)
+compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
+               const uint2* __restrict__ ranges, const uint64_t* __restrict__ bitmaps, uint32_t* __restrict__ wprefix,
+               size_t bitmap_words, uint64_t* __restrict__ act)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const size_t word = (size_t)(i >> 6);
+    if (word >= bitmap_words) return;  // whole wave
+    uint64_t entry = 0;
+    if (i < N) {
+        const uint32_t t = (uint32_t)(keys[i] >> 32);
+        const uint32_t pos1 = (uint32_t)i - ranges[t].x + 1u;
+        entry = ((uint64_t)pos1 << 32) | (uint64_t)(values[i] & GID_MASK);
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t w = (size_t)q * bitmap_words + word;
+        const uint64_t m = bitmaps[w];
+        const uint32_t excl = wprefix[w] - (uint32_t)__popcll(m);
+        if ((m >> lane) & 1ull) act[excl + (uint32_t)__popcll(m & lt)] = entry;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) wprefix[w] = excl;
+    }
+    // dead entries (gaussian 0, position 0) behind the last real one: the blend kernels prefetch a few past the end
+    if (i == 0) {
+        const uint32_t total = wprefix[4 * bitmap_words - 1];  // last word of the last quad is all zero: incl == excl
+        for (int k = 0; k < ACT_PAD; ++k) act[total + k] = 0ull;
     }
 }
 
 void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
-                        uint64_t* bitmaps, size_t bitmap_words, hipStream_t st)
+                        uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix, uint32_t* scan_tmp, uint64_t* act,
+                        hipStream_t st)
 {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st);
-    // the grid covers every bitmap word (also the zero words past N that the blend kernels may prefetch)
+    (void)hipMemsetAsync(act - ACT_PAD, 0, sizeof(uint64_t) * ACT_PAD, st);
+    // the grid covers every bitmap word (also the zero words past N)
     const int64_t threads = (int64_t)bitmap_words * 64;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, keys, values, N, ranges,
-                       bitmaps, bitmap_words);
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, st, keys, values, N, ranges, bitmaps, wprefix,
+                       bitmap_words);
+    launch_scan_inclusive(wprefix, wprefix, scan_tmp, (int)(4 * bitmap_words), st);
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, st, keys, values, N, ranges, bitmaps, wprefix,
+                       bitmap_words, act);
 }
 
 }  // namespace hgs

@@ -65,88 +65,51 @@ __device__ __forceinline__ int remap_tile(int bid, int num_tiles)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// Scalar walk over the set bits of one quad bitmap restricted to list positions [s, e).
-struct BitWalk {
-    const_u64p bm;
-    uint32_t s, e;  // slice of the sorted list
-    uint32_t wd;    // current word
-    uint64_t m;     // unvisited bits of the current word
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4u* const_u4p;
 
-    __device__ __forceinline__ uint64_t word(uint32_t w) const
-    {
-        uint64_t v = bm[w];
-        if (w == (s >> 6)) v &= ~0ull << (s & 63u);
-        if (w == ((e - 1u) >> 6)) {
-            const uint32_t r = e & 63u;
-            if (r) v &= (1ull << r) - 1ull;
-        }
-        return v;
-    }
-    __device__ __forceinline__ void begin_up(const_u64p bm_, uint32_t s_, uint32_t e_)
-    {
-        bm = bm_, s = s_, e = e_, wd = s_ >> 6;
-        m = word(wd);
-    }
-    __device__ __forceinline__ bool next_up(uint32_t& i)  // ascending
-    {
-        const uint32_t last = (e - 1u) >> 6;
-        while (m == 0ull) {
-            if (wd >= last) return false;
-            ++wd;
-            m = word(wd);
-        }
-        const uint32_t k = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1ull;
-        i = (wd << 6) + k;
-        return true;
-    }
-    __device__ __forceinline__ void begin_down(const_u64p bm_, uint32_t s_, uint32_t e_)
-    {
-        bm = bm_, s = s_, e = e_, wd = (e_ - 1u) >> 6;
-        m = word(wd);
-    }
-    __device__ __forceinline__ bool next_down(uint32_t& i)  // descending
-    {
-        const uint32_t first = s >> 6;
-        while (m == 0ull) {
-            if (wd <= first) return false;
-            --wd;
-            m = word(wd);
-        }
-        const uint32_t k = 63u - (uint32_t)__builtin_clzll(m);
-        m &= ~(1ull << k);
-        i = (wd << 6) + k;
-        return true;
-    }
-};
+// Position of list entry `i`'s slot in the compacted list of quad `w`: covering entries before word i/64
+// (wprefix) plus the covering entries below bit i%64 of that word.
+__device__ __forceinline__ uint32_t act_index(const_u32p wprefix, const_u64p bitmaps, uint32_t bitmap_words, int w,
+                                              uint32_t i)
+{
+    const uint32_t word = (uint32_t)w * bitmap_words + (i >> 6);
+    const uint64_t below = bitmaps[word] & ((1ull << (i & 63u)) - 1ull);
+    return wprefix[word] + (uint32_t)__builtin_popcountll(below);
+}
+
+// two consecutive entries of the compacted list: {gaussian0, pos0, gaussian1, pos1} (one s_load_dwordx4)
+__device__ __forceinline__ v4u load_pair(const uint64_t* act, uint32_t idx)
+{
+    return *(const_u4p)(act + idx);
+}
 
 // ------------------------------------------------------------------------------------------------
-// One list entry applied to the wave's 64 pixels, fully predicated (v_cndmask, no exec-mask branches);
-// `pos1` is the entry's 1-based position in the tile list (wave-uniform).
+// One list entry applied to the wave's 64 pixels, fully predicated (v_cndmask, no exec-mask branches).
+// T carries the "done" flag in its sign: a pixel that would fall below T_STOP keeps |T| and turns negative,
+// after which test_T < 0 fails every later update.  `pos1` = 1-based position in the tile list (uniform).
 __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1, float pxf, float pyf, float& T,
-                                               float& C0, float& C1, float& C2, uint32_t& last, bool& done)
+                                               float& C0, float& C1, float& C2, uint32_t& last)
 {
     const float dx = s.x - pxf, dy = s.y - pyf;
     const float power = gauss_power(s, dx, dy);
     const float alpha = fminf(ALPHA_MAX, s.op * __expf(power));
-    const bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+    const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
     const float test_T = T * (1.0f - alpha);
-    const bool stop = ok && test_T < T_STOP;
-    const bool upd = ok && !stop;
+    const bool upd = ok && test_T >= T_STOP;
     const float wgt = upd ? alpha * T : 0.0f;
     C0 = __builtin_fmaf(s.r, wgt, C0);
     C1 = __builtin_fmaf(s.g, wgt, C1);
     C2 = __builtin_fmaf(s.b, wgt, C2);
-    T = upd ? test_T : T;
+    T = upd ? test_T : (ok ? -__builtin_fabsf(T) : T);
     last = upd ? pos1 : last;
-    done = done || stop;
 }
 
 __global__ void __launch_bounds__(256)
-blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words, const Splat* __restrict__ splats,
-                     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
-                     uint32_t* __restrict__ n_contrib)
+blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                     const uint32_t* __restrict__ wprefix, const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words,
+                     const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
+                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
@@ -157,49 +120,49 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_
     const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
     const v2u range = ((const_u2p)ranges)[tile];
-    const_u32p list = (const_u32p)point_list;
 
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
-    bool done = !inside;
 
     if (range.y > range.x) {
-        BitWalk it;
-        it.begin_up((const_u64p)bitmaps + (size_t)w * bitmap_words, range.x, range.y);
-        uint32_t i_cur = 0, i_nxt = 0, i_3 = 0;
-        if (it.next_up(i_cur)) {
-            const uint32_t val_cur = list[i_cur];
-            bool v_nxt = it.next_up(i_nxt);
-            uint32_t val_nxt = list[v_nxt ? i_nxt : i_cur];
-            SplatRec rec_cur = load_rec(splats, val_cur & GID_MASK);
-            while (true) {
-                // top of the pipeline: everything issued one iteration ago has had a full blend to land
-                const SplatRec rec_nxt = load_rec(splats, val_nxt & GID_MASK);
-                const bool v_3 = v_nxt && it.next_up(i_3);
-                const uint32_t val_3 = list[v_3 ? i_3 : i_cur];
-                fwd_accumulate(rec_cur, i_cur - range.x + 1u, pxf, pyf, T, C0, C1, C2, last, done);
-                if (!v_nxt || __ballot(!done) == 0ull) break;
-                rec_cur = rec_nxt;
-                i_cur = i_nxt, i_nxt = i_3;
-                v_nxt = v_3, val_nxt = val_3;
-            }
+        const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x);
+        const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.y) - a;
+        const uint64_t* list = act + a;
+        // Software pipeline, two entries per half-iteration, two register sets (A/B) so nothing is copied:
+        // while set A is blended, set B's records and the following pair of entries are in flight.
+        v4u eA = load_pair(list, 0);
+        SplatRec rA0 = load_rec(splats, eA.x), rA1 = load_rec(splats, eA.z);
+        v4u eB = load_pair(list, 2);
+        for (uint32_t j = 0; j < n; j += 4) {
+            const SplatRec rB0 = load_rec(splats, eB.x), rB1 = load_rec(splats, eB.z);
+            const v4u eA2 = load_pair(list, j + 4);
+            fwd_accumulate(rA0, eA.y, pxf, pyf, T, C0, C1, C2, last);
+            if (j + 1 < n) fwd_accumulate(rA1, eA.w, pxf, pyf, T, C0, C1, C2, last);
+            if (j + 2 >= n || __ballot(T > 0.0f) == 0ull) break;
+            rA0 = load_rec(splats, eA2.x), rA1 = load_rec(splats, eA2.z);
+            const v4u eB2 = load_pair(list, j + 6);
+            fwd_accumulate(rB0, eB.y, pxf, pyf, T, C0, C1, C2, last);
+            if (j + 3 < n) fwd_accumulate(rB1, eB.w, pxf, pyf, T, C0, C1, C2, last);
+            if (__ballot(T > 0.0f) == 0ull) break;
+            eA = eA2, eB = eB2;
         }
     }
     if (inside) {
         const size_t HW = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
-        final_T[pix] = T;
+        const float Tf = __builtin_fabsf(T);
+        final_T[pix] = Tf;
         n_contrib[pix] = last;
-        out_color[pix] = __builtin_fmaf(T, bg[0], C0);
-        out_color[HW + pix] = __builtin_fmaf(T, bg[1], C1);
-        out_color[2 * HW + pix] = __builtin_fmaf(T, bg[2], C2);
+        out_color[pix] = __builtin_fmaf(Tf, bg[0], C0);
+        out_color[HW + pix] = __builtin_fmaf(Tf, bg[1], C1);
+        out_color[2 * HW + pix] = __builtin_fmaf(Tf, bg[2], C2);
     }
 }
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
-                          size_t bitmap_words, const Splat* splats, const float* bg, float* out_color, float* final_T,
-                          uint32_t* n_contrib, hipStream_t st)
+void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
+                          const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
+                          float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, bitmaps,
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, act, wprefix, bitmaps,
                        (uint32_t)bitmap_words, splats, bg, out_color, final_T, n_contrib);
 }
 
@@ -227,9 +190,9 @@ __device__ __forceinline__ float pair_step(float a, float b, bool hi)
 }
 
 __global__ void __launch_bounds__(256)
-blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words, const Splat* __restrict__ splats,
-                      const float* __restrict__ bg, const float* __restrict__ final_T,
+blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                      const uint32_t* __restrict__ wprefix, const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words,
+                      const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                       float* __restrict__ grad_accum)
 {
@@ -242,7 +205,6 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32
     const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
     const v2u range = ((const_u2p)ranges)[tile];
-    const_u32p list = (const_u32p)point_list;
     const size_t HW = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
 
     const float T_final = inside ? final_T[pix] : 0.0f;
@@ -264,93 +226,99 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint32
     float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f, last_alpha = 0.0f;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
-    BitWalk it;
-    it.begin_down((const_u64p)bitmaps + (size_t)w * bitmap_words, range.x, range.x + wmax);
-    uint32_t i_cur = 0, i_nxt = 0, i_3 = 0;
-    if (!it.next_down(i_cur)) return;
-    uint32_t val_cur = list[i_cur];
-    bool v_nxt = it.next_down(i_nxt);
-    uint32_t val_nxt = list[v_nxt ? i_nxt : i_cur];
-    SplatRec s = load_rec(splats, val_cur & GID_MASK);
-    while (true) {
-        const SplatRec rec_nxt = load_rec(splats, val_nxt & GID_MASK);
-        const bool v_3 = v_nxt && it.next_down(i_3);
-        const uint32_t val_3 = list[v_3 ? i_3 : i_cur];
+    // covering entries of this quad with list position <= wmax, walked back to front, two per half-iteration
+    const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x);
+    const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x + wmax) - a;
+    if (n == 0) return;
+    const uint64_t* top = act + a + n;  // one past the deepest entry; pair r covers entries top[-2r-1], top[-2r-2]
 
-        const uint32_t pos1 = i_cur - range.x + 1u;
+    auto backward_entry = [&](const SplatRec& s, uint32_t gid, uint32_t pos1) {
         const float dx = s.x - pxf, dy = s.y - pyf;
         const float power = gauss_power(s, dx, dy);
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, s.op * G);
-        const bool act = pos1 <= last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
-        if (__ballot(act) != 0ull) {
-            float v_mx = 0.0f, v_my = 0.0f, v_cxx = 0.0f, v_cxy = 0.0f, v_cyy = 0.0f, v_op = 0.0f, v_r = 0.0f,
-                  v_g = 0.0f, v_b = 0.0f;
-            if (act) {
-                const float one_m = 1.0f - alpha;
-                const float inv = __builtin_amdgcn_rcpf(one_m);
-                T = T * inv;
-                const float dch = alpha * T;
-                ar0 = __builtin_fmaf(last_alpha, lc0, (1.0f - last_alpha) * ar0);
-                ar1 = __builtin_fmaf(last_alpha, lc1, (1.0f - last_alpha) * ar1);
-                ar2 = __builtin_fmaf(last_alpha, lc2, (1.0f - last_alpha) * ar2);
-                lc0 = s.r, lc1 = s.g, lc2 = s.b;
-                float dL_dalpha = (s.r - ar0) * g0;
-                dL_dalpha = __builtin_fmaf(s.g - ar1, g1, dL_dalpha);
-                dL_dalpha = __builtin_fmaf(s.b - ar2, g2, dL_dalpha);
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
-                const float dL_dG = s.op * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                // conic = (-2A, -B, -2C)
-                const float dG_ddelx = 2.0f * gdx * s.A + gdy * s.B;
-                const float dG_ddely = 2.0f * gdy * s.C + gdx * s.B;
-                v_mx = dL_dG * dG_ddelx * ddelx_dx;
-                v_my = dL_dG * dG_ddely * ddely_dy;
-                const float h = -0.5f * dL_dG;
-                v_cxx = h * gdx * dx;
-                v_cxy = h * gdx * dy;
-                v_cyy = h * gdy * dy;
-                v_op = G * dL_dalpha;
-                v_r = dch * g0, v_g = dch * g1, v_b = dch * g2;
-            }
-            // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
-            // slot order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own -> lane 8)
-            const float w0 = pair_step<DPP_QUAD_XOR1>(v_mx, v_my, b0);
-            const float w1 = pair_step<DPP_QUAD_XOR1>(v_cxx, v_cxy, b0);
-            const float w2 = pair_step<DPP_QUAD_XOR1>(v_cyy, v_op, b0);
-            const float w3 = pair_step<DPP_QUAD_XOR1>(v_r, v_g, b0);
-            const float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
-            const float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
-            const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
-            float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
-            float vb = v_b + dpp_mov<DPP_QUAD_XOR1>(v_b);
-            vb += dpp_mov<DPP_QUAD_XOR2>(vb);
-            const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
-            vb += b2 ? vb_dn : vb_up;
-            y += dpp_mov<DPP_ROW_ROR8>(y);
-            vb += dpp_mov<DPP_ROW_ROR8>(vb);
-            y += __shfl_xor(y, 16, 64);
-            vb += __shfl_xor(vb, 16, 64);
-            y += __shfl_xor(y, 32, 64);
-            vb += __shfl_xor(vb, 32, 64);
-            // lanes 0..8 add the nine totals into the Gaussian's accumulator record with one atomic instruction
-            if (lane < 9) atomicAdd(grad_accum + (size_t)(val_cur & GID_MASK) * 12u + lane, lane == 8 ? vb : y);
+        const bool act_lane = pos1 <= last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
+        if (__ballot(act_lane) == 0ull) return;
+        float v_mx = 0.0f, v_my = 0.0f, v_cxx = 0.0f, v_cxy = 0.0f, v_cyy = 0.0f, v_op = 0.0f, v_r = 0.0f, v_g = 0.0f,
+              v_b = 0.0f;
+        if (act_lane) {
+            const float one_m = 1.0f - alpha;
+            const float inv = __builtin_amdgcn_rcpf(one_m);
+            T = T * inv;
+            const float dch = alpha * T;
+            ar0 = __builtin_fmaf(last_alpha, lc0, (1.0f - last_alpha) * ar0);
+            ar1 = __builtin_fmaf(last_alpha, lc1, (1.0f - last_alpha) * ar1);
+            ar2 = __builtin_fmaf(last_alpha, lc2, (1.0f - last_alpha) * ar2);
+            lc0 = s.r, lc1 = s.g, lc2 = s.b;
+            float dL_dalpha = (s.r - ar0) * g0;
+            dL_dalpha = __builtin_fmaf(s.g - ar1, g1, dL_dalpha);
+            dL_dalpha = __builtin_fmaf(s.b - ar2, g2, dL_dalpha);
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
+            const float dL_dG = s.op * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            // conic = (-2A, -B, -2C)
+            const float dG_ddelx = 2.0f * gdx * s.A + gdy * s.B;
+            const float dG_ddely = 2.0f * gdy * s.C + gdx * s.B;
+            v_mx = dL_dG * dG_ddelx * ddelx_dx;
+            v_my = dL_dG * dG_ddely * ddely_dy;
+            const float h = -0.5f * dL_dG;
+            v_cxx = h * gdx * dx;
+            v_cxy = h * gdx * dy;
+            v_cyy = h * gdy * dy;
+            v_op = G * dL_dalpha;
+            v_r = dch * g0, v_g = dch * g1, v_b = dch * g2;
         }
-        if (!v_nxt) break;
-        s = rec_nxt;
-        val_cur = val_nxt;
-        i_cur = i_nxt, i_nxt = i_3;
-        v_nxt = v_3, val_nxt = val_3;
+        // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
+        // slot order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own -> lane 8)
+        const float w0 = pair_step<DPP_QUAD_XOR1>(v_mx, v_my, b0);
+        const float w1 = pair_step<DPP_QUAD_XOR1>(v_cxx, v_cxy, b0);
+        const float w2 = pair_step<DPP_QUAD_XOR1>(v_cyy, v_op, b0);
+        const float w3 = pair_step<DPP_QUAD_XOR1>(v_r, v_g, b0);
+        const float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
+        const float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
+        const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
+        float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
+        float vb = v_b + dpp_mov<DPP_QUAD_XOR1>(v_b);
+        vb += dpp_mov<DPP_QUAD_XOR2>(vb);
+        const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
+        vb += b2 ? vb_dn : vb_up;
+        y += dpp_mov<DPP_ROW_ROR8>(y);
+        vb += dpp_mov<DPP_ROW_ROR8>(vb);
+        y += __shfl_xor(y, 16, 64);
+        vb += __shfl_xor(vb, 16, 64);
+        y += __shfl_xor(y, 32, 64);
+        vb += __shfl_xor(vb, 32, 64);
+        // lanes 0..8 add the nine totals into the Gaussian's accumulator record with one atomic instruction
+        if (lane < 9) atomicAdd(grad_accum + (size_t)gid * 12u + lane, lane == 8 ? vb : y);
+    };
+
+    // pair p (p = 0, 1, ...) = entries top[-2p-2] (shallower) and top[-2p-1] (deeper); the front pad of `act`
+    // makes the read below `a` of the last, half-used pair harmless
+    v4u eA = load_pair(top - 2, 0);
+    SplatRec rA0 = load_rec(splats, eA.z), rA1 = load_rec(splats, eA.x);  // rA0 = deeper entry, processed first
+    v4u eB = load_pair(top - 4, 0);
+    for (uint32_t j = 0; j < n; j += 4) {
+        const SplatRec rB0 = load_rec(splats, eB.z), rB1 = load_rec(splats, eB.x);
+        const v4u eA2 = load_pair(top - 6 - j, 0);
+        backward_entry(rA0, eA.z, eA.w);
+        if (j + 1 < n) backward_entry(rA1, eA.x, eA.y);
+        if (j + 2 >= n) break;
+        rA0 = load_rec(splats, eA2.z), rA1 = load_rec(splats, eA2.x);
+        const v4u eB2 = load_pair(top - 8 - j, 0);
+        backward_entry(rB0, eB.z, eB.w);
+        if (j + 3 < n) backward_entry(rB1, eB.x, eB.y);
+        eA = eA2, eB = eB2;
     }
 }
 
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
-                           size_t bitmap_words, const Splat* splats, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
+void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
+                           const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
+                           hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, point_list, bitmaps,
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, act, wprefix, bitmaps,
                        (uint32_t)bitmap_words, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 

@@ -240,9 +240,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
                           num_bits, st); }
         STAGE_CHECK(dbg, st, "sort");
     }
-    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, vals_a, N, ranges, num_tiles, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, st); }
+    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, vals_a, N, ranges, num_tiles, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words,
+                       (uint32_t*)(bin + bl.wprefix), (uint32_t*)(bin + bl.scan_tmp), (uint64_t*)(bin + bl.act) + ACT_PAD, st); }
     STAGE_CHECK(dbg, st, "tile_ranges");
-    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, vals_a, (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
+    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, (const uint64_t*)(bin + bl.act) + ACT_PAD, (const uint32_t*)(bin + bl.wprefix),
+                         (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
                          (uint32_t*)(image + il.n_contrib), st); }
     STAGE_CHECK(dbg, st, "blend_forward");
     return N;
@@ -274,8 +276,8 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
-    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint32_t*)(bin + bl.values),
-                          (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, f.s.bg,
+    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
+                          (const uint32_t*)(bin + bl.wprefix), (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, f.s.bg,
                           (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
                           a.grad_accum, st); }
     STAGE_CHECK(dbg, st, "blend_backward");

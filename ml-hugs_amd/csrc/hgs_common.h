@@ -63,12 +63,13 @@ struct ImageLayout {
         total = o;
     }
 };
+constexpr int ACT_PAD = 16;
 constexpr int SORT_ITEMS = 16;                     // keys per thread per block
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS * SORT_THREADS;  // 4096 keys per block
 constexpr int SORT_MAX_BINS = 512;                 // up to 9-bit digits
 struct BinningLayout {
-    size_t keys, keys_alt, values, values_alt, hist, totals, bitmaps, total;
+    size_t keys, keys_alt, values, values_alt, hist, totals, bitmaps, wprefix, scan_tmp, act, total;
     size_t nblocks, bitmap_words;  // bitmap_words = u64 words per quad bitmap
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
@@ -83,6 +84,13 @@ struct BinningLayout {
         // 4 bitmaps (one per 8x8 quad of a tile) over the sorted list: bit i of bitmap q <=> entry i covers quad q
         bitmap_words = n / 64 + 4;
         bitmaps = o;    o = align_up(o + 8 * 4 * bitmap_words);
+        // wprefix[q * bitmap_words + w] = number of set bits of all earlier words (quads concatenated): the position
+        // of word w's first covering entry in the compacted list `act`
+        wprefix = o;    o = align_up(o + 4 * 4 * bitmap_words);
+        scan_tmp = o;   o = align_up(o + 4 * (4 * bitmap_words / 1024 + 2) + 64);
+        // act: for each quad, the covering entries of the sorted list, in list order, as (pos1 << 32 | gaussian);
+        // worst case 4 N entries; ACT_PAD dead entries in front (the backward walk reads pairs downwards) and behind
+        act = o;        o = align_up(o + 8 * (4 * n + 2 * ACT_PAD));
         total = o;
     }
 };
@@ -101,15 +109,18 @@ void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint3
 int sort_input_buffer(int num_bits);
 void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
                        uint32_t* totals, int64_t N, int num_bits, hipStream_t st);
+// ranges + quad bitmaps + compacted per-quad entry lists (act points at the first real entry, after the front pad)
 void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
-                        uint64_t* bitmaps, size_t bitmap_words, hipStream_t st);
+                        uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix, uint32_t* scan_tmp, uint64_t* act,
+                        hipStream_t st);
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
-                          size_t bitmap_words, const Splat* splats, const float* bg, float* out_color, float* final_T,
-                          uint32_t* n_contrib, hipStream_t st);
+void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
+                          const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
+                          float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const uint64_t* bitmaps,
-                           size_t bitmap_words, const Splat* splats, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
+void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
+                           const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
+                           hipStream_t st);
 
 }  // namespace hgs

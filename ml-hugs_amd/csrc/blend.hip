@@ -223,7 +223,8 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     if (wmax == 0) return;
 
-    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f, last_alpha = 0.0f;
+    float behind_g = 0.0f, last_cg = 0.0f, last_alpha = 0.0f;
+    const float neg_Tf_bg = -T_final * bg_dot;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
     // covering entries of this quad with list position <= wmax, walked back to front, two per half-iteration
@@ -246,16 +247,14 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
             const float inv = __builtin_amdgcn_rcpf(one_m);
             T = T * inv;
             const float dch = alpha * T;
-            ar0 = __builtin_fmaf(last_alpha, lc0, (1.0f - last_alpha) * ar0);
-            ar1 = __builtin_fmaf(last_alpha, lc1, (1.0f - last_alpha) * ar1);
-            ar2 = __builtin_fmaf(last_alpha, lc2, (1.0f - last_alpha) * ar2);
-            lc0 = s.r, lc1 = s.g, lc2 = s.b;
-            float dL_dalpha = (s.r - ar0) * g0;
-            dL_dalpha = __builtin_fmaf(s.g - ar1, g1, dL_dalpha);
-            dL_dalpha = __builtin_fmaf(s.b - ar2, g2, dL_dalpha);
-            dL_dalpha *= T;
+            // "colour behind" only ever enters through its dot product with dL/dpixel, so carry that scalar:
+            // behind_g = last_alpha * (last_colour . g) + (1 - last_alpha) * behind_g
+            behind_g = __builtin_fmaf(last_alpha, last_cg, (1.0f - last_alpha) * behind_g);
+            const float cg = __builtin_fmaf(s.r, g0, __builtin_fmaf(s.g, g1, s.b * g2));
+            last_cg = cg;
             last_alpha = alpha;
-            dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
+            // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
+            const float dL_dalpha = __builtin_fmaf(neg_Tf_bg, inv, (cg - behind_g) * T);
             const float dL_dG = s.op * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
             // conic = (-2A, -B, -2C)

@@ -380,8 +380,8 @@ tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict
     }
     const size_t word = (size_t)(i >> 6);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint64_t m = __ballot((v >> (GID_BITS + q)) & 1u);
+    for (int q = 0; q < NUM_BITMAPS; ++q) {  // q < 4: quad q covered; q == 4: any quad covered
+        const uint64_t m = __ballot(q < 4 ? ((v >> (GID_BITS + q)) & 1u) : ((v >> GID_BITS) != 0u));
         if ((threadIdx.x & 63) == 0 && word < bitmap_words) {
             bitmaps[(size_t)q * bitmap_words + word] = m;
             wcount[(size_t)q * bitmap_words + word] = (uint32_t)__popcll(m);
@@ -399,15 +399,15 @@ compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ v
     const int lane = threadIdx.x & 63;
     const size_t word = (size_t)(i >> 6);
     if (word >= bitmap_words) return;  // whole wave
-    uint64_t entry = 0;
+    uint64_t entry = 0;  // (pos1 << 32) | quad mask << 28 | gaussian
     if (i < N) {
         const uint32_t t = (uint32_t)(keys[i] >> 32);
         const uint32_t pos1 = (uint32_t)i - ranges[t].x + 1u;
-        entry = ((uint64_t)pos1 << 32) | (uint64_t)(values[i] & GID_MASK);
+        entry = ((uint64_t)pos1 << 32) | (uint64_t)values[i];
     }
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NUM_BITMAPS; ++q) {
         const size_t w = (size_t)q * bitmap_words + word;
         const uint64_t m = bitmaps[w];
         const uint32_t excl = wprefix[w] - (uint32_t)__popcll(m);
@@ -417,7 +417,7 @@ compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ v
     }
     // dead entries (gaussian 0, position 0) behind the last real one: the blend kernels prefetch a few past the end
     if (i == 0) {
-        const uint32_t total = wprefix[4 * bitmap_words - 1];  // last word of the last quad is all zero: incl == excl
+        const uint32_t total = wprefix[NUM_BITMAPS * bitmap_words - 1];  // the last word is all zero: incl == excl
         for (int k = 0; k < ACT_PAD; ++k) act[total + k] = 0ull;
     }
 }
@@ -433,7 +433,7 @@ void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N,
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, st, keys, values, N, ranges, bitmaps, wprefix,
                        bitmap_words);
-    launch_scan_inclusive(wprefix, wprefix, scan_tmp, (int)(4 * bitmap_words), st);
+    launch_scan_inclusive(wprefix, wprefix, scan_tmp, (int)(NUM_BITMAPS * bitmap_words), st);
     hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, st, keys, values, N, ranges, bitmaps, wprefix,
                        bitmap_words, act);
 }

@@ -131,15 +131,15 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_
         // Software pipeline, two entries per half-iteration, two register sets (A/B) so nothing is copied:
         // while set A is blended, set B's records and the following pair of entries are in flight.
         v4u eA = load_pair(list, 0);
-        SplatRec rA0 = load_rec(splats, eA.x), rA1 = load_rec(splats, eA.z);
+        SplatRec rA0 = load_rec(splats, eA.x & GID_MASK), rA1 = load_rec(splats, eA.z & GID_MASK);
         v4u eB = load_pair(list, 2);
         for (uint32_t j = 0; j < n; j += 4) {
-            const SplatRec rB0 = load_rec(splats, eB.x), rB1 = load_rec(splats, eB.z);
+            const SplatRec rB0 = load_rec(splats, eB.x & GID_MASK), rB1 = load_rec(splats, eB.z & GID_MASK);
             const v4u eA2 = load_pair(list, j + 4);
             fwd_accumulate(rA0, eA.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 1 < n) fwd_accumulate(rA1, eA.w, pxf, pyf, T, C0, C1, C2, last);
             if (j + 2 >= n || __ballot(T > 0.0f) == 0ull) break;
-            rA0 = load_rec(splats, eA2.x), rA1 = load_rec(splats, eA2.z);
+            rA0 = load_rec(splats, eA2.x & GID_MASK), rA1 = load_rec(splats, eA2.z & GID_MASK);
             const v4u eB2 = load_pair(list, j + 6);
             fwd_accumulate(rB0, eB.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 3 < n) fwd_accumulate(rB1, eB.w, pxf, pyf, T, C0, C1, C2, last);
@@ -189,6 +189,63 @@ __device__ __forceinline__ float pair_step(float a, float b, bool hi)
     return keep + dpp_mov<CTRL>(send);
 }
 
+// Per-pixel backward state of one lane; a lane owns FOUR pixels, one in each 8x8 quad of the tile
+// (same (lx, ly) offset inside every quad), so that one wave covers the whole 16x16 tile.
+struct PixBwd {
+    float pxf, pyf;
+    float T, behind_g, last_cg, last_alpha;  // running transmittance; (colour behind).g; previous splat's c.g, alpha
+    float g0, g1, g2, neg_Tf_bg;             // dL/dpixel, and -T_final * (bg . dL/dpixel)
+    uint32_t last_contributor;
+};
+
+// Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9].
+// Returns (wave-uniform) whether any lane contributed.
+__device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9], float ddelx_dx,
+                                          float ddely_dy)
+{
+    const float dx = s.x - p.pxf, dy = s.y - p.pyf;
+    const float power = gauss_power(s, dx, dy);
+    const float G = __expf(power);
+    const float alpha = fminf(ALPHA_MAX, s.op * G);
+    const bool act_lane = pos1 <= p.last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
+    if (__ballot(act_lane) == 0ull) return false;
+    if (act_lane) {
+        const float one_m = 1.0f - alpha;
+        const float inv = __builtin_amdgcn_rcpf(one_m);
+        p.T = p.T * inv;
+        const float dch = alpha * p.T;
+        // "colour behind" only ever enters through its dot product with dL/dpixel, so carry that scalar:
+        // behind_g = last_alpha * (last_colour . g) + (1 - last_alpha) * behind_g
+        p.behind_g = __builtin_fmaf(p.last_alpha, p.last_cg, (1.0f - p.last_alpha) * p.behind_g);
+        const float cg = __builtin_fmaf(s.r, p.g0, __builtin_fmaf(s.g, p.g1, s.b * p.g2));
+        p.last_cg = cg;
+        p.last_alpha = alpha;
+        // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
+        const float dL_dalpha = __builtin_fmaf(p.neg_Tf_bg, inv, (cg - p.behind_g) * p.T);
+        const float dL_dG = s.op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        // conic = (-2A, -B, -2C)
+        const float dG_ddelx = __builtin_fmaf(2.0f * gdx, s.A, gdy * s.B);
+        const float dG_ddely = __builtin_fmaf(2.0f * gdy, s.C, gdx * s.B);
+        v[0] = __builtin_fmaf(dL_dG * dG_ddelx, ddelx_dx, v[0]);
+        v[1] = __builtin_fmaf(dL_dG * dG_ddely, ddely_dy, v[1]);
+        const float h = -0.5f * dL_dG;
+        const float hgdx = h * gdx, hgdy = h * gdy;
+        v[2] = __builtin_fmaf(hgdx, dx, v[2]);
+        v[3] = __builtin_fmaf(hgdx, dy, v[3]);
+        v[4] = __builtin_fmaf(hgdy, dy, v[4]);
+        v[5] = __builtin_fmaf(G, dL_dalpha, v[5]);
+        v[6] = __builtin_fmaf(dch, p.g0, v[6]);
+        v[7] = __builtin_fmaf(dch, p.g1, v[7]);
+        v[8] = __builtin_fmaf(dch, p.g2, v[8]);
+    }
+    return true;
+}
+
+// One wave per tile (four tiles per 256-thread workgroup, no LDS, no barrier).  A lane's four pixels sit in
+// the four quads, so the quad coverage mask of a list entry decides -- with scalar branches -- which of the
+// four per-pixel evaluations run at all, while the nine partial sums of ALL covered quads are added up in
+// registers before the single cross-lane reduction + atomic of that (tile, entry) pair.
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                       const uint32_t* __restrict__ wprefix, const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words,
@@ -196,90 +253,69 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                       float* __restrict__ grad_accum)
 {
-    const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int num_tiles = cam.gx * cam.gy;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int vbid = blockIdx.x * 4 + w;
+    if (vbid >= num_tiles) return;
+    const int tile = remap_tile(vbid, num_tiles);
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
     const v2u range = ((const_u2p)ranges)[tile];
-    const size_t HW = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
-
-    const float T_final = inside ? final_T[pix] : 0.0f;
-    float T = T_final;
-    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const float g0 = inside ? dL_dpix[pix] : 0.0f;
-    const float g1 = inside ? dL_dpix[HW + pix] : 0.0f;
-    const float g2 = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    if (range.y <= range.x) return;
+    const size_t HW = (size_t)cam.H * cam.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * (float)cam.W, ddely_dy = 0.5f * (float)cam.H;
 
+    PixBwd p[4];
+    uint32_t wmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = tx * TILE + (k & 1) * 8 + (lane & 7);
+        const int py = ty * TILE + (k >> 1) * 8 + (lane >> 3);
+        const bool inside = px < cam.W && py < cam.H;
+        const size_t pix = (size_t)py * cam.W + px;
+        const float Tf = inside ? final_T[pix] : 0.0f;
+        p[k].pxf = (float)px, p[k].pyf = (float)py;
+        p[k].T = Tf;
+        p[k].behind_g = 0.0f, p[k].last_cg = 0.0f, p[k].last_alpha = 0.0f;
+        p[k].g0 = inside ? dL_dpix[pix] : 0.0f;
+        p[k].g1 = inside ? dL_dpix[HW + pix] : 0.0f;
+        p[k].g2 = inside ? dL_dpix[2 * HW + pix] : 0.0f;
+        p[k].neg_Tf_bg = -Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
+        p[k].last_contributor = inside ? n_contrib[pix] : 0u;
+        wmax = max(wmax, p[k].last_contributor);
+    }
     // the wave starts at the deepest entry any of its pixels composited
-    uint32_t wmax = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     if (wmax == 0) return;
-
-    float behind_g = 0.0f, last_cg = 0.0f, last_alpha = 0.0f;
-    const float neg_Tf_bg = -T_final * bg_dot;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
-    // covering entries of this quad with list position <= wmax, walked back to front, two per half-iteration
-    const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x);
-    const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x + wmax) - a;
+    // entries of this tile that cover at least one quad (bitmap 4), positions <= wmax, walked back to front
+    const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, 4, range.x);
+    const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, 4, range.x + wmax) - a;
     if (n == 0) return;
-    const uint64_t* top = act + a + n;  // one past the deepest entry; pair r covers entries top[-2r-1], top[-2r-2]
+    const uint64_t* top = act + a + n;  // one past the deepest entry
 
-    auto backward_entry = [&](const SplatRec& s, uint32_t gid, uint32_t pos1) {
-        const float dx = s.x - pxf, dy = s.y - pyf;
-        const float power = gauss_power(s, dx, dy);
-        const float G = __expf(power);
-        const float alpha = fminf(ALPHA_MAX, s.op * G);
-        const bool act_lane = pos1 <= last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
-        if (__ballot(act_lane) == 0ull) return;
-        float v_mx = 0.0f, v_my = 0.0f, v_cxx = 0.0f, v_cxy = 0.0f, v_cyy = 0.0f, v_op = 0.0f, v_r = 0.0f, v_g = 0.0f,
-              v_b = 0.0f;
-        if (act_lane) {
-            const float one_m = 1.0f - alpha;
-            const float inv = __builtin_amdgcn_rcpf(one_m);
-            T = T * inv;
-            const float dch = alpha * T;
-            // "colour behind" only ever enters through its dot product with dL/dpixel, so carry that scalar:
-            // behind_g = last_alpha * (last_colour . g) + (1 - last_alpha) * behind_g
-            behind_g = __builtin_fmaf(last_alpha, last_cg, (1.0f - last_alpha) * behind_g);
-            const float cg = __builtin_fmaf(s.r, g0, __builtin_fmaf(s.g, g1, s.b * g2));
-            last_cg = cg;
-            last_alpha = alpha;
-            // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
-            const float dL_dalpha = __builtin_fmaf(neg_Tf_bg, inv, (cg - behind_g) * T);
-            const float dL_dG = s.op * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            // conic = (-2A, -B, -2C)
-            const float dG_ddelx = 2.0f * gdx * s.A + gdy * s.B;
-            const float dG_ddely = 2.0f * gdy * s.C + gdx * s.B;
-            v_mx = dL_dG * dG_ddelx * ddelx_dx;
-            v_my = dL_dG * dG_ddely * ddely_dy;
-            const float h = -0.5f * dL_dG;
-            v_cxx = h * gdx * dx;
-            v_cxy = h * gdx * dy;
-            v_cyy = h * gdy * dy;
-            v_op = G * dL_dalpha;
-            v_r = dch * g0, v_g = dch * g1, v_b = dch * g2;
-        }
+    auto backward_entry = [&](const SplatRec& s, uint32_t val, uint32_t pos1) {
+        float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((val >> (GID_BITS + k)) & 1u) any |= bwd_pixel(s, pos1, p[k], v, ddelx_dx, ddely_dy);
+        if (!any) return;
         // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
         // slot order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own -> lane 8)
-        const float w0 = pair_step<DPP_QUAD_XOR1>(v_mx, v_my, b0);
-        const float w1 = pair_step<DPP_QUAD_XOR1>(v_cxx, v_cxy, b0);
-        const float w2 = pair_step<DPP_QUAD_XOR1>(v_cyy, v_op, b0);
-        const float w3 = pair_step<DPP_QUAD_XOR1>(v_r, v_g, b0);
+        const float w0 = pair_step<DPP_QUAD_XOR1>(v[0], v[1], b0);
+        const float w1 = pair_step<DPP_QUAD_XOR1>(v[2], v[3], b0);
+        const float w2 = pair_step<DPP_QUAD_XOR1>(v[4], v[5], b0);
+        const float w3 = pair_step<DPP_QUAD_XOR1>(v[6], v[7], b0);
         const float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
         const float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
         const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
         float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
-        float vb = v_b + dpp_mov<DPP_QUAD_XOR1>(v_b);
+        float vb = v[8] + dpp_mov<DPP_QUAD_XOR1>(v[8]);
         vb += dpp_mov<DPP_QUAD_XOR2>(vb);
         const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
         vb += b2 ? vb_dn : vb_up;
@@ -290,21 +326,22 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
         y += __shfl_xor(y, 32, 64);
         vb += __shfl_xor(vb, 32, 64);
         // lanes 0..8 add the nine totals into the Gaussian's accumulator record with one atomic instruction
-        if (lane < 9) atomicAdd(grad_accum + (size_t)gid * 12u + lane, lane == 8 ? vb : y);
+        if (lane < 9) atomicAdd(grad_accum + (size_t)(val & GID_MASK) * 12u + lane, lane == 8 ? vb : y);
     };
 
-    // pair p (p = 0, 1, ...) = entries top[-2p-2] (shallower) and top[-2p-1] (deeper); the front pad of `act`
-    // makes the read below `a` of the last, half-used pair harmless
+    // pair p = entries top[-2p-2] (shallower) and top[-2p-1] (deeper); the front pad of `act` makes the read
+    // below `a` by the last, half-used pair harmless.  Two register sets (A/B): while one is consumed the
+    // other's records and the next pair of entries are in flight.
     v4u eA = load_pair(top - 2, 0);
-    SplatRec rA0 = load_rec(splats, eA.z), rA1 = load_rec(splats, eA.x);  // rA0 = deeper entry, processed first
+    SplatRec rA0 = load_rec(splats, eA.z & GID_MASK), rA1 = load_rec(splats, eA.x & GID_MASK);  // rA0: deeper, first
     v4u eB = load_pair(top - 4, 0);
     for (uint32_t j = 0; j < n; j += 4) {
-        const SplatRec rB0 = load_rec(splats, eB.z), rB1 = load_rec(splats, eB.x);
+        const SplatRec rB0 = load_rec(splats, eB.z & GID_MASK), rB1 = load_rec(splats, eB.x & GID_MASK);
         const v4u eA2 = load_pair(top - 6 - j, 0);
         backward_entry(rA0, eA.z, eA.w);
         if (j + 1 < n) backward_entry(rA1, eA.x, eA.y);
         if (j + 2 >= n) break;
-        rA0 = load_rec(splats, eA2.z), rA1 = load_rec(splats, eA2.x);
+        rA0 = load_rec(splats, eA2.z & GID_MASK), rA1 = load_rec(splats, eA2.x & GID_MASK);
         const v4u eB2 = load_pair(top - 8 - j, 0);
         backward_entry(rB0, eB.z, eB.w);
         if (j + 3 < n) backward_entry(rB1, eB.x, eB.y);
@@ -317,8 +354,8 @@ void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint64_
                            const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, act, wprefix, bitmaps,
-                       (uint32_t)bitmap_words, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+    hipLaunchKernelGGL(blend_backward_kernel, dim3((cam.gx * cam.gy + 3) / 4), dim3(256), 0, st, cam, ranges, act, wprefix,
+                       bitmaps, (uint32_t)bitmap_words, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
 }  // namespace hgs

@@ -64,6 +64,7 @@ struct ImageLayout {
     }
 };
 constexpr int ACT_PAD = 16;
+constexpr int NUM_BITMAPS = 5;  // four per-quad bitmaps + one "any quad" bitmap over the sorted list
 constexpr int SORT_ITEMS = 16;                     // keys per thread per block
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS * SORT_THREADS;  // 4096 keys per block
@@ -83,14 +84,14 @@ struct BinningLayout {
         totals = o;     o = align_up(o + 4 * (size_t)SORT_MAX_BINS * 8);
         // 4 bitmaps (one per 8x8 quad of a tile) over the sorted list: bit i of bitmap q <=> entry i covers quad q
         bitmap_words = n / 64 + 4;
-        bitmaps = o;    o = align_up(o + 8 * 4 * bitmap_words);
+        bitmaps = o;    o = align_up(o + 8 * NUM_BITMAPS * bitmap_words);
         // wprefix[q * bitmap_words + w] = number of set bits of all earlier words (quads concatenated): the position
         // of word w's first covering entry in the compacted list `act`
-        wprefix = o;    o = align_up(o + 4 * 4 * bitmap_words);
-        scan_tmp = o;   o = align_up(o + 4 * (4 * bitmap_words / 1024 + 2) + 64);
+        wprefix = o;    o = align_up(o + 4 * NUM_BITMAPS * bitmap_words);
+        scan_tmp = o;   o = align_up(o + 4 * (NUM_BITMAPS * bitmap_words / 1024 + 2) + 64);
         // act: for each quad, the covering entries of the sorted list, in list order, as (pos1 << 32 | gaussian);
         // worst case 4 N entries; ACT_PAD dead entries in front (the backward walk reads pairs downwards) and behind
-        act = o;        o = align_up(o + 8 * (4 * n + 2 * ACT_PAD));
+        act = o;        o = align_up(o + 8 * (NUM_BITMAPS * n + 2 * ACT_PAD));
         total = o;
     }
 };

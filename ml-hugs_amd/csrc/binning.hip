@@ -131,14 +131,14 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
 }
 
 __global__ void __launch_bounds__(256)
-emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ offsets,
-                 uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
+emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys, uint32_t* __restrict__ values)
 {
     __shared__ float4 stage[4][64][3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g0 = (blockIdx.x * 4 + w) * 64;
-    if (g0 >= P) return;  // whole wave
-    const int g = g0 + lane;
+    const int g0 = (blockIdx.x * 4 + w) * 64;  // first depth RANK of this wave
+    if (g0 >= P) return;                       // whole wave
+    const int g = g0 + lane < P ? (int)order[g0 + lane] : P;  // the Gaussian holding rank g0 + lane
 
     uint32_t cnt = 0;
     float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = make_float4(-1.f, 3.0e38f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -159,7 +159,7 @@ emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint
             // covers the blend kernels' rounding (and makes the mask a strict superset)
             const float thr = -(5.5412635f + __logf(mid.y)) - 0.05f;
             r0 = make_float4(px, py, head.z, head.w);
-            r1 = make_float4(mid.x, thr, tail.y, 0.f);
+            r1 = make_float4(mid.x, thr, __int_as_float(g), 0.f);
             r2 = make_float4(__int_as_float(minx), __int_as_float(miny), __int_as_float(maxx - minx), 0.f);
         }
     }
@@ -195,17 +195,17 @@ emit_keys_kernel(int P, Camera cam, const Splat* __restrict__ splats, const uint
                     if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
                         mask |= 1u << q;
             }
-            const uint64_t key = ((uint64_t)(uint32_t)(ty * cam.gx + tx) << 32) | (uint64_t)__float_as_uint(b.z);
-            keys[wave_base + s] = key;
-            values[wave_base + s] = (mask << GID_BITS) | (uint32_t)(g0 + lo);
+            keys[wave_base + s] = (uint32_t)(ty * cam.gx + tx);
+            values[wave_base + s] = (mask << GID_BITS) | (uint32_t)__float_as_int(b.z);
         }
     }
 }
 
-void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* offsets, uint64_t* keys,
-                      uint32_t* values, hipStream_t st)
+void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* order, const uint32_t* offsets,
+                      uint32_t* keys, uint32_t* values, hipStream_t st)
 {
-    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, cam, splats, offsets, keys, values);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, cam, splats, order, offsets, keys,
+                       values);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -236,8 +236,9 @@ static SortPlan make_plan(int num_bits)
 }
 int sort_input_buffer(int num_bits) { return make_plan(num_bits).passes & 1; }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(SORT_THREADS)
-sort_upsweep_kernel(const uint64_t* __restrict__ keys, int64_t N, int shift, int nbits, uint32_t* __restrict__ hist,
+sort_upsweep_kernel(const KeyT* __restrict__ keys, int64_t N, int shift, int nbits, uint32_t* __restrict__ hist,
                     uint32_t* __restrict__ totals, int nblocks)
 {
     __shared__ uint32_t h[SORT_MAX_BINS];
@@ -281,9 +282,11 @@ sort_scan_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ total
     }
 }
 
+// vals_in == nullptr: the value of element i is i itself (first pass of an argsort)
+template <typename KeyT>
 __global__ void __launch_bounds__(SORT_THREADS)
-sort_downsweep_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t N, int shift,
+sort_downsweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t N, int shift,
                       int nbits, const uint32_t* __restrict__ hist, int nblocks)
 {
     __shared__ uint32_t cnt[4][SORT_MAX_BINS];
@@ -297,13 +300,13 @@ sort_downsweep_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __re
     const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * (SORT_ITEMS * 64);
     const uint32_t mask = (uint32_t)nbins - 1u;
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint64_t key[SORT_ITEMS];
+    KeyT key[SORT_ITEMS];
     uint32_t loc[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int64_t i = wbase + r * 64 + lane;
         const bool valid = i < N;
-        key[r] = valid ? keys_in[i] : ~0ull;
+        key[r] = valid ? keys_in[i] : (KeyT)~(KeyT)0;
         const uint32_t digit = (uint32_t)(key[r] >> shift) & mask;
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < nbits; ++b) {
@@ -336,46 +339,66 @@ sort_downsweep_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __re
             const uint32_t digit = (uint32_t)(key[r] >> shift) & mask;
             const uint32_t pos = cnt[w][digit] + loc[r];
             keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[i];
+            vals_out[pos] = vals_in ? vals_in[i] : (uint32_t)i;
         }
     }
 }
 
-void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
-                       uint32_t* totals, int64_t N, int num_bits, hipStream_t st)
+template <typename KeyT>
+static void sort_pairs_impl(KeyT* keys_a, KeyT* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool iota_values,
+                            uint32_t* hist, uint32_t* totals, int64_t N, int num_bits, hipStream_t st)
 {
     if (N <= 0) return;
     SortPlan p = make_plan(num_bits);
     const int nblocks = (int)((N + SORT_TILE - 1) / SORT_TILE);
     (void)hipMemsetAsync(totals, 0, sizeof(uint32_t) * SORT_MAX_BINS * 8, st);
-    uint64_t *kin = (p.passes & 1) ? keys_b : keys_a, *kout = (p.passes & 1) ? keys_a : keys_b;
+    KeyT *kin = (p.passes & 1) ? keys_b : keys_a, *kout = (p.passes & 1) ? keys_a : keys_b;
     uint32_t *vin = (p.passes & 1) ? vals_b : vals_a, *vout = (p.passes & 1) ? vals_a : vals_b;
     for (int i = 0; i < p.passes; ++i) {
         uint32_t* tot = totals + (size_t)i * SORT_MAX_BINS;
-        hipLaunchKernelGGL(sort_upsweep_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, N, p.shift[i], p.bits[i],
-                           hist, tot, nblocks);
+        hipLaunchKernelGGL(sort_upsweep_kernel<KeyT>, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, N, p.shift[i],
+                           p.bits[i], hist, tot, nblocks);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(1 << p.bits[i]), dim3(256), 0, st, hist, tot, nblocks);
-        hipLaunchKernelGGL(sort_downsweep_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N,
-                           p.shift[i], p.bits[i], hist, nblocks);
-        uint64_t* tk = kin; kin = kout; kout = tk;
+        hipLaunchKernelGGL(sort_downsweep_kernel<KeyT>, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin,
+                           (i == 0 && iota_values) ? (const uint32_t*)nullptr : vin, kout, vout, N, p.shift[i], p.bits[i],
+                           hist, nblocks);
+        KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
+}
+
+void launch_sort_pairs32(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool iota_values,
+                         uint32_t* hist, uint32_t* totals, int64_t N, int num_bits, hipStream_t st)
+{
+    sort_pairs_impl<uint32_t>(keys_a, keys_b, vals_a, vals_b, iota_values, hist, totals, N, num_bits, st);
+}
+
+// tt_sorted[r] = tiles_touched[order[r]]  (tile counts in depth order, input of the offsets scan)
+__global__ void __launch_bounds__(256)
+gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ order, uint32_t* __restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[order[i]];
+}
+void launch_gather_u32(const uint32_t* src, const uint32_t* order, uint32_t* dst, int n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, order, dst, n);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K5: tile ranges, the four per-quad bitmaps over the sorted list (one ballot per quad per 64 entries), and --
 // after a prefix sum over the bitmap words' popcounts -- the compacted per-quad lists the blend kernels stream.
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
+tile_ranges_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
                    uint2* __restrict__ ranges, uint64_t* __restrict__ bitmaps, uint32_t* __restrict__ wcount,
                    size_t bitmap_words)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t v = 0;
     if (i < N) {
-        const uint32_t t = (uint32_t)(keys[i] >> 32);
-        if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
-        if (i == N - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+        const uint32_t t = keys[i];
+        if (i == 0 || keys[i - 1] != t) ranges[t].x = (uint32_t)i;
+        if (i == N - 1 || keys[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
         v = values[i];
     }
     const size_t word = (size_t)(i >> 6);
@@ -391,7 +414,7 @@ tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict
 
 // wprefix holds the INCLUSIVE scan of the word popcounts on entry and the exclusive one on exit.
 __global__ void __launch_bounds__(256)
-compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
+compact_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ values, int64_t N,
                const uint2* __restrict__ ranges, const uint64_t* __restrict__ bitmaps, uint32_t* __restrict__ wprefix,
                size_t bitmap_words, uint64_t* __restrict__ act)
 {
@@ -401,7 +424,7 @@ compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ v
     if (word >= bitmap_words) return;  // whole wave
     uint64_t entry = 0;  // (pos1 << 32) | quad mask << 28 | gaussian
     if (i < N) {
-        const uint32_t t = (uint32_t)(keys[i] >> 32);
+        const uint32_t t = keys[i];
         const uint32_t pos1 = (uint32_t)i - ranges[t].x + 1u;
         entry = ((uint64_t)pos1 << 32) | (uint64_t)values[i];
     }
@@ -422,7 +445,7 @@ compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ v
     }
 }
 
-void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
+void launch_tile_ranges(const uint32_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
                         uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix, uint32_t* scan_tmp, uint64_t* act,
                         hipStream_t st)
 {

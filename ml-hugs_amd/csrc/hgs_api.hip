@@ -175,6 +175,7 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     if (!strcmp(name, "splats")) return g.splats;
     if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
     if (!strcmp(name, "offsets")) return g.offsets;
+    if (!strcmp(name, "order")) return g.order;
     if (!strcmp(name, "keys")) return b.keys;
     if (!strcmp(name, "values")) return b.values;
     if (!strcmp(name, "bitmaps")) return b.bitmaps;
@@ -209,10 +210,24 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
     uint32_t* offsets = (uint32_t*)(geom + gl.offsets);
     uint32_t* scan_tmp = (uint32_t*)(geom + gl.scan_tmp);
+    uint32_t *dk_a = (uint32_t*)(geom + gl.depth_keys), *dk_b = (uint32_t*)(geom + gl.depth_keys_alt);
+    uint32_t *order = (uint32_t*)(geom + gl.order), *order_b = (uint32_t*)(geom + gl.order_alt);
+    uint32_t* tt_sorted = (uint32_t*)(geom + gl.tt_sorted);
 
-    { ProfScope ps(HGS_STAGE_PREPROCESS, st); launch_preprocess(a, cam, splats, tiles_touched, st); }
+    // K1 writes the depth keys where the argsort expects its unsorted input (4 passes of 8 bits -> buffer a)
+    const bool dk_in_b = sort_input_buffer(32) != 0;
+    { ProfScope ps(HGS_STAGE_PREPROCESS, st); launch_preprocess(a, cam, splats, tiles_touched, dk_in_b ? dk_b : dk_a, st); }
     STAGE_CHECK(dbg, st, "preprocess");
-    { ProfScope ps(HGS_STAGE_SCAN, st); launch_scan_inclusive(tiles_touched, offsets, scan_tmp, a.P, st); }
+    // Two-level sort, level 1: stable argsort of the P Gaussians by depth bits (ties keep index order).
+    { ProfScope ps(HGS_STAGE_SORT, st);
+      launch_sort_pairs32(dk_a, dk_b, order, order_b, /*iota_values=*/true, (uint32_t*)(geom + gl.psort_hist),
+                          (uint32_t*)(geom + gl.psort_totals), a.P, 32, st); }
+    STAGE_CHECK(dbg, st, "depth_sort");
+    // offsets = inclusive scan of the tile counts taken in depth order: emission then produces, for every tile, its
+    // entries already in (depth, index) order, and only a stable partition by tile id remains (level 2).
+    { ProfScope ps(HGS_STAGE_SCAN, st);
+      launch_gather_u32(tiles_touched, order, tt_sorted, a.P, st);
+      launch_scan_inclusive(tt_sorted, offsets, scan_tmp, a.P, st); }
     STAGE_CHECK(dbg, st, "scan");
 
     // the one host synchronisation of the forward pass: N sizes the binning buffer
@@ -226,17 +241,17 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
     if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
     state->binning = bin, state->binning_bytes = bl.total;
-    uint64_t *keys_a = (uint64_t*)(bin + bl.keys), *keys_b = (uint64_t*)(bin + bl.keys_alt);
+    uint32_t *keys_a = (uint32_t*)(bin + bl.keys), *keys_b = (uint32_t*)(bin + bl.keys_alt);
     uint32_t *vals_a = (uint32_t*)(bin + bl.values), *vals_b = (uint32_t*)(bin + bl.values_alt);
     uint2* ranges = (uint2*)(image + il.ranges);
     const int num_tiles = cam.gx * cam.gy;
 
     if (N > 0) {
-        const int num_bits = 32 + bits_for((uint32_t)num_tiles);
+        const int num_bits = bits_for((uint32_t)num_tiles);  // level 2 sorts on the tile id only
         const bool in_b = sort_input_buffer(num_bits) != 0;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit_keys(a.P, cam, splats, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit_keys(a.P, cam, splats, order, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st); }
         STAGE_CHECK(dbg, st, "emit_keys");
-        { ProfScope ps(HGS_STAGE_SORT, st); launch_sort_pairs(keys_a, keys_b, vals_a, vals_b, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
+        { ProfScope ps(HGS_STAGE_SORT, st); launch_sort_pairs32(keys_a, keys_b, vals_a, vals_b, false, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
                           num_bits, st); }
         STAGE_CHECK(dbg, st, "sort");
     }

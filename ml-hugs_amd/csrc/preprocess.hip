@@ -103,7 +103,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                   const float* __restrict__ scales, const float* __restrict__ rots,
                   const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
-                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii)
+                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys, int32_t* __restrict__ radii)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -199,16 +199,17 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     dst[1] = make_float4(out.cc, out.opacity, out.r, out.g);
     dst[2] = make_float4(out.b, out.depth, __int_as_float(out.radius), __uint_as_float(out.clamped));
     tiles_touched[i] = touched;
+    depth_keys[i] = __float_as_uint(out.depth);  // positive floats order like their bit patterns; culled => 0
     radii[i] = out.radius;
 }
 
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       hipStream_t st)
+                       uint32_t* depth_keys, hipStream_t st)
 {
     int blocks = (a.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
                        a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
-                       a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii);
+                       a.s.projmatrix, a.s.campos, splats, tiles_touched, depth_keys, a.radii);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -391,9 +391,13 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
         holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W)
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
-        holder["keys"] = sub(binning, "keys", 8 * N, torch.int64)
+        holder["order"] = sub(geom, "order", 4 * P, torch.int32)           # Gaussian index at depth rank r
+        holder["tile_keys"] = sub(binning, "keys", 4 * N, torch.int32)      # sorted list: tile id of entry i
         raw = sub(binning, "values", 4 * N, torch.int32)
-        holder["values"] = raw & 0x0FFFFFFF                 # Gaussian index
-        holder["quad_masks"] = (raw >> 28) & 0xF            # conservative 8x8-quad coverage mask
+        holder["values"] = raw & 0x0FFFFFFF                                 # sorted list: Gaussian index of entry i
+        holder["quad_masks"] = (raw >> 28) & 0xF                            # conservative 8x8-quad coverage mask
+        # the 64-bit key of entry i (tile << 32 | fp32 depth bits), re-assembled from what the device keeps
+        depth_bits = holder["splats"][:, 9].contiguous().view(torch.int32)[holder["values"].long()].long() & 0xFFFFFFFF
+        holder["keys"] = (holder["tile_keys"].long() << 32) | depth_bits
     holder["N"] = N
     return color.detach(), radii, holder

@@ -105,7 +105,12 @@ def test_forward_stages_and_image(name, device):
     assert np.array_equal(sp[vis, 11].view(np.uint32), clamp_bits[vis].astype(np.uint32))
     # ---- K2..K5 exact
     assert st["N"] == ref["N"]
-    assert np.array_equal(st["offsets"].cpu().numpy().view(np.uint32), ref["offsets"])
+    # level 1 of the sort: stable argsort of the Gaussians by fp32 depth bits (culled ones carry 0); the device's
+    # `offsets` are the inclusive scan of the tile counts in THAT order (the oracle's are in index order)
+    dbits = np.where(vis, np.ascontiguousarray(ref["depths"]).view(np.uint32), 0).astype(np.uint32)
+    order = np.argsort(dbits, kind="stable")
+    assert np.array_equal(st["order"].cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(st["offsets"].cpu().numpy().view(np.uint32), np.cumsum(ref["tiles_touched"][order], dtype=np.uint64).astype(np.uint32))
     assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
     assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
     assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])

@@ -17,7 +17,7 @@
  * image state) is obtained through the caller's allocation callback so that it lives in
  * caller-owned memory (torch uint8 tensors kept by the autograd ctx until backward).
  * All work is enqueued on `stream` (a hipStream_t); forward performs ONE host
- * synchronisation on that stream (to learn N and size the binning buffer).
+ * synchronisation on that stream (to learn N, the number of (tile, Gaussian) pairs, and size the binning buffer).
  * All floating point is fp32, contiguous.
  */
 #ifndef HGS_RASTERIZER_H
@@ -146,11 +146,9 @@ void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);
 
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
- * Names: geom: "splats","tiles_touched","offsets"; binning: "keys","values","bitmaps";
- * image: "final_T","n_contrib","ranges". Returns (size_t)-1 for an unknown name.
- * For "keys"/"values" the offset is of the SORTED list and depends on the last forward's N
- * and image size. */
-/* NB: a sorted `values` entry is (quad coverage mask << 28) | Gaussian index. */
+ * Names: geom: "splats" (48-byte records), "tiles_touched"; binning: "list" (the sorted list, one u64 per entry:
+ * (1-based position inside the tile << 32) | quad coverage mask << 28 | Gaussian index), "bitmaps";
+ * image: "final_T", "n_contrib", "ranges". Returns (size_t)-1 for an unknown name. */
 size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int32_t image_height,
                           int32_t image_width);
 

@@ -174,10 +174,7 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     BinningLayout b(N);
     if (!strcmp(name, "splats")) return g.splats;
     if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
-    if (!strcmp(name, "offsets")) return g.offsets;
-    if (!strcmp(name, "order")) return g.order;
-    if (!strcmp(name, "keys")) return b.keys;
-    if (!strcmp(name, "values")) return b.values;
+    if (!strcmp(name, "list")) return b.list;
     if (!strcmp(name, "bitmaps")) return b.bitmaps;
     if (!strcmp(name, "final_T")) return im.final_T;
     if (!strcmp(name, "n_contrib")) return im.n_contrib;
@@ -208,31 +205,22 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     Splat* splats = (Splat*)(geom + gl.splats);
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
-    uint32_t* offsets = (uint32_t*)(geom + gl.offsets);
-    uint32_t* scan_tmp = (uint32_t*)(geom + gl.scan_tmp);
-    uint32_t *dk_a = (uint32_t*)(geom + gl.depth_keys), *dk_b = (uint32_t*)(geom + gl.depth_keys_alt);
-    uint32_t *order = (uint32_t*)(geom + gl.order), *order_b = (uint32_t*)(geom + gl.order_alt);
-    uint32_t* tt_sorted = (uint32_t*)(geom + gl.tt_sorted);
+    uint2* ranges = (uint2*)(image + il.ranges);
+    uint32_t* tile_count = (uint32_t*)(image + il.tile_count);
+    uint32_t* cursor = (uint32_t*)(image + il.cursor);
+    uint32_t* n_total = (uint32_t*)(image + il.n_total);
+    const int num_tiles = cam.gx * cam.gy;
 
-    // K1 writes the depth keys where the argsort expects its unsorted input (4 passes of 8 bits -> buffer a)
-    const bool dk_in_b = sort_input_buffer(32) != 0;
-    { ProfScope ps(HGS_STAGE_PREPROCESS, st); launch_preprocess(a, cam, splats, tiles_touched, dk_in_b ? dk_b : dk_a, st); }
+    { ProfScope ps(HGS_STAGE_PREPROCESS, st);
+      HIP_TRY(hipMemsetAsync(tile_count, 0, il.counters_bytes, st));
+      launch_preprocess(a, cam, splats, tiles_touched, tile_count, st); }
     STAGE_CHECK(dbg, st, "preprocess");
-    // Two-level sort, level 1: stable argsort of the P Gaussians by depth bits (ties keep index order).
-    { ProfScope ps(HGS_STAGE_SORT, st);
-      launch_sort_pairs32(dk_a, dk_b, order, order_b, /*iota_values=*/true, (uint32_t*)(geom + gl.psort_hist),
-                          (uint32_t*)(geom + gl.psort_totals), a.P, 32, st); }
-    STAGE_CHECK(dbg, st, "depth_sort");
-    // offsets = inclusive scan of the tile counts taken in depth order: emission then produces, for every tile, its
-    // entries already in (depth, index) order, and only a stable partition by tile id remains (level 2).
-    { ProfScope ps(HGS_STAGE_SCAN, st);
-      launch_gather_u32(tiles_touched, order, tt_sorted, a.P, st);
-      launch_scan_inclusive(tt_sorted, offsets, scan_tmp, a.P, st); }
-    STAGE_CHECK(dbg, st, "scan");
+    { ProfScope ps(HGS_STAGE_SCAN, st); launch_tile_scan(tile_count, cam.gx, cam.gy, ranges, cursor, n_total, st); }
+    STAGE_CHECK(dbg, st, "tile_scan");
 
     // the one host synchronisation of the forward pass: N sizes the binning buffer
     uint32_t n32 = 0;
-    HIP_TRY(hipMemcpyAsync(&n32, offsets + (a.P - 1), sizeof n32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n32, n_total, sizeof n32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t N = (int64_t)n32;
     state->num_rendered = N;
@@ -241,23 +229,20 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
     if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
     state->binning = bin, state->binning_bytes = bl.total;
-    uint32_t *keys_a = (uint32_t*)(bin + bl.keys), *keys_b = (uint32_t*)(bin + bl.keys_alt);
-    uint32_t *vals_a = (uint32_t*)(bin + bl.values), *vals_b = (uint32_t*)(bin + bl.values_alt);
-    uint2* ranges = (uint2*)(image + il.ranges);
-    const int num_tiles = cam.gx * cam.gy;
+    uint32_t* values = (uint32_t*)(bin + bl.values);
+    uint64_t* list = (uint64_t*)(bin + bl.list);
+    uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
 
     if (N > 0) {
-        const int num_bits = bits_for((uint32_t)num_tiles);  // level 2 sorts on the tile id only
-        const bool in_b = sort_input_buffer(num_bits) != 0;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit_keys(a.P, cam, splats, order, offsets, in_b ? keys_b : keys_a, in_b ? vals_b : vals_a, st); }
-        STAGE_CHECK(dbg, st, "emit_keys");
-        { ProfScope ps(HGS_STAGE_SORT, st); launch_sort_pairs32(keys_a, keys_b, vals_a, vals_b, false, (uint32_t*)(bin + bl.hist), (uint32_t*)(bin + bl.totals), N,
-                          num_bits, st); }
-        STAGE_CHECK(dbg, st, "sort");
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, values, st); }
+        STAGE_CHECK(dbg, st, "emit");
+        { ProfScope ps(HGS_STAGE_SORT, st); launch_tile_sort(ranges, num_tiles, values, splats, list, (uint64_t*)(bin + bl.scratch), st); }
+        STAGE_CHECK(dbg, st, "tile_sort");
     }
-    { ProfScope ps(HGS_STAGE_TILE_RANGES, st); launch_tile_ranges(keys_a, vals_a, N, ranges, num_tiles, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words,
-                       (uint32_t*)(bin + bl.wprefix), (uint32_t*)(bin + bl.scan_tmp), (uint64_t*)(bin + bl.act) + ACT_PAD, st); }
-    STAGE_CHECK(dbg, st, "tile_ranges");
+    { ProfScope ps(HGS_STAGE_TILE_RANGES, st);
+      launch_bitmaps_and_compact(list, N, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, (uint32_t*)(bin + bl.wprefix),
+                                 (uint32_t*)(bin + bl.scan_tmp), act, st); }
+    STAGE_CHECK(dbg, st, "bitmaps_compact");
     { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, (const uint64_t*)(bin + bl.act) + ACT_PAD, (const uint32_t*)(bin + bl.wprefix),
                          (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
                          (uint32_t*)(image + il.n_contrib), st); }

@@ -42,55 +42,50 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
 struct GeomLayout {
-    size_t splats, tiles_touched, offsets, scan_tmp, total;
+    size_t splats, tiles_touched, total;
     explicit GeomLayout(int P) {
         size_t o = 0;
-        splats = o;        o = align_up(o + sizeof(Splat) * (size_t)P);
-        tiles_touched = o; o = align_up(o + 4 * (size_t)P);
-        offsets = o;       o = align_up(o + 4 * (size_t)P);
-        scan_tmp = o;      o = align_up(o + 4 * ((size_t)P / 1024 + 2) + 64);
+        splats = o;         o = align_up(o + sizeof(Splat) * (size_t)P);
+        tiles_touched = o;  o = align_up(o + 4 * (size_t)P);
         total = o;
     }
 };
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, total;
+    size_t final_T, n_contrib, ranges, tile_count, cursor, n_total, total;
+    size_t counters_bytes;  // tile_count .. n_total are contiguous: one memset before the preprocess kernel
     ImageLayout(int H, int W) {
         size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
         size_t o = 0;
-        final_T = o;   o = align_up(o + 4 * S);
-        n_contrib = o; o = align_up(o + 4 * S);
-        ranges = o;    o = align_up(o + 8 * T);
+        final_T = o;    o = align_up(o + 4 * S);
+        n_contrib = o;  o = align_up(o + 4 * S);
+        ranges = o;     o = align_up(o + 8 * T);
+        // 2-D difference array of "Gaussians touching each tile" on the (gx+1) x (gy+1) grid (atomics in K1)
+        tile_count = o; o = align_up(o + 4 * (size_t)((H + TILE - 1) / TILE + 1) * ((W + TILE - 1) / TILE + 1));
+        cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
+        n_total = o;    o = align_up(o + 64);
+        counters_bytes = o - tile_count;
         total = o;
     }
 };
 constexpr int ACT_PAD = 16;
 constexpr int NUM_BITMAPS = 5;  // four per-quad bitmaps + one "any quad" bitmap over the sorted list
-constexpr int SORT_ITEMS = 16;                     // keys per thread per block
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_TILE = SORT_ITEMS * SORT_THREADS;  // 4096 keys per block
-constexpr int SORT_MAX_BINS = 512;                 // up to 9-bit digits
 struct BinningLayout {
-    size_t keys, keys_alt, values, values_alt, hist, totals, bitmaps, wprefix, scan_tmp, act, total;
-    size_t nblocks, bitmap_words;  // bitmap_words = u64 words per quad bitmap
+    size_t values, list, scratch, bitmaps, wprefix, scan_tmp, act, total;
+    size_t bitmap_words;  // u64 words per bitmap
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
-        nblocks = (n + SORT_TILE - 1) / SORT_TILE;
         size_t o = 0;
-        keys = o;       o = align_up(o + 8 * n);
-        keys_alt = o;   o = align_up(o + 8 * n);
-        values = o;     o = align_up(o + 4 * n + 64);  // +64: the blend kernels fetch list entries 4 at a time
-        values_alt = o; o = align_up(o + 4 * n + 64);
-        hist = o;       o = align_up(o + 4 * (size_t)SORT_MAX_BINS * nblocks);
-        totals = o;     o = align_up(o + 4 * (size_t)SORT_MAX_BINS * 8);
-        // 4 bitmaps (one per 8x8 quad of a tile) over the sorted list: bit i of bitmap q <=> entry i covers quad q
+        values = o;     o = align_up(o + 4 * n);   // bucket-scattered, unsorted: mask << 28 | gaussian
+        list = o;       o = align_up(o + 8 * n);   // sorted: (pos1 << 32) | mask << 28 | gaussian
+        scratch = o;    o = align_up(o + 8 * n);   // keys of tiles too long for LDS (fallback path of tile_sort)
         bitmap_words = n / 64 + 4;
         bitmaps = o;    o = align_up(o + 8 * NUM_BITMAPS * bitmap_words);
-        // wprefix[q * bitmap_words + w] = number of set bits of all earlier words (quads concatenated): the position
-        // of word w's first covering entry in the compacted list `act`
+        // wprefix[q * bitmap_words + w] = number of set bits of all earlier words (bitmaps concatenated): the
+        // position of word w's first covering entry in the compacted list `act`
         wprefix = o;    o = align_up(o + 4 * NUM_BITMAPS * bitmap_words);
         scan_tmp = o;   o = align_up(o + 4 * (NUM_BITMAPS * bitmap_words / 1024 + 2) + 64);
-        // act: for each quad, the covering entries of the sorted list, in list order, as (pos1 << 32 | gaussian);
-        // worst case 4 N entries; ACT_PAD dead entries in front (the backward walk reads pairs downwards) and behind
+        // act: for each bitmap, its covering entries in list order; worst case NUM_BITMAPS * N entries; ACT_PAD dead
+        // entries in front (the backward walk reads pairs downwards) and behind
         act = o;        o = align_up(o + 8 * (NUM_BITMAPS * n + 2 * ACT_PAD));
         total = o;
     }
@@ -98,22 +93,19 @@ struct BinningLayout {
 
 // kernels / launchers (defined in the .hip files)
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       hipStream_t st);
+                       uint32_t* tile_count, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
 void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st);
-void launch_emit_keys(int P, const Camera& cam, const Splat* splats, const uint32_t* offsets, uint64_t* keys,
-                      uint32_t* values, hipStream_t st);
-// sorts N (key,value) pairs on key bits [0,num_bits); result ends in (keys_a, vals_a).
-// returns which buffer the UNSORTED input must be placed in: 0 => (keys_a, vals_a), 1 => (keys_b, vals_b)
-int sort_input_buffer(int num_bits);
-void launch_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* hist,
-                       uint32_t* totals, int64_t N, int num_bits, hipStream_t st);
-// ranges + quad bitmaps + compacted per-quad entry lists (act points at the first real entry, after the front pad)
-void launch_tile_ranges(const uint64_t* keys, const uint32_t* values, int64_t N, uint2* ranges, int num_tiles,
-                        uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix, uint32_t* scan_tmp, uint64_t* act,
-                        hipStream_t st);
+void launch_tile_scan(uint32_t* tile_count_diff, int gx, int gy, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+                      hipStream_t st);
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint32_t* values, hipStream_t st);
+void launch_tile_sort(const uint2* ranges, int num_tiles, const uint32_t* values, const Splat* splats, uint64_t* list,
+                      uint64_t* scratch, hipStream_t st);
+// act points at the first real entry (after the front pad)
+void launch_bitmaps_and_compact(const uint64_t* list, int64_t N, uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix,
+                                uint32_t* scan_tmp, uint64_t* act, hipStream_t st);
 
 void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
                           const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,

@@ -387,17 +387,19 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
     if P > 0:
         holder["splats"] = sub(geom, "splats", 48 * P, torch.float32).view(P, 12)
         holder["tiles_touched"] = sub(geom, "tiles_touched", 4 * P, torch.int32)
-        holder["offsets"] = sub(geom, "offsets", 4 * P, torch.int32)
         holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
         holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W)
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
-        holder["order"] = sub(geom, "order", 4 * P, torch.int32)           # Gaussian index at depth rank r
-        holder["tile_keys"] = sub(binning, "keys", 4 * N, torch.int32)      # sorted list: tile id of entry i
-        raw = sub(binning, "values", 4 * N, torch.int32)
-        holder["values"] = raw & 0x0FFFFFFF                                 # sorted list: Gaussian index of entry i
-        holder["quad_masks"] = (raw >> 28) & 0xF                            # conservative 8x8-quad coverage mask
-        # the 64-bit key of entry i (tile << 32 | fp32 depth bits), re-assembled from what the device keeps
+        lst = sub(binning, "list", 8 * N, torch.int64)                      # sorted: (pos1 << 32) | mask << 28 | gaussian
+        raw = lst & 0xFFFFFFFF
+        holder["values"] = (raw & 0x0FFFFFFF).to(torch.int32)               # sorted list: Gaussian index of entry i
+        holder["quad_masks"] = ((raw >> 28) & 0xF).to(torch.int32)          # conservative 8x8-quad coverage mask
+        holder["pos1"] = (lst >> 32).to(torch.int32)                        # 1-based position inside the tile
+        # the 64-bit key of entry i (tile << 32 | fp32 depth bits), re-assembled from what the device keeps:
+        # the tile is the one whose range holds i, the depth is the Gaussian's
+        counts = (holder["ranges"][:, 1] - holder["ranges"][:, 0]).long()
+        tile_of = torch.repeat_interleave(torch.arange(T, device=lst.device), counts)
         depth_bits = holder["splats"][:, 9].contiguous().view(torch.int32)[holder["values"].long()].long() & 0xFFFFFFFF
-        holder["keys"] = (holder["tile_keys"].long() << 32) | depth_bits
+        holder["keys"] = (tile_of << 32) | depth_bits
     holder["N"] = N
     return color.detach(), radii, holder

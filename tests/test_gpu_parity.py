@@ -2,7 +2,7 @@
 C ABI of include/hgs_rasterizer.h), against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star "bit-exact for tile/key indexing"):
-  * integers -- radii, tiles_touched, offsets, N, sorted (key,value) list, tile ranges -- EXACT
+  * integers -- radii, tiles_touched, N, sorted (key,value) list, tile ranges -- EXACT
   * per-Gaussian fp32 projection outputs (pixel xy, depth, conic, colour) -- bit-exact (same op order,
     IEEE div/sqrt, no contraction)
   * blend: the only arithmetic difference vs the oracle is the GPU's exp; a pixel whose alpha sits
@@ -105,12 +105,10 @@ def test_forward_stages_and_image(name, device):
     assert np.array_equal(sp[vis, 11].view(np.uint32), clamp_bits[vis].astype(np.uint32))
     # ---- K2..K5 exact
     assert st["N"] == ref["N"]
-    # level 1 of the sort: stable argsort of the Gaussians by fp32 depth bits (culled ones carry 0); the device's
-    # `offsets` are the inclusive scan of the tile counts in THAT order (the oracle's are in index order)
-    dbits = np.where(vis, np.ascontiguousarray(ref["depths"]).view(np.uint32), 0).astype(np.uint32)
-    order = np.argsort(dbits, kind="stable")
-    assert np.array_equal(st["order"].cpu().numpy(), order.astype(np.int32))
-    assert np.array_equal(st["offsets"].cpu().numpy().view(np.uint32), np.cumsum(ref["tiles_touched"][order], dtype=np.uint64).astype(np.uint32))
+    # the device bucket-scatters entries into per-tile segments and sorts every segment by (depth bits, index):
+    # list position, tile, depth key and Gaussian of every entry must equal the oracle's stable 64-bit-key sort
+    rr = ref["ranges"].astype(np.int64)
+    assert np.array_equal(st["pos1"].cpu().numpy(), (np.arange(ref["N"]) - np.repeat(rr[:, 0], rr[:, 1] - rr[:, 0]) + 1).astype(np.int32))
     assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
     assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
     assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])

@@ -111,40 +111,18 @@ void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile_scan: single workgroup.  Integrates K1's 2-D difference array into per-tile counts (row pass, column
-// pass; in LDS when the grid fits, in place in global memory otherwise), then scans the counts in tile order.
-// ranges[t] = (0,0) for an empty tile (as the oracle leaves them).
-constexpr int TILE_SCAN_LDS_CELLS = 36 * 1024;  // 144 KB of the CU's 160 KB
-
+// tile_scan: single workgroup; exclusive scan of the per-tile counts.  ranges[t] = (0,0) for an empty tile (as the
+// oracle leaves them); cursor[t] = start of the tile's segment; *n_total = N.
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(uint32_t* __restrict__ diff, int gx, int gy, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                 uint32_t* __restrict__ n_total)
+tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
+                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total)
 {
-    extern __shared__ uint32_t grid_lds[];
     __shared__ uint32_t wsum[16];
-    const int pitch = gx + 1, cells = pitch * (gy + 1), num_tiles = gx * gy;
-    const bool in_lds = cells <= TILE_SCAN_LDS_CELLS;
-    uint32_t* g = in_lds ? grid_lds : diff;
-    if (in_lds) {
-        for (int i = threadIdx.x; i < cells; i += 1024) g[i] = diff[i];
-        __syncthreads();
-    }
-    for (int y = threadIdx.x; y <= gy; y += 1024) {  // prefix along x
-        uint32_t acc = 0;
-        for (int x = 0; x <= gx; ++x) acc += g[y * pitch + x], g[y * pitch + x] = acc;
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x <= gx; x += 1024) {  // prefix along y
-        uint32_t acc = 0;
-        for (int y = 0; y <= gy; ++y) acc += g[y * pitch + x], g[y * pitch + x] = acc;
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (int base = 0; base < num_tiles; base += 1024) {
         const int t = base + threadIdx.x;
-        const uint32_t c = t < num_tiles ? g[(t / gx) * pitch + (t % gx)] : 0u;
+        const uint32_t c = t < num_tiles ? tile_count[t] : 0u;
         const uint32_t inc = wave_inclusive_scan(c);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
@@ -166,12 +144,10 @@ tile_scan_kernel(uint32_t* __restrict__ diff, int gx, int gy, uint2* __restrict_
     if (threadIdx.x == 0) *n_total = carry;
 }
 
-void launch_tile_scan(uint32_t* tile_count_diff, int gx, int gy, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       hipStream_t st)
 {
-    const int cells = (gx + 1) * (gy + 1);
-    const size_t lds = cells <= TILE_SCAN_LDS_CELLS ? sizeof(uint32_t) * (size_t)cells : 0;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), lds, st, tile_count_diff, gx, gy, ranges, cursor, n_total);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -204,16 +180,25 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
     return best;
 }
 
-__global__ void __launch_bounds__(256)
-emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
-            uint32_t* __restrict__ values)
-{
-    __shared__ float4 stage[4][64][3];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g0 = (blockIdx.x * 4 + w) * 64;
-    if (g0 >= P) return;  // whole wave
-    const int g = g0 + lane;
+// Both binning kernels below walk the (Gaussian, tile) pairs the same way.  A workgroup owns BIN_GROUP Gaussians;
+// wave w takes them 64 at a time, stages their rectangles in LDS, prefix-sums the tile counts in registers and
+// deals the pairs to lanes 64 at a time.  Atomics are aggregated per workgroup in an LDS array indexed by tile
+// and touch global memory once per (workgroup, tile) with coalesced vector atomics: scattered global atomics cost
+// ~15 G cache-line transactions/s on this chip, i.e. more than everything else in the binning phase together.
+constexpr int BIN_GROUP = 1024;           // Gaussians per workgroup
+constexpr int BIN_THREADS = 1024;         // 16 waves: one 64-Gaussian group each
+constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to 48 KB of staging
 
+struct PairStage {  // one wave's 64 staged Gaussians
+    float4 (*rec)[3];
+    uint32_t incl, total;
+};
+
+__device__ __forceinline__ void stage_wave(int P, const Camera& cam, const Splat* __restrict__ splats, int g0,
+                                           bool with_mask_inputs, PairStage& st)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = g0 + lane;
     uint32_t cnt = 0;
     float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = make_float4(-1.f, 3.0e38f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
     if (g < P) {
@@ -221,7 +206,6 @@ emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __res
         const int radius = __float_as_int(tail.z);
         if (radius > 0) {
             const float4 head = reinterpret_cast<const float4*>(splats + g)[0];
-            const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
             const float px = head.x, py = head.y, radf = (float)radius;
             // identical expressions to the preprocess kernel => identical rectangle
             const int minx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
@@ -229,94 +213,247 @@ emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __res
             const int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
             const int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
             cnt = (uint32_t)((maxx - minx) * (maxy - miny));
-            // contributes iff opacity * exp(power) >= 1/255  <=>  power >= -(ln 255 + ln opacity); 0.05 of slack
-            // covers the blend kernels' rounding (and makes the mask a strict superset)
-            const float thr = -(5.5412635f + __logf(mid.y)) - 0.05f;
             r0 = make_float4(px, py, head.z, head.w);
-            r1 = make_float4(mid.x, thr, 0.f, 0.f);
+            if (with_mask_inputs) {
+                const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
+                // contributes iff opacity * exp(power) >= 1/255  <=>  power >= -(ln 255 + ln opacity); 0.05 of
+                // slack covers the blend kernels' rounding (and makes the mask a strict superset)
+                const float thr = -(5.5412635f + __logf(mid.y)) - 0.05f;
+                r1 = make_float4(mid.x, thr, tail.y, 0.f);  // C, threshold, depth
+            }
             r2 = make_float4(__int_as_float(minx), __int_as_float(miny), __int_as_float(maxx - minx), 0.f);
         }
     }
-    const uint32_t incl = wave_inclusive_scan(cnt);
-    r1.w = __uint_as_float(incl - cnt);
-    stage[w][lane][0] = r0, stage[w][lane][1] = r1, stage[w][lane][2] = r2;
+    st.incl = wave_inclusive_scan(cnt);
+    r1.w = __uint_as_float(st.incl - cnt);
+    __builtin_amdgcn_wave_barrier();  // the previous group's readers are done (same wave, in-order LDS)
+    st.rec[lane][0] = r0, st.rec[lane][1] = r1, st.rec[lane][2] = r2;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    st.total = (uint32_t)__shfl((int)st.incl, 63, 64);
+}
 
-    // four rounds of 64 pairs per trip: the four returning atomics of a lane are independent and in flight together
-    for (uint32_t s0 = 0; s0 < total; s0 += 256) {
-        uint32_t tile_id[4], val[4];
-        bool valid[4];
+// calls f(owner_lane, tx, ty, rec0, rec1) for every pair of the staged wave, 64 pairs per trip
+template <class F>
+__device__ __forceinline__ void for_each_pair(const PairStage& st, F&& f)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t s0 = 0; s0 < st.total; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        // owner = smallest lane whose inclusive count exceeds s (all lanes take part in the shuffles)
+        int lo = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t s = s0 + u * 64 + lane;
-            // owner = smallest lane whose inclusive count exceeds s (all lanes take part in the shuffles)
-            int lo = 0;
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const uint32_t v = (uint32_t)__shfl((int)incl, lo + step - 1, 64);
-                if (v <= s) lo += step;
-            }
-            valid[u] = s < total;
-            tile_id[u] = 0, val[u] = 0;
-            if (valid[u]) {
-                const float4 a = stage[w][lo][0], b = stage[w][lo][1], c = stage[w][lo][2];
-                const uint32_t k = s - __float_as_uint(b.w);
-                const uint32_t wdt = (uint32_t)__float_as_int(c.z);
-                const uint32_t ry = k / wdt, rx = k - ry * wdt;
-                const int tx = __float_as_int(c.x) + (int)rx, ty = __float_as_int(c.y) + (int)ry;
-                const float A = a.z, B = a.w, C = b.x, thr = b.y;
-                uint32_t mask = 0xFu;
-                if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
-                    mask = 0;
-                    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
-                            mask |= 1u << q;
-                }
-                tile_id[u] = (uint32_t)(ty * cam.gx + tx);
-                val[u] = (mask << GID_BITS) | (uint32_t)(g0 + lo);
-            }
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t v = (uint32_t)__shfl((int)st.incl, lo + step - 1, 64);
+            if (v <= s) lo += step;
         }
-        uint32_t slot[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) slot[u] = valid[u] ? atomicAdd(&cursor[tile_id[u]], 1u) : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (valid[u]) values[slot[u]] = val[u];
+        if (s < st.total) {
+            const float4 a = st.rec[lo][0], b = st.rec[lo][1], c = st.rec[lo][2];
+            const uint32_t k = s - __float_as_uint(b.w);
+            const uint32_t wdt = (uint32_t)__float_as_int(c.z);
+            const uint32_t ry = k / wdt, rx = k - ry * wdt;
+            f(lo, __float_as_int(c.x) + (int)rx, __float_as_int(c.y) + (int)ry, a, b);
+        }
     }
 }
 
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint32_t* values, hipStream_t st)
+// count: tile_count[t] += number of Gaussians of this workgroup touching tile t
+template <bool USE_LDS>
+__global__ void __launch_bounds__(BIN_THREADS)
+count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ tile_count)
 {
-    hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, cam, splats, cursor, values);
+    extern __shared__ uint32_t hist[];
+    __shared__ float4 stage[BIN_THREADS / 64][64][3];
+    const int w = threadIdx.x >> 6, num_tiles = cam.gx * cam.gy;
+    uint32_t* bins = USE_LDS ? hist : tile_count;
+    if (USE_LDS) {
+        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
+        __syncthreads();
+    }
+    PairStage st;
+    st.rec = stage[w];
+    for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
+        const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
+        if (g0 >= P) break;
+        stage_wave(P, cam, splats, g0, false, st);
+        for_each_pair(st, [&](int, int tx, int ty, const float4&, const float4&) { atomicAdd(&bins[ty * cam.gx + tx], 1u); });
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
+        }
+    }
+}
+
+// emit: every pair takes a slot of its tile's segment and stores its 64-bit sort key there.
+// The value's low 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on some
+// pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never missing):
+// the blend kernels skip a (quad, splat) pair whose bit is clear without touching a VGPR.
+template <bool USE_LDS>
+__global__ void __launch_bounds__(BIN_THREADS)
+emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
+            uint64_t* __restrict__ keys)
+{
+    extern __shared__ uint32_t hist[];
+    __shared__ float4 stage[BIN_THREADS / 64][64][3];
+    const int w = threadIdx.x >> 6, num_tiles = cam.gx * cam.gy;
+    uint32_t* bins = USE_LDS ? hist : cursor;
+    PairStage st;
+    st.rec = stage[w];
+    if (USE_LDS) {
+        // pass A: this workgroup's population of every tile; then ONE returning atomic per touched tile reserves
+        // a contiguous run of the tile's segment, and bins[] becomes the workgroup-private cursor into it
+        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
+        __syncthreads();
+        for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
+            const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
+            if (g0 >= P) break;
+            stage_wave(P, cam, splats, g0, false, st);
+            for_each_pair(st, [&](int, int tx, int ty, const float4&, const float4&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) {
+            const uint32_t c = hist[t];
+            if (c) hist[t] = atomicAdd(&cursor[t], c);
+        }
+        __syncthreads();
+    }
+    for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
+        const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
+        if (g0 >= P) break;
+        stage_wave(P, cam, splats, g0, true, st);
+        for_each_pair(st, [&](int lo, int tx, int ty, const float4& a, const float4& b) {
+            const float A = a.z, B = a.w, C = b.x, thr = b.y;
+            uint32_t mask = 0xFu;
+            if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
+                mask = 0;
+                const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
+                        mask |= 1u << q;
+            }
+            const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
+            // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
+            keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + lo) << 4) | mask);
+        });
+    }
+}
+
+void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
+{
+    const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
+    if (num_tiles <= BIN_LDS_TILES)
+        hipLaunchKernelGGL(count_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, tile_count);
+    else
+        hipLaunchKernelGGL(count_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
+}
+
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, hipStream_t st)
+{
+    const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
+    if (num_tiles <= BIN_LDS_TILES)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, keys);
+    else
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, keys);
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile_sort: one workgroup per tile; CAP = LDS capacity in entries.  Kernel<CAP_SMALL> sorts the tiles with
-// n <= CAP_SMALL, kernel<CAP_LARGE> those with CAP_SMALL < n <= CAP_LARGE and -- by brute-force ranking through
-// global scratch, slow but only for absurdly dense tiles -- everything longer.
+// tile_sort: one workgroup per tile.  tile_sort_small_kernel sorts the tiles with n <= CAP_SMALL in registers;
+// tile_sort_kernel<CAP_LARGE> (bitonic in LDS) those with CAP_SMALL < n <= CAP_LARGE and -- by brute-force ranking
+// through global scratch, slow but only for absurdly dense tiles -- everything longer.
 // Sort key: (depth bits << 32) | (gaussian << 4) | mask: depth first, then Gaussian index (the mask rides along).
 // Output: list[i] = (pos1 << 32) | (mask << 28 | gaussian), pos1 = 1-based position inside the tile.
 constexpr int SORT_CAP_SMALL = 1024, SORT_CAP_LARGE = 8192;
 
-__device__ __forceinline__ uint64_t sort_key(const Splat* __restrict__ splats, uint32_t v)
-{
-    const uint32_t gid = v & GID_MASK;
-    const uint32_t dbits = __float_as_uint(reinterpret_cast<const float*>(splats + gid)[9]);
-    return ((uint64_t)dbits << 32) | (uint64_t)((gid << 4) | (v >> GID_BITS));
-}
 __device__ __forceinline__ uint64_t list_entry(uint64_t key, uint32_t pos1)
 {
     const uint32_t low = (uint32_t)key;
     return ((uint64_t)pos1 << 32) | (uint64_t)(((low & 15u) << GID_BITS) | (low >> 4));
 }
 
+// Small tiles (n <= 1024, i.e. practically all of them): the bitonic network runs in REGISTERS.  Thread t holds
+// elements i = e * 256 + t (e < E = m / 256).  A compare-exchange distance j >= 256 pairs two registers of the
+// same thread, j < 64 pairs two lanes of a wave (ds_bpermute shuffles, no barrier), and only j = 64 / 128 go
+// through LDS with barriers -- 3 of the 36 steps at m = 256.
+template <int E>
+__device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_t* sh)
+{
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (uint32_t k = 2; k <= 256u * E; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 256u) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int f = e | (int)(j >> 8);
+                    if (f != e && f < E) {
+                        const bool asc = (((uint32_t)e * 256u + tid) & k) == 0u;
+                        const uint64_t a = key[e], b = key[f];
+                        if ((a > b) == asc) key[e] = b, key[f] = a;
+                    }
+                }
+            } else {
+                uint64_t other[E];
+                if (j >= 64u) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) sh[e * 256 + tid] = key[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = sh[e * 256 + (tid ^ j)];
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = __shfl_xor((unsigned long long)key[e], (int)j, 64);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = (uint32_t)e * 256u + tid;
+                    const bool want_min = ((i & j) == 0u) == ((i & k) == 0u);
+                    const uint64_t a = key[e], b = other[e];
+                    key[e] = want_min ? (a < b ? a : b) : (a > b ? a : b);
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void tile_sort_small(uint32_t s, uint32_t n, const uint64_t* __restrict__ keys,
+                                                uint64_t* __restrict__ list, uint64_t* sh)
+{
+    uint64_t key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * 256u + threadIdx.x;
+        key[e] = i < n ? keys[s + i] : ~0ull;
+    }
+    bitonic_in_registers<E>(key, sh);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * 256u + threadIdx.x;
+        if (i < n) list[s + i] = list_entry(key[e], i + 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list)
+{
+    __shared__ uint64_t sh[SORT_CAP_SMALL];
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t s = rg.x, n = rg.y - rg.x;
+    if (n == 0 || n > (uint32_t)SORT_CAP_SMALL) return;
+    if (n <= 256u) tile_sort_small<1>(s, n, keys, list, sh);
+    else if (n <= 512u) tile_sort_small<2>(s, n, keys, list, sh);
+    else tile_sort_small<4>(s, n, keys, list, sh);
+}
+
 template <int CAP, bool IS_LARGE>
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ values, const Splat* __restrict__ splats,
-                 uint64_t* __restrict__ list, uint64_t* __restrict__ scratch)
+tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
+                 uint64_t* __restrict__ scratch)
 {
     __shared__ uint64_t sh[CAP];
     const uint2 rg = ranges[blockIdx.x];
@@ -326,7 +463,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     if (n <= (uint32_t)CAP) {
         uint32_t m = 2;
         while (m < n) m <<= 1;
-        for (uint32_t i = threadIdx.x; i < m; i += 256) sh[i] = i < n ? sort_key(splats, values[s + i]) : ~0ull;
+        for (uint32_t i = threadIdx.x; i < m; i += 256) sh[i] = i < n ? keys[s + i] : ~0ull;
         __syncthreads();
         for (uint32_t k = 2; k <= m; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -340,7 +477,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
         for (uint32_t i = threadIdx.x; i < n; i += 256) list[s + i] = list_entry(sh[i], i + 1u);
     } else {
         // n > CAP_LARGE: rank every key against all others (keys are distinct: they embed the Gaussian index)
-        for (uint32_t i = threadIdx.x; i < n; i += 256) scratch[s + i] = sort_key(splats, values[s + i]);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) scratch[s + i] = keys[s + i];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint64_t ki = scratch[s + i];
@@ -351,13 +488,12 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     }
 }
 
-void launch_tile_sort(const uint2* ranges, int num_tiles, const uint32_t* values, const Splat* splats, uint64_t* list,
-                      uint64_t* scratch, hipStream_t st)
+void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
+                      hipStream_t st)
 {
-    hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP_SMALL, false>), dim3(num_tiles), dim3(256), 0, st, ranges, values, splats,
-                       list, scratch);
-    hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP_LARGE, true>), dim3(num_tiles), dim3(256), 0, st, ranges, values, splats,
-                       list, scratch);
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list);
+    hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP_LARGE, true>), dim3(num_tiles), dim3(256), 0, st, ranges, keys, list,
+                       scratch);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -213,9 +213,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
       HIP_TRY(hipMemsetAsync(tile_count, 0, il.counters_bytes, st));
-      launch_preprocess(a, cam, splats, tiles_touched, tile_count, st); }
+      launch_preprocess(a, cam, splats, tiles_touched, st); }
     STAGE_CHECK(dbg, st, "preprocess");
-    { ProfScope ps(HGS_STAGE_SCAN, st); launch_tile_scan(tile_count, cam.gx, cam.gy, ranges, cursor, n_total, st); }
+    { ProfScope ps(HGS_STAGE_SCAN, st);
+      launch_count(a.P, cam, splats, tile_count, st);
+      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
 
     // the one host synchronisation of the forward pass: N sizes the binning buffer
@@ -229,14 +231,14 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
     if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
     state->binning = bin, state->binning_bytes = bl.total;
-    uint32_t* values = (uint32_t*)(bin + bl.values);
+    uint64_t* keys = (uint64_t*)(bin + bl.values);
     uint64_t* list = (uint64_t*)(bin + bl.list);
     uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
 
     if (N > 0) {
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, values, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, st); }
         STAGE_CHECK(dbg, st, "emit");
-        { ProfScope ps(HGS_STAGE_SORT, st); launch_tile_sort(ranges, num_tiles, values, splats, list, (uint64_t*)(bin + bl.scratch), st); }
+        { ProfScope ps(HGS_STAGE_SORT, st); launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), st); }
         STAGE_CHECK(dbg, st, "tile_sort");
     }
     { ProfScope ps(HGS_STAGE_TILE_RANGES, st);

@@ -59,8 +59,7 @@ struct ImageLayout {
         final_T = o;    o = align_up(o + 4 * S);
         n_contrib = o;  o = align_up(o + 4 * S);
         ranges = o;     o = align_up(o + 8 * T);
-        // 2-D difference array of "Gaussians touching each tile" on the (gx+1) x (gy+1) grid (atomics in K1)
-        tile_count = o; o = align_up(o + 4 * (size_t)((H + TILE - 1) / TILE + 1) * ((W + TILE - 1) / TILE + 1));
+        tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (count kernel)
         cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
         n_total = o;    o = align_up(o + 64);
         counters_bytes = o - tile_count;
@@ -75,7 +74,7 @@ struct BinningLayout {
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
         size_t o = 0;
-        values = o;     o = align_up(o + 4 * n);   // bucket-scattered, unsorted: mask << 28 | gaussian
+        values = o;     o = align_up(o + 8 * n);   // bucket-scattered, unsorted sort keys: depth bits << 32 | gaussian << 4 | mask
         list = o;       o = align_up(o + 8 * n);   // sorted: (pos1 << 32) | mask << 28 | gaussian
         scratch = o;    o = align_up(o + 8 * n);   // keys of tiles too long for LDS (fallback path of tile_sort)
         bitmap_words = n / 64 + 4;
@@ -93,16 +92,17 @@ struct BinningLayout {
 
 // kernels / launchers (defined in the .hip files)
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, hipStream_t st);
+                       hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
 void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st);
-void launch_tile_scan(uint32_t* tile_count_diff, int gx, int gy, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
+void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       hipStream_t st);
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint32_t* values, hipStream_t st);
-void launch_tile_sort(const uint2* ranges, int num_tiles, const uint32_t* values, const Splat* splats, uint64_t* list,
-                      uint64_t* scratch, hipStream_t st);
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, hipStream_t st);
+void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
+                      hipStream_t st);
 // act points at the first real entry (after the front pad)
 void launch_bitmaps_and_compact(const uint64_t* list, int64_t N, uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix,
                                 uint32_t* scan_tmp, uint64_t* act, hipStream_t st);

@@ -103,7 +103,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                   const float* __restrict__ scales, const float* __restrict__ rots,
                   const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
-                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii)
+                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -113,7 +113,6 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     out.radius = 0;
     out.clamped = 0;
     uint32_t touched = 0;
-    int rect_minx = 0, rect_maxx = 0, rect_miny = 0, rect_maxy = 0;
 
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     float pv[3];
@@ -155,7 +154,6 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
             bool finite = (fabsf(px) <= 3.0e38f) && (fabsf(py) <= 3.0e38f) && (radf <= 1.0e9f);
             int minx = (int)fminx, maxx = (int)fmaxx, miny = (int)fminy, maxy = (int)fmaxy;
             alive = finite && maxx > minx && maxy > miny;
-            rect_minx = minx, rect_maxx = maxx, rect_miny = miny, rect_maxy = maxy;
             if (alive) {
                 out.x = px;
                 out.y = py;
@@ -202,28 +200,15 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     dst[2] = make_float4(out.b, out.depth, __int_as_float(out.radius), __uint_as_float(out.clamped));
     tiles_touched[i] = touched;
     radii[i] = out.radius;
-    // Per-tile population (sizes the tiles' segments of the list), as a 2-D difference array on the
-    // (gx+1) x (gy+1) grid: four fire-and-forget atomics per Gaussian whatever its size; the tile-scan
-    // kernel integrates it (count[ty][tx] = sum over y <= ty, x <= tx).
-#ifndef HGS_EXPERIMENT_NO_COUNT
-    if (touched) {
-        const int pitch = cam.gx + 1;
-        int* d = reinterpret_cast<int*>(tile_count);
-        atomicAdd(&d[rect_miny * pitch + rect_minx], 1);
-        atomicAdd(&d[rect_miny * pitch + rect_maxx], -1);
-        atomicAdd(&d[rect_maxy * pitch + rect_minx], -1);
-        atomicAdd(&d[rect_maxy * pitch + rect_maxx], 1);
-    }
-#endif
 }
 
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, hipStream_t st)
+                       hipStream_t st)
 {
     int blocks = (a.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
                        a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
-                       a.s.projmatrix, a.s.campos, splats, tiles_touched, tile_count, a.radii);
+                       a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@
 //   emit        wave-balanced: every (Gaussian, tile) pair takes a slot of its tile's segment with a returning
 //               atomic and stores (quad coverage mask << 28 | Gaussian index) there          -- a bucket scatter
 //   tile_sort   one workgroup per tile: bitonic sort of the segment in LDS by (fp32 depth bits, Gaussian index)
-//   bitmaps / compact   per-quad bitmaps over the sorted list and the compacted lists the blend kernels stream
+//               ... and, while the segment is at hand, writes the tile's compacted per-quad lists for the blend kernels
 //
 // The result is, for every tile, exactly the order a stable sort of the 64-bit keys (tile << 32 | depth bits)
 // produces (ties: ascending Gaussian index) -- bit-identical to the oracle's sorted list -- without ever moving a
@@ -46,68 +46,6 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
     total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
     return inc + base;
-}
-
-constexpr int SCAN_ITEMS = 4;
-constexpr int SCAN_TILE = 256 * SCAN_ITEMS;  // 1024 elements per block
-
-__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ block_sums, int n)
-{
-    __shared__ uint32_t wsum[4];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += in[base + k];
-    uint32_t total;
-    block_inclusive_scan(s, wsum, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// single block: exclusive scan of block_sums[0..m) in place
-__global__ void __launch_bounds__(256) scan_sums_kernel(uint32_t* __restrict__ block_sums, int m)
-{
-    __shared__ uint32_t wsum[4];
-    uint32_t carry = 0;
-    for (int base = 0; base < m; base += 256) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < m ? block_sums[i] : 0;
-        uint32_t total;
-        uint32_t inc = block_inclusive_scan(v, wsum, total);
-        if (i < m) block_sums[i] = carry + inc - v;
-        carry += total;
-    }
-}
-
-__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ block_sums,
-                                                         uint32_t* out, int n)  // in may alias out
-{
-    __shared__ uint32_t wsum[4];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = base + k < n ? in[base + k] : 0;
-        s += v[k];
-    }
-    uint32_t total;
-    uint32_t inc = block_inclusive_scan(s, wsum, total);
-    uint32_t run = block_sums[blockIdx.x] + inc - s;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        run += v[k];
-        if (base + k < n) out[base + k] = run;
-    }
-}
-
-void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st)
-{
-    if (n <= 0) return;
-    int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, st, in, tmp, n);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, tmp, nb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, tmp, out, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,9 +298,8 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile_sort: one workgroup per tile.  tile_sort_small_kernel sorts the tiles with n <= CAP_SMALL in registers;
-// tile_sort_kernel<CAP_LARGE> (bitonic in LDS) those with CAP_SMALL < n <= CAP_LARGE and -- by brute-force ranking
-// through global scratch, slow but only for absurdly dense tiles -- everything longer.
+// tile_sort: one workgroup per tile sorts the tile's segment and, while it still holds it, writes the tile's
+// compacted per-quad lists the blend kernels stream (no bitmaps, no global prefix sum, no extra kernels).
 // Sort key: (depth bits << 32) | (gaussian << 4) | mask: depth first, then Gaussian index (the mask rides along).
 // Output: list[i] = (pos1 << 32) | (mask << 28 | gaussian), pos1 = 1-based position inside the tile.
 constexpr int SORT_CAP_SMALL = 1024, SORT_CAP_LARGE = 8192;
@@ -420,9 +357,45 @@ __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_
     }
 }
 
+// Appends up to 256 consecutive sorted entries of a tile (one per thread, `valid` when it exists) to the tile's
+// NUM_LISTS compacted lists: list q < 4 keeps the entries covering quad q, list 4 those covering any quad.  List q
+// of a tile lives at act[q * stride + s ...] (same offsets as the tile's segment of the sorted list, so no global
+// prefix sum is needed).  carry[q] = entries already appended.  sh32: >= 4 * NUM_LISTS words of LDS.
+__device__ __forceinline__ void compact_chunk(uint64_t entry, bool valid, uint32_t (&carry)[NUM_LISTS], uint32_t s,
+                                              uint64_t* __restrict__ act, size_t stride, uint32_t* sh32)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t mask = valid ? ((uint32_t)entry >> GID_BITS) : 0u;
+    uint32_t wrank[NUM_LISTS];
+    bool flag[NUM_LISTS];
+#pragma unroll
+    for (int q = 0; q < NUM_LISTS; ++q) {
+        flag[q] = q < 4 ? ((mask >> q) & 1u) != 0u : mask != 0u;
+        const uint64_t m = __ballot(flag[q]);
+        wrank[q] = (uint32_t)__popcll(m & lt);
+        if (lane == 0) sh32[q * 4 + w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NUM_LISTS; ++q) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t c = sh32[q * 4 + k];
+            if (k < w) before += c;
+            total += c;
+        }
+        if (flag[q]) act[(size_t)q * stride + s + carry[q] + before + wrank[q]] = entry;
+        carry[q] += total;
+    }
+    __syncthreads();
+}
+
 template <int E>
-__device__ __forceinline__ void tile_sort_small(uint32_t s, uint32_t n, const uint64_t* __restrict__ keys,
-                                                uint64_t* __restrict__ list, uint64_t* sh)
+__device__ __forceinline__ void tile_sort_small(uint32_t tile, uint32_t s, uint32_t n, const uint64_t* __restrict__ keys,
+                                                uint64_t* __restrict__ list, uint64_t* __restrict__ act, size_t stride,
+                                                uint32_t* __restrict__ act_count, uint64_t* sh)
 {
     uint64_t key[E];
 #pragma unroll
@@ -431,35 +404,48 @@ __device__ __forceinline__ void tile_sort_small(uint32_t s, uint32_t n, const ui
         key[e] = i < n ? keys[s + i] : ~0ull;
     }
     bitonic_in_registers<E>(key, sh);
+    uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)e * 256u + threadIdx.x;
-        if (i < n) list[s + i] = list_entry(key[e], i + 1u);
+        const uint64_t entry = list_entry(key[e], i + 1u);
+        if (i < n) list[s + i] = entry;
+        compact_chunk(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
     }
+#pragma unroll
+    for (int q = 0; q < NUM_LISTS; ++q)
+        if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
 }
 
 __global__ void __launch_bounds__(256)
-tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list)
+tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
+                       uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count)
 {
     __shared__ uint64_t sh[SORT_CAP_SMALL];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t s = rg.x, n = rg.y - rg.x;
-    if (n == 0 || n > (uint32_t)SORT_CAP_SMALL) return;
-    if (n <= 256u) tile_sort_small<1>(s, n, keys, list, sh);
-    else if (n <= 512u) tile_sort_small<2>(s, n, keys, list, sh);
-    else tile_sort_small<4>(s, n, keys, list, sh);
+    if (n == 0) {
+        if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
+        return;
+    }
+    if (n > (uint32_t)SORT_CAP_SMALL) return;
+    if (n <= 256u) tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
+    else if (n <= 512u) tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
+    else tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
 }
 
-template <int CAP, bool IS_LARGE>
+// Tiles with more than CAP_SMALL entries: bitonic in LDS up to CAP entries, brute-force ranking through global
+// scratch beyond that (slow, but only for absurdly dense tiles).
+template <int CAP>
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
-                 uint64_t* __restrict__ scratch)
+tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
+                       uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
+                       uint32_t* __restrict__ act_count)
 {
     __shared__ uint64_t sh[CAP];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t s = rg.x, n = rg.y - rg.x;
-    if (n == 0) return;
-    if (IS_LARGE ? n <= (uint32_t)SORT_CAP_SMALL : n > (uint32_t)CAP) return;  // the other launch's tile
+    if (n <= (uint32_t)SORT_CAP_SMALL) return;  // the small kernel's tile
     if (n <= (uint32_t)CAP) {
         uint32_t m = 2;
         while (m < n) m <<= 1;
@@ -476,7 +462,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ 
             }
         for (uint32_t i = threadIdx.x; i < n; i += 256) list[s + i] = list_entry(sh[i], i + 1u);
     } else {
-        // n > CAP_LARGE: rank every key against all others (keys are distinct: they embed the Gaussian index)
+        // rank every key against all others (keys are distinct: they embed the Gaussian index)
         for (uint32_t i = threadIdx.x; i < n; i += 256) scratch[s + i] = keys[s + i];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -486,74 +472,25 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ 
             list[s + rank] = list_entry(ki, rank + 1u);
         }
     }
+    // the segment is sorted in global memory (written by this workgroup): compact it chunk by chunk
+    __syncthreads();
+    uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t entry = i < n ? __builtin_nontemporal_load(&list[s + i]) : 0ull;
+        compact_chunk(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
+    }
+#pragma unroll
+    for (int q = 0; q < NUM_LISTS; ++q)
+        if (threadIdx.x == 0) act_count[blockIdx.x * NUM_LISTS + q] = carry[q];
 }
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      hipStream_t st)
+                      uint64_t* act, size_t stride, uint32_t* act_count, hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list);
-    hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP_LARGE, true>), dim3(num_tiles), dim3(256), 0, st, ranges, keys, list,
-                       scratch);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Bitmaps over the sorted list (one ballot per bitmap per 64 entries: bitmap q < 4 = "covers quad q", bitmap 4 =
-// "covers any quad"), and -- after a prefix sum over the words' popcounts -- the compacted lists the blend
-// kernels stream.
-__global__ void __launch_bounds__(256)
-bitmap_kernel(const uint64_t* __restrict__ list, int64_t N, uint64_t* __restrict__ bitmaps, uint32_t* __restrict__ wcount,
-              size_t bitmap_words)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t v = i < N ? (uint32_t)list[i] : 0u;
-    const size_t word = (size_t)(i >> 6);
-#pragma unroll
-    for (int q = 0; q < NUM_BITMAPS; ++q) {
-        const uint64_t m = __ballot(q < 4 ? ((v >> (GID_BITS + q)) & 1u) : ((v >> GID_BITS) != 0u));
-        if ((threadIdx.x & 63) == 0 && word < bitmap_words) {
-            bitmaps[(size_t)q * bitmap_words + word] = m;
-            wcount[(size_t)q * bitmap_words + word] = (uint32_t)__popcll(m);
-        }
-    }
-}
-
-// wprefix holds the INCLUSIVE scan of the word popcounts on entry and the exclusive one on exit.
-__global__ void __launch_bounds__(256)
-compact_kernel(const uint64_t* __restrict__ list, int64_t N, const uint64_t* __restrict__ bitmaps,
-               uint32_t* __restrict__ wprefix, size_t bitmap_words, uint64_t* __restrict__ act)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const size_t word = (size_t)(i >> 6);
-    if (word >= bitmap_words) return;  // whole wave
-    const uint64_t entry = i < N ? list[i] : 0ull;  // (pos1 << 32) | quad mask << 28 | gaussian
-    const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int q = 0; q < NUM_BITMAPS; ++q) {
-        const size_t w = (size_t)q * bitmap_words + word;
-        const uint64_t m = bitmaps[w];
-        const uint32_t excl = wprefix[w] - (uint32_t)__popcll(m);
-        if ((m >> lane) & 1ull) act[excl + (uint32_t)__popcll(m & lt)] = entry;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) wprefix[w] = excl;
-    }
-    // dead entries (gaussian 0, position 0) around the real ones: the blend kernels prefetch a few past either end
-    if (i < ACT_PAD) {
-        const uint32_t total = wprefix[NUM_BITMAPS * bitmap_words - 1];  // the last word is all zero: incl == excl
-        act[total + i] = 0ull;
-        act[(int64_t)i - ACT_PAD] = 0ull;
-    }
-}
-
-void launch_bitmaps_and_compact(const uint64_t* list, int64_t N, uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix,
-                                uint32_t* scan_tmp, uint64_t* act, hipStream_t st)
-{
-    // the grid covers every bitmap word (also the zero words past N)
-    const int64_t threads = (int64_t)bitmap_words * 64;
-    const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(bitmap_kernel, dim3(blocks), dim3(256), 0, st, list, N, bitmaps, wprefix, bitmap_words);
-    launch_scan_inclusive(wprefix, wprefix, scan_tmp, (int)(NUM_BITMAPS * bitmap_words), st);
-    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, st, list, N, bitmaps, wprefix, bitmap_words, act);
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count);
+    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, scratch,
+                       act, stride, act_count);
 }
 
 }  // namespace hgs

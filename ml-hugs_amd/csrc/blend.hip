@@ -36,8 +36,11 @@ struct SplatRec {  // wave-uniform (lives in SGPRs)
     float x, y, A, B, C, op, r, g, b;
 };
 
-__device__ __forceinline__ SplatRec load_rec(const Splat* splats, uint32_t gid)
+// `entry_low` = low word of a list entry (mask << 28 | gaussian); the index is clamped because the software
+// pipeline reads a few entries past either end of a list, where memory may hold anything
+__device__ __forceinline__ SplatRec load_rec(const Splat* splats, uint32_t entry_low, uint32_t last_gaussian)
 {
+    const uint32_t gid = min(entry_low & GID_MASK, last_gaussian);
     // 32-bit byte offset (P * 48 < 2^32 is checked by the API): one s_mul_i32 + base+offset scalar loads
     const_f4p p = (const_f4p)((const char*)splats + gid * 48u);
     const v4f h0 = p[0], h1 = p[1];
@@ -68,16 +71,6 @@ __device__ __forceinline__ int remap_tile(int bid, int num_tiles)
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4u* const_u4p;
 
-// Position of list entry `i`'s slot in the compacted list of quad `w`: covering entries before word i/64
-// (wprefix) plus the covering entries below bit i%64 of that word.
-__device__ __forceinline__ uint32_t act_index(const_u32p wprefix, const_u64p bitmaps, uint32_t bitmap_words, int w,
-                                              uint32_t i)
-{
-    const uint32_t word = (uint32_t)w * bitmap_words + (i >> 6);
-    const uint64_t below = bitmaps[word] & ((1ull << (i & 63u)) - 1ull);
-    return wprefix[word] + (uint32_t)__builtin_popcountll(below);
-}
-
 // two consecutive entries of the compacted list: {gaussian0, pos0, gaussian1, pos1} (one s_load_dwordx4)
 __device__ __forceinline__ v4u load_pair(const uint64_t* act, uint32_t idx)
 {
@@ -106,9 +99,8 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
 }
 
 __global__ void __launch_bounds__(256)
-blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
-                     const uint32_t* __restrict__ wprefix, const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words,
-                     const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
+blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                     size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
@@ -125,21 +117,20 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_
     uint32_t last = 0;
 
     if (range.y > range.x) {
-        const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.x);
-        const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, w, range.y) - a;
-        const uint64_t* list = act + a;
+        const uint32_t n = ((const_u32p)act_count)[tile * NUM_LISTS + w];
+        const uint64_t* list = act + (size_t)w * act_stride + range.x;
         // Software pipeline, two entries per half-iteration, two register sets (A/B) so nothing is copied:
         // while set A is blended, set B's records and the following pair of entries are in flight.
         v4u eA = load_pair(list, 0);
-        SplatRec rA0 = load_rec(splats, eA.x & GID_MASK), rA1 = load_rec(splats, eA.z & GID_MASK);
+        SplatRec rA0 = load_rec(splats, eA.x, lastg), rA1 = load_rec(splats, eA.z, lastg);
         v4u eB = load_pair(list, 2);
         for (uint32_t j = 0; j < n; j += 4) {
-            const SplatRec rB0 = load_rec(splats, eB.x & GID_MASK), rB1 = load_rec(splats, eB.z & GID_MASK);
+            const SplatRec rB0 = load_rec(splats, eB.x, lastg), rB1 = load_rec(splats, eB.z, lastg);
             const v4u eA2 = load_pair(list, j + 4);
             fwd_accumulate(rA0, eA.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 1 < n) fwd_accumulate(rA1, eA.w, pxf, pyf, T, C0, C1, C2, last);
             if (j + 2 >= n || __ballot(T > 0.0f) == 0ull) break;
-            rA0 = load_rec(splats, eA2.x & GID_MASK), rA1 = load_rec(splats, eA2.z & GID_MASK);
+            rA0 = load_rec(splats, eA2.x, lastg), rA1 = load_rec(splats, eA2.z, lastg);
             const v4u eB2 = load_pair(list, j + 6);
             fwd_accumulate(rB0, eB.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 3 < n) fwd_accumulate(rB1, eB.w, pxf, pyf, T, C0, C1, C2, last);
@@ -158,12 +149,12 @@ blend_forward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_
     }
 }
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
-                          const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
-                          float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st)
+void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
+                          const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
+                          float* final_T, uint32_t* n_contrib, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, ranges, act, wprefix, bitmaps,
-                       (uint32_t)bitmap_words, splats, bg, out_color, final_T, n_contrib);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
+                       act_stride, act_count, splats, bg, out_color, final_T, n_contrib);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,9 +238,8 @@ __device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
 // four per-pixel evaluations run at all, while the nine partial sums of ALL covered quads are added up in
 // registers before the single cross-lane reduction + atomic of that (tile, entry) pair.
 __global__ void __launch_bounds__(256)
-blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
-                      const uint32_t* __restrict__ wprefix, const uint64_t* __restrict__ bitmaps, uint32_t bitmap_words,
-                      const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
+blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                       float* __restrict__ grad_accum)
 {
@@ -292,13 +282,14 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
     if (wmax == 0) return;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
-    // entries of this tile that cover at least one quad (bitmap 4), positions <= wmax, walked back to front
-    const uint32_t a = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, 4, range.x);
-    const uint32_t n = act_index((const_u32p)wprefix, (const_u64p)bitmaps, bitmap_words, 4, range.x + wmax) - a;
+    // entries of this tile that cover at least one quad (list 4), walked back to front; those beyond the deepest
+    // position any pixel composited (pos1 > wmax) are skipped with a scalar branch
+    const uint32_t n = ((const_u32p)act_count)[tile * NUM_LISTS + 4];
     if (n == 0) return;
-    const uint64_t* top = act + a + n;  // one past the deepest entry
+    const uint64_t* top = act + 4 * act_stride + range.x + n;  // one past the deepest entry
 
     auto backward_entry = [&](const SplatRec& s, uint32_t val, uint32_t pos1) {
+        if (pos1 > wmax) return;
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         bool any = false;
 #pragma unroll
@@ -333,15 +324,15 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
     // below `a` by the last, half-used pair harmless.  Two register sets (A/B): while one is consumed the
     // other's records and the next pair of entries are in flight.
     v4u eA = load_pair(top - 2, 0);
-    SplatRec rA0 = load_rec(splats, eA.z & GID_MASK), rA1 = load_rec(splats, eA.x & GID_MASK);  // rA0: deeper, first
+    SplatRec rA0 = load_rec(splats, eA.z, lastg), rA1 = load_rec(splats, eA.x, lastg);  // rA0: deeper, first
     v4u eB = load_pair(top - 4, 0);
     for (uint32_t j = 0; j < n; j += 4) {
-        const SplatRec rB0 = load_rec(splats, eB.z & GID_MASK), rB1 = load_rec(splats, eB.x & GID_MASK);
+        const SplatRec rB0 = load_rec(splats, eB.z, lastg), rB1 = load_rec(splats, eB.x, lastg);
         const v4u eA2 = load_pair(top - 6 - j, 0);
         backward_entry(rA0, eA.z, eA.w);
         if (j + 1 < n) backward_entry(rA1, eA.x, eA.y);
         if (j + 2 >= n) break;
-        rA0 = load_rec(splats, eA2.z & GID_MASK), rA1 = load_rec(splats, eA2.x & GID_MASK);
+        rA0 = load_rec(splats, eA2.z, lastg), rA1 = load_rec(splats, eA2.x, lastg);
         const v4u eB2 = load_pair(top - 8 - j, 0);
         backward_entry(rB0, eB.z, eB.w);
         if (j + 3 < n) backward_entry(rB1, eB.x, eB.y);
@@ -349,13 +340,12 @@ blend_backward_kernel(Camera cam, const uint2* __restrict__ ranges, const uint64
     }
 }
 
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
-                           const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
-                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
-                           hipStream_t st)
+void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
+                           const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3((cam.gx * cam.gy + 3) / 4), dim3(256), 0, st, cam, ranges, act, wprefix,
-                       bitmaps, (uint32_t)bitmap_words, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+    hipLaunchKernelGGL(blend_backward_kernel, dim3((cam.gx * cam.gy + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
+                       act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
 }  // namespace hgs

@@ -175,7 +175,6 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     if (!strcmp(name, "splats")) return g.splats;
     if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
     if (!strcmp(name, "list")) return b.list;
-    if (!strcmp(name, "bitmaps")) return b.bitmaps;
     if (!strcmp(name, "final_T")) return im.final_T;
     if (!strcmp(name, "n_contrib")) return im.n_contrib;
     if (!strcmp(name, "ranges")) return im.ranges;
@@ -231,23 +230,21 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
     if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
     state->binning = bin, state->binning_bytes = bl.total;
-    uint64_t* keys = (uint64_t*)(bin + bl.values);
+    uint64_t* keys = (uint64_t*)(bin + bl.keys);
     uint64_t* list = (uint64_t*)(bin + bl.list);
     uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
+    uint32_t* act_count = (uint32_t*)(image + il.act_count);
 
     if (N > 0) {
         { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, st); }
         STAGE_CHECK(dbg, st, "emit");
-        { ProfScope ps(HGS_STAGE_SORT, st); launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), st); }
-        STAGE_CHECK(dbg, st, "tile_sort");
     }
-    { ProfScope ps(HGS_STAGE_TILE_RANGES, st);
-      launch_bitmaps_and_compact(list, N, (uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, (uint32_t*)(bin + bl.wprefix),
-                                 (uint32_t*)(bin + bl.scan_tmp), act, st); }
-    STAGE_CHECK(dbg, st, "bitmaps_compact");
-    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st); launch_blend_forward(cam, ranges, (const uint64_t*)(bin + bl.act) + ACT_PAD, (const uint32_t*)(bin + bl.wprefix),
-                         (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, a.s.bg, a.out_color, (float*)(image + il.final_T),
-                         (uint32_t*)(image + il.n_contrib), st); }
+    { ProfScope ps(HGS_STAGE_SORT, st);
+      launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, st); }
+    STAGE_CHECK(dbg, st, "tile_sort");
+    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
+      launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
+                           (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), st); }
     STAGE_CHECK(dbg, st, "blend_forward");
     return N;
 }
@@ -278,10 +275,10 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
-    launch_blend_backward(cam, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
-                          (const uint32_t*)(bin + bl.wprefix), (const uint64_t*)(bin + bl.bitmaps), bl.bitmap_words, splats, f.s.bg,
-                          (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
-                          a.grad_accum, st); }
+      launch_blend_backward(cam, f.P, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
+                            bl.act_stride, (const uint32_t*)(image + il.act_count), splats, f.s.bg,
+                            (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
+                            a.grad_accum, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");

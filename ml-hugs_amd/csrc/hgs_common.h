@@ -50,8 +50,10 @@ struct GeomLayout {
         total = o;
     }
 };
+constexpr int ACT_PAD = 16;
+constexpr int NUM_LISTS = 5;  // four per-quad lists + one "any quad" list per tile
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_count, cursor, n_total, total;
+    size_t final_T, n_contrib, ranges, act_count, tile_count, cursor, n_total, total;
     size_t counters_bytes;  // tile_count .. n_total are contiguous: one memset before the preprocess kernel
     ImageLayout(int H, int W) {
         size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
@@ -59,6 +61,7 @@ struct ImageLayout {
         final_T = o;    o = align_up(o + 4 * S);
         n_contrib = o;  o = align_up(o + 4 * S);
         ranges = o;     o = align_up(o + 8 * T);
+        act_count = o;  o = align_up(o + 4 * T * NUM_LISTS);   // entries in each tile's compacted lists
         tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (count kernel)
         cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
         n_total = o;    o = align_up(o + 64);
@@ -66,26 +69,20 @@ struct ImageLayout {
         total = o;
     }
 };
-constexpr int ACT_PAD = 16;
-constexpr int NUM_BITMAPS = 5;  // four per-quad bitmaps + one "any quad" bitmap over the sorted list
 struct BinningLayout {
-    size_t values, list, scratch, bitmaps, wprefix, scan_tmp, act, total;
-    size_t bitmap_words;  // u64 words per bitmap
+    size_t keys, list, scratch, act, total;
+    size_t act_stride;  // entries between consecutive compacted-list arrays
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
         size_t o = 0;
-        values = o;     o = align_up(o + 8 * n);   // bucket-scattered, unsorted sort keys: depth bits << 32 | gaussian << 4 | mask
+        keys = o;       o = align_up(o + 8 * n);   // bucket-scattered, unsorted sort keys: depth bits << 32 | gaussian << 4 | mask
         list = o;       o = align_up(o + 8 * n);   // sorted: (pos1 << 32) | mask << 28 | gaussian
         scratch = o;    o = align_up(o + 8 * n);   // keys of tiles too long for LDS (fallback path of tile_sort)
-        bitmap_words = n / 64 + 4;
-        bitmaps = o;    o = align_up(o + 8 * NUM_BITMAPS * bitmap_words);
-        // wprefix[q * bitmap_words + w] = number of set bits of all earlier words (bitmaps concatenated): the
-        // position of word w's first covering entry in the compacted list `act`
-        wprefix = o;    o = align_up(o + 4 * NUM_BITMAPS * bitmap_words);
-        scan_tmp = o;   o = align_up(o + 4 * (NUM_BITMAPS * bitmap_words / 1024 + 2) + 64);
-        // act: for each bitmap, its covering entries in list order; worst case NUM_BITMAPS * N entries; ACT_PAD dead
-        // entries in front (the backward walk reads pairs downwards) and behind
-        act = o;        o = align_up(o + 8 * (NUM_BITMAPS * n + 2 * ACT_PAD));
+        // act: NUM_LISTS arrays with the sorted list's indexing; array q holds, at a tile's offsets, the tile's entries
+        // that cover quad q (q == 4: any quad), compacted to the front of the tile's slot.  ACT_PAD entries of slack
+        // between arrays and at both ends: the blend kernels prefetch a few entries past either end of a list.
+        act_stride = n + ACT_PAD;
+        act = o;        o = align_up(o + 8 * (NUM_LISTS * act_stride + 2 * ACT_PAD));
         total = o;
     }
 };
@@ -96,24 +93,20 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
-void launch_scan_inclusive(const uint32_t* in, uint32_t* out, uint32_t* tmp, int n, hipStream_t st);
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, hipStream_t st);
+// act points at the first entry of list array 0 (after the front pad)
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      hipStream_t st);
-// act points at the first real entry (after the front pad)
-void launch_bitmaps_and_compact(const uint64_t* list, int64_t N, uint64_t* bitmaps, size_t bitmap_words, uint32_t* wprefix,
-                                uint32_t* scan_tmp, uint64_t* act, hipStream_t st);
+                      uint64_t* act, size_t stride, uint32_t* act_count, hipStream_t st);
 
-void launch_blend_forward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
-                          const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
-                          float* out_color, float* final_T, uint32_t* n_contrib, hipStream_t st);
+void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
+                          const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
+                          float* final_T, uint32_t* n_contrib, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
-void launch_blend_backward(const Camera& cam, const uint2* ranges, const uint64_t* act, const uint32_t* wprefix,
-                           const uint64_t* bitmaps, size_t bitmap_words, const Splat* splats, const float* bg,
-                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
-                           hipStream_t st);
+void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
+                           const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
 
 }  // namespace hgs

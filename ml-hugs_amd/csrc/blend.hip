@@ -1,25 +1,27 @@
 // Per-tile alpha blending: forward (K6) and pixel-side backward (K7).  SURVEY.md A.4 / A.5.
 //
 // CDNA4 design (not the CUDA shape):
-//  * A 16x16 tile is one 256-thread workgroup = 4 independent wave64s, each owning an 8x8 pixel quad.
-//    There is NO LDS staging and NO barrier: the splat record of a list entry is the same for every lane,
-//    so it is fetched through the scalar data cache (s_load_dwordx8 from the constant address space)
-//    straight into SGPRs and used as a scalar operand of the VALU math.
-//  * Each quad has a bitmap over the sorted list (built by the tile-ranges kernel from the coverage masks
-//    the emission kernel computed).  A wave walks only the set bits of its bitmap with scalar bit scans
-//    (s_ff1 / s_flbit), so list entries that cannot touch its 64 pixels cost no vector instruction at all
-//    -- in the 200k / 1080p workload that is ~60 % of all (wave, splat) pairs.
-//  * The walk is software pipelined: the list value of entry n+2 and the record of entry n+1 are in
-//    flight while entry n is blended out of SGPRs (scalar loads return out of order, so the single
-//    lgkmcnt(0) sits at the top of the iteration, before the next record load is issued).
-//  * The per-pixel update is fully predicated (v_cndmask), early-out is per wave (64 pixels).
-//  * Backward: the 9 per-splat partial sums of a wave are combined with a butterfly transpose-reduce
-//    (quad_perm / row_shl / row_shr / row_ror DPP + two cross-row shuffles) that leaves the totals in 9
-//    different lanes, which then issue ONE global_atomic_add_f32 instruction into a [P][12] accumulator
-//    record (contiguous 36 bytes per Gaussian).
+//  * No LDS staging, no barrier: the splat record of a list entry is the same for every lane, so it is fetched
+//    through the scalar data cache (s_load_dwordx8 from the constant address space) straight into SGPRs and
+//    used as a scalar operand of the VALU math.
+//  * Coverage culling: the tile-sort kernel leaves, for every tile, five compacted lists -- the entries that can
+//    reach alpha >= 1/255 in quad q (q = 0..3, the tile's four 8x8 quads) and those that reach any quad.  A wave
+//    streams only its list, so the ~60 % of (quad, splat) pairs that cannot touch its pixels cost no instruction
+//    at all (the tile list itself stays bit-identical to the reference's sorted list).
+//  * The walk is software pipelined with two SGPR register sets: while one pair of entries is blended, the next
+//    pair's records and the pair of entries after that are in flight (scalar loads return out of order, so the
+//    single lgkmcnt(0) sits at the top of the half-iteration, before new loads are issued).
+//  * Forward: a 16x16 tile is one 256-thread workgroup = 4 independent wave64s, one per quad; the per-pixel
+//    update is fully predicated (v_cndmask), the "done" flag is the sign bit of T, early-out is per wave.
+//  * Backward: ONE wave per tile; a lane owns four pixels, one in each quad, and the entry's quad mask selects
+//    with scalar branches which of the four per-pixel evaluations run.  The nine partial sums of all covered
+//    quads are added in registers, so there is one cross-lane reduction -- a butterfly transpose-reduce (quad_perm
+//    / row_shl / row_shr / row_ror DPP + two cross-row shuffles) that leaves the nine totals in nine lanes -- and
+//    ONE global_atomic_add_f32 instruction per (tile, entry) into a contiguous [P][12] accumulator record.
 //
-// Compiled with -ffp-contract=off; the FMAs below are explicit so forward and backward evaluate alpha
-// with the identical instruction sequence (backward must re-take forward's skip decisions).
+// Compiled with -ffp-contract=off (and -fno-slp-vectorize: packed f32 ops issue at half rate on gfx950, so SLP
+// packing only adds register shuffles); the FMAs below are explicit so forward and backward evaluate alpha with
+// the identical instruction sequence (backward must re-take forward's skip decisions).
 #include "hgs_common.h"
 
 namespace hgs {
@@ -71,7 +73,7 @@ __device__ __forceinline__ int remap_tile(int bid, int num_tiles)
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4u* const_u4p;
 
-// two consecutive entries of the compacted list: {gaussian0, pos0, gaussian1, pos1} (one s_load_dwordx4)
+// two consecutive entries of a compacted list: {mask|gaussian 0, pos 0, mask|gaussian 1, pos 1} (one s_load_dwordx4)
 __device__ __forceinline__ v4u load_pair(const uint64_t* act, uint32_t idx)
 {
     return *(const_u4p)(act + idx);

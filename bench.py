@@ -173,6 +173,17 @@ def main():
         "stages_ms": stages,
     }
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs of this same
+    # command; collected and corrected as MI355X_MICROARCH.md prescribes) -- only for the workload they were taken on
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")))
+        wl = pmc["workload"]
+        if (wl["gaussians"], wl["height"], wl["width"], wl["sh_degree"]) == (P, H, W, D):
+            out["roofline"]["traffic"] = pmc["kernels"][dominant + "_kernel"]["hbm_bytes_corrected"]
+            out["roofline"]["traffic_source"] = "profiles/r1f_pmc_traffic.json"
+    except Exception:
+        pass
+
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)
     print(json.dumps(out), flush=True)
@@ -185,7 +196,8 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
     """The oracle (a CPU port of the same algorithm -- the reference has no CPU path) timed on
     this box's host cores on a bounded sample of the same workload. Baseline only."""
     from oracle import hgs_oracle as ho
-    cores = os.cpu_count() or 1
+    # the port keeps one double-precision gradient accumulator per thread: beyond ~32 threads that costs more than it buys
+    cores = min(os.cpu_count() or 1, 32)
     ho.set_threads(cores)
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
                     cam["camera_center"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), H, W,

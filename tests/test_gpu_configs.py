@@ -1,0 +1,169 @@
+"""GPU: the BASELINE.json configurations other than the bench workload, as parity-test cases (each against the
+oracle with the same tolerances as tests/test_gpu_parity.py), driven through the renderer adapter the trainer uses.
+
+  C1  10k random Gaussians, 256x256, single camera
+  C3  HUGS human-only: SMPL-sized (6 890) and subdivided (110 210) Gaussian sets, [P,16,3] SH at active degree 0,
+      512x512, the canonical rotating-camera rig (dist 5, fov 0.4)
+  C4  HUGS joint human+scene at 1080p, degree 0 taken from the human model, two renders per step
+      (full set on a random background + human only on its own background), one backward through both
+  C5  one frame of the 300k-Gaussian / 1080p batch from a yawed camera (frames are independent; sharding is
+      covered by tests/test_sharding_gloo.py)
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hugs_amd import synthetic as syn
+from oracle import hgs_oracle as ho
+from test_gpu_parity import GRAD_REL_TOL, check_image, rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def human_gaussians(P, seed):
+    """A person-sized blob at the origin (y up/down extent ~1.7 m), small isotropic-ish splats, non-unit quats
+    (the HUGS models feed un-normalised quaternions, hugs_trimlp.py:517-518)."""
+    rng = np.random.default_rng(seed)
+    means = (rng.standard_normal((P, 3)) * np.array([0.22, 0.55, 0.14])).astype(np.float32)
+    s0 = 0.035 / math.sqrt(P / 6890.0)
+    scales = (s0 * np.exp(0.3 * rng.standard_normal((P, 3)))).astype(np.float32)
+    q = rng.standard_normal((P, 4))
+    q = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.8, 1.2, (P, 1))
+    shs = np.zeros((P, 16, 3), np.float32)
+    shs[:, 0] = rng.standard_normal((P, 3))
+    shs[:, 1:] = 0.1 * rng.standard_normal((P, 15, 3))
+    opac = rng.uniform(0.05, 1.0, (P, 1)).astype(np.float32)
+    return {"xyz": means, "scales": scales, "rotq": q.astype(np.float32), "shs": shs, "opacity": opac}
+
+
+def scene_model(P, cam0, seed, sigma_px=4.0):
+    g = syn.scene_gaussians(P, cam0, seed=seed, sigma_px=sigma_px)
+    return {"xyz": g["means3D"], "scales": g["scales"], "rotq": g["rotations"], "shs": g["shs"], "opacity": g["opacities"]}
+
+
+def as_model(m, device, degree):
+    out = {k: to_dev(v, device, True) for k, v in m.items()}
+    out["active_sh_degree"] = degree
+    return out
+
+
+def cam_data(cam, device):
+    return {k: (to_dev(v, device) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+
+
+def oracle_run(m, cam, bg, degree, dL):
+    inp = ho.Inputs(m["xyz"], m["opacity"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
+                    math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), cam["image_height"], cam["image_width"],
+                    np.asarray(bg, np.float32), shs=m["shs"], scales=m["scales"], rotations=m["rotq"], sh_degree=degree)
+    ho.set_threads(min(os.cpu_count() or 1, 32))
+    f = ho.forward(inp)
+    return f, ho.backward(inp, f, dL)
+
+
+def check_grads(model, ref_g, what, sl=slice(None)):
+    for k, rk in (("xyz", "means3D"), ("opacity", "opacities"), ("shs", "shs"), ("scales", "scales"), ("rotq", "rotations")):
+        r = ref_g[rk][sl]
+        g = model[k].grad.cpu().numpy().reshape(r.shape)
+        assert rel_l2(g, r) <= GRAD_REL_TOL, f"{what}: grad {k} rel L2 {rel_l2(g, r):.2e}"
+
+
+def test_c1_random_10k_256(device):
+    from hugs_amd.renderer import render
+    cam = syn.pinhole_camera(256, 256)
+    m = scene_model(10_000, cam, seed=11, sigma_px=2.0)
+    dL = np.random.default_rng(0).standard_normal((3, 256, 256)).astype(np.float32)
+    ref_f, ref_g = oracle_run(m, cam, (0, 0, 0), 3, dL)
+    mod = as_model(m, device, 3)
+    pkg = render(mod["xyz"], mod["shs"], mod["opacity"], mod["scales"], mod["rotq"], cam_data(cam, device),
+                 bg_color=None, active_sh_degree=3)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), ref_f["radii"])
+    check_image(pkg["render"].detach().cpu().numpy(), np.clip(ref_f["color"], 0, 1), "C1")
+    # backward through the clamp of render(): pass-through where the unclamped colour is inside (0,1)
+    inside = ((ref_f["color"] >= 0) & (ref_f["color"] <= 1)).astype(np.float32)
+    _, ref_g = oracle_run(m, cam, (0, 0, 0), 3, dL * inside)
+    pkg["render"].backward(to_dev(dL, device))
+    check_grads(mod, ref_g, "C1")
+    assert rel_l2(pkg["viewspace_points"].grad.cpu().numpy(), ref_g["means2D"]) <= GRAD_REL_TOL
+
+
+@pytest.mark.parametrize("P", [6890, 110_210])
+def test_c3_human_only_512(P, device):
+    from hugs_amd.renderer import render_human_scene
+    cam = syn.rotating_camera(3, 10, dist=5.0, fov=0.4, img_size=512)
+    m = human_gaussians(P, seed=5)
+    dL = (np.random.default_rng(1).standard_normal((3, 512, 512)) * 1e-3).astype(np.float32)
+    bg = (1.0, 1.0, 1.0)
+    ref_f, _ = oracle_run(m, cam, bg, 0, dL)
+    assert (ref_f["radii"] > 0).mean() > 0.9 and ref_f["N"] > P  # the rig really looks at the blob
+    inside = ((ref_f["color"] >= 0) & (ref_f["color"] <= 1)).astype(np.float32)
+    _, ref_g = oracle_run(m, cam, bg, 0, dL * inside)
+    human = as_model(m, device, 0)
+    pkg = render_human_scene(cam_data(cam, device), human, None, bg_color=torch.ones(3, device=device), render_mode="human")
+    assert np.array_equal(pkg["human_radii"].cpu().numpy(), ref_f["radii"])
+    assert np.array_equal(pkg["human_visibility_filter"].cpu().numpy(), ref_f["radii"] > 0)
+    check_image(pkg["render"].detach().cpu().numpy(), np.clip(ref_f["color"], 0, 1), f"C3 P={P}")
+    pkg["render"].backward(to_dev(dL, device))
+    check_grads(human, ref_g, f"C3 P={P}")
+    # degree 0 on 16-coefficient storage: coefficients above the active degree get exactly zero gradient
+    assert float(human["shs"].grad[:, 1:].abs().max()) == 0.0
+
+
+def test_c4_joint_human_scene_1080p(device):
+    from hugs_amd.renderer import render_human_scene
+    H, W = 1080, 1920
+    cam0 = syn.pinhole_camera(H, W)
+    hm = human_gaussians(30_000, seed=7)
+    hm["xyz"] = (hm["xyz"] + np.array([0.0, 0.0, 4.0], np.float32)).astype(np.float32)  # stand 4 m in front of the camera
+    sm = scene_model(100_000, cam0, seed=8)
+    rng = np.random.default_rng(2)
+    bg, hbg = rng.uniform(0, 1, 3).astype(np.float32), rng.uniform(0, 1, 3).astype(np.float32)
+    dL1 = (rng.standard_normal((3, H, W)) * 1e-3).astype(np.float32)
+    dL2 = (rng.standard_normal((3, H, W)) * 1e-3).astype(np.float32)
+    joint = {k: np.concatenate([hm[k], sm[k]], 0) for k in hm}  # human first, scene second (gs_renderer.py:33-37)
+    f1, _ = oracle_run(joint, cam0, bg, 0, dL1)
+    f2, _ = oracle_run(hm, cam0, hbg, 0, dL2)
+    in1 = ((f1["color"] >= 0) & (f1["color"] <= 1)).astype(np.float32)
+    in2 = ((f2["color"] >= 0) & (f2["color"] <= 1)).astype(np.float32)
+    _, g1 = oracle_run(joint, cam0, bg, 0, dL1 * in1)
+    _, g2 = oracle_run(hm, cam0, hbg, 0, dL2 * in2)
+
+    human, scene = as_model(hm, device, 0), as_model(sm, device, 3)  # the joint render uses the HUMAN's degree
+    pkg = render_human_scene(cam_data(cam0, device), human, scene, bg_color=to_dev(bg, device),
+                             human_bg_color=to_dev(hbg, device), render_mode="human_scene", render_human_separate=True)
+    nh = hm["xyz"].shape[0]
+    assert np.array_equal(pkg["radii"].cpu().numpy(), f1["radii"])
+    assert np.array_equal(pkg["human_radii"].cpu().numpy(), f2["radii"])
+    assert np.array_equal(pkg["scene_radii"].cpu().numpy(), f1["radii"][nh:])
+    check_image(pkg["render"].detach().cpu().numpy(), np.clip(f1["color"], 0, 1), "C4 joint")
+    check_image(pkg["human_img"].detach().cpu().numpy(), np.clip(f2["color"], 0, 1), "C4 human-only")
+    (pkg["render"] * to_dev(dL1, device)).sum().backward(retain_graph=True)
+    (pkg["human_img"] * to_dev(dL2, device)).sum().backward()
+    # the human's parameters receive the sum of both renders' gradients; the scene's only the joint render's
+    for k, rk in (("xyz", "means3D"), ("opacity", "opacities"), ("scales", "scales"), ("rotq", "rotations")):
+        r = g1[rk][:nh] + g2[rk]
+        assert rel_l2(human[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+        r = g1[rk][nh:]
+        assert rel_l2(scene[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+    # only the FIRST render's screen-space gradient is what the trainer consumes (gs_trainer.py:316-342)
+    assert rel_l2(pkg["viewspace_points"].grad.cpu().numpy(), g1["means2D"]) <= GRAD_REL_TOL
+
+
+def test_c5_one_frame_of_the_300k_batch(device):
+    from hugs_amd.renderer import render
+    H, W, P = 1080, 1920, 300_000
+    cam0 = syn.pinhole_camera(H, W)
+    m = scene_model(P, cam0, seed=0)
+    yaw = math.radians(1.5) * 5  # the camera rank 5 of an 8-GPU run renders
+    w2c = np.eye(4)
+    w2c[0, 0], w2c[0, 2], w2c[2, 0], w2c[2, 2] = math.cos(yaw), math.sin(yaw), -math.sin(yaw), math.cos(yaw)
+    cam = syn.camera_from_w2c(w2c, cam0["fovx"], cam0["fovy"], H, W)
+    ref_f, _ = oracle_run(m, cam, (1, 1, 1), 3, np.zeros((3, H, W), np.float32))
+    mod = as_model(m, device, 3)
+    with torch.no_grad():
+        pkg = render(mod["xyz"], mod["shs"], mod["opacity"], mod["scales"], mod["rotq"], cam_data(cam, device),
+                     bg_color=torch.ones(3, device=device), active_sh_degree=3)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), ref_f["radii"])
+    check_image(pkg["render"].cpu().numpy(), np.clip(ref_f["color"], 0, 1), "C5 frame")

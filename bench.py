@@ -61,10 +61,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    device = torch.device("cuda", local_rank)
+    # HGS_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (several
+    # ranks then share a GPU); the driver's runs use the default: one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, profile_enable,
@@ -83,7 +89,8 @@ def main():
 
     dev = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
     t = {k: dev(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    sharding.broadcast_gaussians([v.data for v in t.values()])  # replicas of rank 0's Gaussians
+    if backend == "nccl":
+        sharding.broadcast_gaussians([v.data for v in t.values()])  # replicas of rank 0's Gaussians (same seed anyway)
     means2D = torch.zeros(P, 3, device=device, requires_grad=True)
     dLd = dev(dL)
     settings = GaussianRasterizationSettings(
@@ -120,7 +127,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = profile_read()
     profile_enable(())
-    elapsed = sharding.max_over_ranks(elapsed, device)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")  # where the tiny metric collectives run
+    elapsed = sharding.max_over_ranks(elapsed, coll_dev)
 
     # exact integers of this frame (shared with the oracle): N and the visible count
     N = color.grad_fn.num_rendered if color.grad_fn is not None else None
@@ -129,7 +137,7 @@ def main():
         from diff_gaussian_rasterization import _debug_forward_state
         N = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
                                  scales=t["scales"].detach(), rotations=t["rotations"].detach())[2]["N"]
-    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv)]], world, device=device)
+    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv)]], world, device=coll_dev)
 
     # per-stage breakdown in a separate, untimed pass (every stage bracketed by events)
     profile_enable()

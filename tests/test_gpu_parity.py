@@ -377,3 +377,70 @@ def test_full_size_workload_parity_and_properties(device):
         r = refg[rk]
         assert rel_l2(g1[k].cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
     assert rel_l2(m1.cpu().numpy(), refg["means2D"]) <= GRAD_REL_TOL
+
+
+def _stacked_scene(P, H, W, seed, spread_px):
+    """P small Gaussians whose centres all project into a few neighbouring tiles in the image centre: exercises the
+    tile-sort paths for long lists (LDS bitonic for 1024 < n <= 8192, rank fallback beyond) and heavy atomics."""
+    import math
+    from hugs_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    cam = syn.pinhole_camera(H, W)
+    f = W / (2.0 * math.tan(cam["fovx"] / 2))
+    z = rng.uniform(2.0, 9.0, P)
+    # a handful of exactly repeated depths so that ties are broken by index inside the long lists too
+    z[rng.choice(P, P // 10, replace=False)] = 5.0
+    x = rng.uniform(-spread_px, spread_px, P) / f * z
+    y = rng.uniform(-spread_px, spread_px, P) / f * z
+    sc = dict(means3D=np.stack([x, y, z], 1).astype(np.float32),
+              scales=(np.exp(rng.normal(np.log(0.004), 0.3, (P, 3))) * z[:, None] / 5.0).astype(np.float32),
+              rotations=rng.standard_normal((P, 4)).astype(np.float32),
+              opacities=rng.uniform(0.01, 0.3, (P, 1)).astype(np.float32),
+              shs=(0.5 * rng.standard_normal((P, 16, 3))).astype(np.float32), colors_precomp=None, cov3D_precomp=None,
+              cam=cam, H=H, W=W, D=1, M=16, bg=np.array([0.1, 0.2, 0.3], np.float32), scale_modifier=1.0,
+              tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5))
+    sc["rotations"] /= np.linalg.norm(sc["rotations"], axis=1, keepdims=True)
+    sc["dL_dpix"] = rng.standard_normal((3, H, W)).astype(np.float32)
+    return sc
+
+
+@pytest.mark.parametrize("P,longest_at_least", [(3000, 1025), (20000, 8193)])
+def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, device):
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = _stacked_scene(P, 64, 64, seed=40 + P, spread_px=6.0)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert lens.max() >= longest_at_least, f"scene not dense enough: longest tile list {lens.max()}"
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], f"stacked P={P}")
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    t, color, _ = run_gpu(sc, device)
+    color.backward(to_dev(sc["dL_dpix"], device))
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        r = refg[k]
+        assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+
+
+def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):
+    """A 4096 x 2304 image has 36 864 tiles: the binning kernels cannot keep a per-tile array in LDS and fall back
+    to direct global atomics; results must not change."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(P=3000, H=2304, W=4096, seed=50, D=2, sigma_px=20.0, with_culled=True)
+    sc["dL_dpix"] = None
+    ref = ho.forward(oracle_inputs(sc))
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], "36k tiles")

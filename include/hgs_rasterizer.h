@@ -121,6 +121,15 @@ int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);
 int32_t hgs_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present,
                          void *stream);
 
+/* SURVEY.md 8f row f-1 -- fused densification statistics, the trainer-side consumer of the rasterizer's outputs
+ * (/root/reference/hugs/trainer/gs_trainer.py:406-411,429-435 and hugs/models/scene.py:460-462): for the first n
+ * Gaussians with visibility_filter[i] != 0, in place:
+ *   max_radii2D[i] = max(max_radii2D[i], radii[i]);  xyz_gradient_accum[i] += ||viewspace_grad[i, 0:2]||;  denom[i] += 1
+ * viewspace_grad is the [>= n, 3] gradient the rasterizer left in viewspace_points.grad. */
+int32_t hgs_densification_stats(int32_t n, const float *viewspace_grad, const int32_t *radii,
+                                const uint8_t *visibility_filter, float *max_radii2D, float *xyz_gradient_accum,
+                                float *denom, void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

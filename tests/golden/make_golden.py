@@ -199,6 +199,48 @@ def main():
                                     "kwargs": {k: _desc(v) for k, v in c["kwargs"].items()}})
     out["boundary_transcript_json"] = np.frombuffer(json.dumps(transcript, sort_keys=True).encode(), dtype=np.uint8)
 
+    # ---- densification statistics: the reference's own statements, executed ----
+    # gs_trainer.py:406-411 (GaussianTrainer.scene_densification) and scene.py:460-462 (SceneGS.add_densification_stats)
+    # (the two modules pull in half of the reference's dependency tree, so the two methods are compiled straight
+    # from their source files -- the reference's own statements, untouched -- instead of importing the modules)
+    import ast
+
+    def _method_from_source(path, cls, name, ns):
+        tree = ast.parse(open(path).read())
+        node = next(f for c in tree.body if isinstance(c, ast.ClassDef) and c.name == cls
+                    for f in c.body if isinstance(f, ast.FunctionDef) and f.name == name)
+        node.decorator_list = []
+        exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        return ns[name]
+
+    ns = {"torch": torch, "logger": mock.MagicMock()}
+    SceneGS = types.SimpleNamespace(add_densification_stats=_method_from_source(
+        os.path.join(REF, "hugs/models/scene.py"), "SceneGS", "add_densification_stats", dict(ns)))
+    GaussianTrainer = types.SimpleNamespace(scene_densification=_method_from_source(
+        os.path.join(REF, "hugs/trainer/gs_trainer.py"), "GaussianTrainer", "scene_densification", dict(ns)))
+    n, extra = 300, 40          # the gradient tensor has `extra` more rows than the model (joint human+scene mode)
+    g = torch.Generator().manual_seed(7)
+    vpt = torch.zeros(n + extra, 3, requires_grad=True)
+    vpt.grad = torch.randn(n + extra, 3, generator=g)
+    radii = torch.randint(0, 60, (n,), generator=g, dtype=torch.int32)
+    vis = radii > 12
+    state = types.SimpleNamespace(max_radii2D=torch.rand(n, generator=g) * 50, xyz_gradient_accum=torch.rand(n, 1, generator=g),
+                                  denom=torch.randint(0, 5, (n, 1), generator=g).float())
+    out["dens_grad"], out["dens_radii"], out["dens_vis"] = vpt.grad.numpy().copy(), radii.numpy().copy(), vis.numpy().copy()
+    out["dens_in_max_radii2D"], out["dens_in_accum"], out["dens_in_denom"] = (state.max_radii2D.numpy().copy(),
+                                                                              state.xyz_gradient_accum.numpy().copy(),
+                                                                              state.denom.numpy().copy())
+    state.add_densification_stats = lambda v, f: SceneGS.add_densification_stats(state, v, f)
+    trainer = types.SimpleNamespace(
+        scene_gs=state, bg_color=torch.zeros(3),
+        cfg=types.SimpleNamespace(scene=types.SimpleNamespace(densify_from_iter=10 ** 9, densification_interval=1,
+                                                              opacity_reset_interval=10 ** 9)))
+    with torch.no_grad():
+        GaussianTrainer.scene_densification(trainer, visibility_filter=vis, radii=radii, viewspace_point_tensor=vpt, iteration=1)
+    out["dens_out_max_radii2D"], out["dens_out_accum"], out["dens_out_denom"] = (state.max_radii2D.numpy().copy(),
+                                                                                 state.xyz_gradient_accum.numpy().copy(),
+                                                                                 state.denom.numpy().copy())
+
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT) / 1024:.1f} KiB")
 

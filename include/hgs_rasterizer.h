@@ -16,8 +16,9 @@
  * The library allocates nothing that outlives a call: per-call scratch (geometry, binning and
  * image state) is obtained through the caller's allocation callback so that it lives in
  * caller-owned memory (torch uint8 tensors kept by the autograd ctx until backward).
- * All work is enqueued on `stream` (a hipStream_t); forward performs ONE host
- * synchronisation on that stream (to learn N, the number of (tile, Gaussian) pairs, and size the binning buffer).
+ * All work is enqueued on `stream` (a hipStream_t); forward waits ONCE on the host for a 4-byte copy of N, the number
+ * of (tile, Gaussian) pairs that sizes the binning buffer -- before enqueueing the rest of the frame, or, when the
+ * caller passes binning_capacity_hint, after it (the wait then overlaps the GPU's work).
  * All floating point is fp32, contiguous.
  */
 #ifndef HGS_RASTERIZER_H
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 1
+#define HGS_ABI_VERSION 2
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
@@ -82,6 +83,11 @@ typedef struct hgs_forward_args {
     const float *cov3D_precomp;  /* [P,6] or NULL (exactly one of (scales,rotations) / cov3D_precomp) */
     float *out_color;            /* [3,H,W], written for every pixel when P > 0 */
     int32_t *radii;              /* [P] */
+    /* Optional guess (entries) of N, the number of (tile, Gaussian) pairs -- e.g. last frame's N plus a margin; 0 =
+     * none.  With a guess the binning buffer is allocated and the whole frame enqueued before N is known, so the GPU
+     * never waits for the host; if the frame needs more than the guess, binning + blending are enqueued again with
+     * the exact size (results are identical either way). */
+    int64_t binning_capacity_hint;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -89,7 +95,8 @@ typedef struct hgs_forward_state {
     void *geom;    size_t geom_bytes;
     void *binning; size_t binning_bytes;
     void *image;   size_t image_bytes;
-    int64_t num_rendered; /* N = sum of tiles touched */
+    int64_t num_rendered;     /* N = sum of tiles touched */
+    int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */

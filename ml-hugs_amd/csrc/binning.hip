@@ -50,10 +50,12 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
 
 // ---------------------------------------------------------------------------------------------
 // tile_scan: single workgroup; exclusive scan of the per-tile counts.  ranges[t] = (0,0) for an empty tile (as the
-// oracle leaves them); cursor[t] = start of the tile's segment; *n_total = N.
+// oracle leaves them); cursor[t] = start of the tile's segment; n_total[0] = N; n_total[1] = (N > capacity), the gate
+// that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
+// too small (hgs_api.hip).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total)
+                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t capacity)
 {
     __shared__ uint32_t wsum[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -79,13 +81,14 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
         }
         carry += total;
     }
-    if (threadIdx.x == 0) *n_total = carry;
+    if (threadIdx.x == 0) n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u;
 }
 
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      hipStream_t st)
+                      uint32_t capacity, hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total,
+                       capacity);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -231,8 +234,9 @@ count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __re
 template <bool USE_LDS>
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
-            uint64_t* __restrict__ keys)
+            uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
 {
+    if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     extern __shared__ uint32_t hist[];
     __shared__ float4 stage[BIN_THREADS / 64][64][3];
     const int w = threadIdx.x >> 6, num_tiles = cam.gx * cam.gy;
@@ -288,13 +292,14 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
         hipLaunchKernelGGL(count_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
 }
 
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, hipStream_t st)
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
+                 hipStream_t st)
 {
     const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
     if (num_tiles <= BIN_LDS_TILES)
-        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, keys);
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, keys, gate);
     else
-        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, keys);
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, keys, gate);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,9 +424,11 @@ __device__ __forceinline__ void tile_sort_small(uint32_t tile, uint32_t s, uint3
 
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
-                       uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count)
+                       uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count,
+                       const uint32_t* __restrict__ gate)
 {
     __shared__ uint64_t sh[SORT_CAP_SMALL];
+    if (*gate) return;
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t s = rg.x, n = rg.y - rg.x;
     if (n == 0) {
@@ -440,9 +447,10 @@ template <int CAP>
 __global__ void __launch_bounds__(256)
 tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
                        uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
-                       uint32_t* __restrict__ act_count)
+                       uint32_t* __restrict__ act_count, const uint32_t* __restrict__ gate)
 {
     __shared__ uint64_t sh[CAP];
+    if (*gate) return;
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t s = rg.x, n = rg.y - rg.x;
     if (n <= (uint32_t)SORT_CAP_SMALL) return;  // the small kernel's tile
@@ -486,11 +494,12 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
 }
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      uint64_t* act, size_t stride, uint32_t* act_count, hipStream_t st)
+                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* gate, hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count);
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
+                       gate);
     hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, scratch,
-                       act, stride, act_count);
+                       act, stride, act_count, gate);
 }
 
 }  // namespace hgs

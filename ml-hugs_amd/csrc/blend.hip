@@ -103,8 +103,9 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ gate)
 {
+    if (*(const_u32p)gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63;
@@ -153,10 +154,10 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, hipStream_t st)
+                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, hipStream_t st)
 {
     hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
-                       act_stride, act_count, splats, bg, out_color, final_T, n_contrib);
+                       act_stride, act_count, splats, bg, out_color, final_T, n_contrib, gate);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,6 +88,25 @@ struct ProfScope {
     }
 };
 
+// Pinned 4-byte host slots (+ an event each) for the N read-back; a small ring so concurrent calls do not collide.
+struct PinnedSlot { uint32_t* host; hipEvent_t ev; };
+PinnedSlot pinned_slot()
+{
+    constexpr int RING = 64;
+    static std::mutex mu;
+    static uint32_t* base = nullptr;
+    static hipEvent_t evs[RING];
+    static unsigned next = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base) {
+        if (hipHostMalloc((void**)&base, RING * 64, hipHostMallocDefault) != hipSuccess) return {nullptr, nullptr};
+        for (int i = 0; i < RING; ++i)
+            if (hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) return {nullptr, nullptr};
+    }
+    const unsigned k = next++ % RING;
+    return {base + 16 * k, evs[k]};
+}
+
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
 {
     int b = 0;
@@ -214,38 +233,54 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
       HIP_TRY(hipMemsetAsync(tile_count, 0, il.counters_bytes, st));
       launch_preprocess(a, cam, splats, tiles_touched, st); }
     STAGE_CHECK(dbg, st, "preprocess");
+    // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
+    const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
+    const uint32_t cap32 = hint > 0 ? (uint32_t)(hint > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : hint) : 0xFFFFFFFFu;
     { ProfScope ps(HGS_STAGE_SCAN, st);
       launch_count(a.P, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, st); }
+      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, cap32, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
 
-    // the one host synchronisation of the forward pass: N sizes the binning buffer
-    uint32_t n32 = 0;
-    HIP_TRY(hipMemcpyAsync(&n32, n_total, sizeof n32, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const int64_t N = (int64_t)n32;
-    state->num_rendered = N;
+    // N travels to a pinned host slot; the event marks its arrival
+    PinnedSlot slot = pinned_slot();
+    if (!slot.host || !slot.ev) return fail(HGS_ERR_HIP, "pinned host buffer / event creation failed");
+    HIP_TRY(hipMemcpyAsync(slot.host, n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(slot.ev, st));
 
-    BinningLayout bl(N);
-    char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
-    if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
-    state->binning = bin, state->binning_bytes = bl.total;
-    uint64_t* keys = (uint64_t*)(bin + bl.keys);
-    uint64_t* list = (uint64_t*)(bin + bl.list);
-    uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
-
-    if (N > 0) {
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, st); }
+    const uint32_t* gate = n_total + 1;
+    // enqueue emit -> sort -> blend for a binning buffer laid out for `capacity` entries
+    auto enqueue_frame = [&](int64_t capacity) -> int {
+        BinningLayout bl(capacity);
+        char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
+        if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
+        state->binning = bin, state->binning_bytes = bl.total, state->binning_capacity = capacity;
+        uint64_t* keys = (uint64_t*)(bin + bl.keys);
+        uint64_t* list = (uint64_t*)(bin + bl.list);
+        uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
+        { ProfScope ps(HGS_STAGE_SORT, st);
+          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, gate, st); }
+        STAGE_CHECK(dbg, st, "tile_sort");
+        { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
+          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
+                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, st); }
+        STAGE_CHECK(dbg, st, "blend_forward");
+        return HGS_OK;
+    };
+
+    if (hint > 0)
+        if (int rc = enqueue_frame(hint)) return rc;  // optimistic: the GPU runs on while the host waits for N below
+    HIP_TRY(hipEventSynchronize(slot.ev));
+    const int64_t N = (int64_t)*slot.host;
+    state->num_rendered = N;
+    if (hint <= 0 || N > hint) {
+        // exact size known now; after a too-small guess the gated kernels above did nothing, and the emit cursors are
+        // untouched, so the frame is simply enqueued again
+        HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
+        if (int rc = enqueue_frame(N)) return rc;
     }
-    { ProfScope ps(HGS_STAGE_SORT, st);
-      launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, st); }
-    STAGE_CHECK(dbg, st, "tile_sort");
-    { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-      launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
-                           (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), st); }
-    STAGE_CHECK(dbg, st, "blend_forward");
     return N;
 }
 
@@ -266,7 +301,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const bool dbg = f.s.debug != 0;
     GeomLayout gl(f.P);
     ImageLayout il(cam.H, cam.W);
-    BinningLayout bl(a.state.num_rendered);
+    BinningLayout bl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered);
     if (a.state.geom_bytes < gl.total || a.state.image_bytes < il.total || a.state.binning_bytes < bl.total)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size");
     const char* geom = (const char*)a.state.geom;

@@ -95,15 +95,16 @@ void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* p
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      hipStream_t st);
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, hipStream_t st);
+                      uint32_t capacity, hipStream_t st);
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
+                 hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      uint64_t* act, size_t stride, uint32_t* act_count, hipStream_t st);
+                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* gate, hipStream_t st);
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, hipStream_t st);
+                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,

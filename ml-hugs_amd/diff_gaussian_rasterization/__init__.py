@@ -27,7 +27,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 1
+_ABI_VERSION = 2
 
 
 def library_path():
@@ -47,13 +47,13 @@ class _ForwardArgs(C.Structure):
     _fields_ = [("s", _Settings), ("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
-                ("out_color", C.c_void_p), ("radii", C.c_void_p)]
+                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64)]
 
 
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
-                ("num_rendered", C.c_int64)]
+                ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64)]
 
 
 class _BackwardArgs(C.Structure):
@@ -196,6 +196,18 @@ def _fill_forward(a, rs, means3D, sh, colors_precomp, opacities, scales, rotatio
     a.cov3D_precomp = _ptr(cov3D_precomp)
 
 
+# Last frame's N per (device, P, H, W): the next frame of the same shape passes it (plus a margin) as
+# binning_capacity_hint, so the library enqueues the whole frame before it waits for this frame's N.
+# HGS_BINNING_HINT=0 turns the guess off (forward then waits for N before binning, as upstream does).
+_last_num_rendered = {}
+_USE_HINT = os.environ.get("HGS_BINNING_HINT", "1") != "0"
+
+
+def _capacity_hint(key):
+    n = _last_num_rendered.get(key) if _USE_HINT else None
+    return 0 if n is None else n + n // 8 + 4096
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -228,6 +240,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         args, state = _ForwardArgs(), _ForwardState()
         _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
+        hint_key = (dev.index, P, H, W)
+        args.binning_capacity_hint = _capacity_hint(hint_key)
         with torch.cuda.device(dev):
             n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), _stream_ptr(dev))
         if n < 0:
@@ -235,6 +249,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(n)
+        ctx.binning_capacity = int(state.binning_capacity)
+        _last_num_rendered[hint_key] = int(n)
         ctx.state = (state.geom_bytes, state.binning_bytes, state.image_bytes)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D,
@@ -283,6 +299,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             a.state.geom, a.state.binning, a.state.image = _ptr(geom), _ptr(binning), _ptr(image)
             a.state.geom_bytes, a.state.binning_bytes, a.state.image_bytes = ctx.state
             a.state.num_rendered = ctx.num_rendered
+            a.state.binning_capacity = ctx.binning_capacity
             grad_out_color = _f32c(grad_out_color)
             a.dL_dout_color = grad_out_color.data_ptr()
             a.grad_accum, a.dL_dmeans2D, a.dL_dopacity = g_accum.data_ptr(), g_means2D.data_ptr(), g_opacity.data_ptr()
@@ -377,7 +394,8 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
     geom, binning, image = saved[8], saved[9], saved[10]
     P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
     N = color.grad_fn.num_rendered
-    off = lambda name: lib.hgs_scratch_offset(name.encode(), P, N, H, W)
+    cap = color.grad_fn.binning_capacity if P > 0 else 0   # the binning buffer is laid out for `cap` >= N entries
+    off = lambda name: lib.hgs_scratch_offset(name.encode(), P, cap, H, W)
     T = ((H + 15) // 16) * ((W + 15) // 16)
 
     def sub(buf, name, nbytes, dtype):
@@ -402,4 +420,5 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         depth_bits = holder["splats"][:, 9].contiguous().view(torch.int32)[holder["values"].long()].long() & 0xFFFFFFFF
         holder["keys"] = (tile_of << 32) | depth_bits
     holder["N"] = N
+    holder["binning_capacity"] = cap
     return color.detach(), radii, holder

@@ -181,6 +181,35 @@ def test_forward_is_deterministic_and_debug_mode_matches(device):
     assert torch.equal(c1, c2) and torch.equal(r1, r2)
 
 
+@pytest.mark.parametrize("guess", ["none", "too_small", "ample"])
+def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch):
+    """forward enqueues the frame before N is known when it has a guess of N (include/hgs_rasterizer.h,
+    binning_capacity_hint); a guess that is too small must be detected on the device and the frame redone."""
+    import diff_gaussian_rasterization as dgr
+    sc = make_scene(**CASES["basic_d3"])
+    key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])
+    dgr._last_num_rendered.pop(key, None)
+    t0, c0, r0 = run_gpu(sc, device)                       # no guess: waits for N, exact capacity
+    n = c0.grad_fn.num_rendered
+    assert c0.grad_fn.binning_capacity == n and dgr._last_num_rendered[key] == n
+    c0.backward(to_dev(sc["dL_dpix"], device))
+    if guess == "none":
+        dgr._last_num_rendered.pop(key)
+    elif guess == "too_small":
+        monkeypatch.setattr(dgr, "_capacity_hint", lambda k: 100)
+        assert n > 1000
+    t1, c1, r1 = run_gpu(sc, device)
+    cap = c1.grad_fn.binning_capacity
+    assert c1.grad_fn.num_rendered == n
+    assert cap == (n if guess != "ample" else n + n // 8 + 4096)
+    c1.backward(to_dev(sc["dL_dpix"], device))
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        if t0[k] is not None and t0[k].grad is not None:   # float atomics: summation order differs run to run
+            assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= 1e-5, k
+
+
 def test_api_errors(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(**CASES["single"])

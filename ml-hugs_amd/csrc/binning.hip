@@ -52,10 +52,12 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
 // tile_scan: single workgroup; exclusive scan of the per-tile counts.  ranges[t] = (0,0) for an empty tile (as the
 // oracle leaves them); cursor[t] = start of the tile's segment; n_total[0] = N; n_total[1] = (N > capacity), the gate
 // that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
-// too small (hgs_api.hip).
+// too small (hgs_api.hip).  N is also published to the host, straight from this kernel, as ONE 64-bit system-scope
+// store (ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t capacity)
+                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t capacity,
+                 unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
     __shared__ uint32_t wsum[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -81,14 +83,18 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
         }
         carry += total;
     }
-    if (threadIdx.x == 0) n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u;
+        __hip_atomic_store(host_slot, ((unsigned long long)ticket << 32) | carry, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t capacity, hipStream_t st)
+                      uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
 {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total,
-                       capacity);
+                       capacity, host_slot, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -170,9 +170,33 @@ __device__ __forceinline__ float dpp_mov(float v)
 }
 constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
-constexpr int DPP_ROW_SHL4 = 0x104;  // lane i <- lane i+4 (within a row of 16)
-constexpr int DPP_ROW_SHR4 = 0x114;  // lane i <- lane i-4
 constexpr int DPP_ROW_ROR8 = 0x128;  // lane i <- lane i^8 (rotate by half a row)
+constexpr int DPP_ROW_MIRROR = 0x140;       // lane i <- lane 15-i of its row
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i of its half-row
+constexpr int DPP_ROW_BCAST15 = 0x142;      // lane 15 of each row -> every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143;      // lane 31 -> every lane of rows 2 and 3
+
+// DPP move applied to the rows in ROW_MASK only; the other rows read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_rows(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// a and b are exchanged across the wave halves (W = 32) or across odd/even rows of 16 (W = 16) and added:
+// W = 32: lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l];
+// W = 16: rows 0 and 2 get a[row] + a[row+1], rows 1 and 3 get b[row-1] + b[row].
+typedef uint32_t swap_pair_t __attribute__((ext_vector_type(2)));
+template <int W>
+__device__ __forceinline__ float swap_add(float a, float b)
+{
+    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+    swap_pair_t r;
+    if constexpr (W == 32) r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+    else r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+    const uint32_t r0 = r.x, r1 = r.y;
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
 
 // pairwise transpose-reduce step: afterwards lanes with `hi` clear hold (a + partner's a) and lanes
 // with `hi` set hold (b + partner's b); partner = lane ^ XOR within the quad.
@@ -194,8 +218,7 @@ struct PixBwd {
 
 // Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9].
 // Returns (wave-uniform) whether any lane contributed.
-__device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9], float ddelx_dx,
-                                          float ddely_dy)
+__device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9])
 {
     const float dx = s.x - p.pxf, dy = s.y - p.pyf;
     const float power = gauss_power(s, dx, dy);
@@ -216,19 +239,18 @@ __device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
         p.last_alpha = alpha;
         // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
         const float dL_dalpha = __builtin_fmaf(p.neg_Tf_bg, inv, (cg - p.behind_g) * p.T);
-        const float dL_dG = s.op * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        // conic = (-2A, -B, -2C)
-        const float dG_ddelx = __builtin_fmaf(2.0f * gdx, s.A, gdy * s.B);
-        const float dG_ddely = __builtin_fmaf(2.0f * gdy, s.C, gdx * s.B);
-        v[0] = __builtin_fmaf(dL_dG * dG_ddelx, ddelx_dx, v[0]);
-        v[1] = __builtin_fmaf(dL_dG * dG_ddely, ddely_dy, v[1]);
-        const float h = -0.5f * dL_dG;
-        const float hgdx = h * gdx, hgdy = h * gdy;
-        v[2] = __builtin_fmaf(hgdx, dx, v[2]);
-        v[3] = __builtin_fmaf(hgdx, dy, v[3]);
-        v[4] = __builtin_fmaf(hgdy, dy, v[4]);
-        v[5] = __builtin_fmaf(G, dL_dalpha, v[5]);
+        // The geometry sums are kept in raw-moment form, u = G dL/dalpha:
+        //   v0 = sum u dx, v1 = sum u dy, v2 = sum u dx^2, v3 = sum u dx dy, v4 = sum u dy^2, v5 = sum u;
+        // the per-Gaussian factors (opacity, conic, viewport scale, -1/2) are applied once per Gaussian by
+        // preprocess_backward_kernel instead of once per pixel here.
+        const float u = G * dL_dalpha;
+        const float ux = u * dx, uy = u * dy;
+        v[0] += ux;
+        v[1] += uy;
+        v[2] = __builtin_fmaf(ux, dx, v[2]);
+        v[3] = __builtin_fmaf(ux, dy, v[3]);
+        v[4] = __builtin_fmaf(uy, dy, v[4]);
+        v[5] += u;
         v[6] = __builtin_fmaf(dch, p.g0, v[6]);
         v[7] = __builtin_fmaf(dch, p.g1, v[7]);
         v[8] = __builtin_fmaf(dch, p.g2, v[8]);
@@ -257,7 +279,6 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     if (range.y <= range.x) return;
     const size_t HW = (size_t)cam.H * cam.W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const float ddelx_dx = 0.5f * (float)cam.W, ddely_dy = 0.5f * (float)cam.H;
 
     PixBwd p[4];
     uint32_t wmax = 0;
@@ -283,7 +304,11 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     if (wmax == 0) return;
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    const bool b3 = lane & 8;
+    // which accumulator slot this lane's reduced value belongs to (see the reduction below); -1: none
+    const int half_row = lane >> 3;  // row = half_row >> 1, half = half_row & 1
+    const int slot_in_row[4] = {0, 2, 1, 3};
+    const int slot_of_lane = lane == 63 ? 8 : ((lane & 7) == 0 ? slot_in_row[half_row >> 1] + 4 * (half_row & 1) : -1);
 
     // entries of this tile that cover at least one quad (list 4), walked back to front; those beyond the deepest
     // position any pixel composited (pos1 > wmax) are skipped with a scalar branch
@@ -297,30 +322,29 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
         bool any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if ((val >> (GID_BITS + k)) & 1u) any |= bwd_pixel(s, pos1, p[k], v, ddelx_dx, ddely_dy);
+            if ((val >> (GID_BITS + k)) & 1u) any |= bwd_pixel(s, pos1, p[k], v);
         if (!any) return;
-        // ---- butterfly transpose-reduce of 8 values; lane (l & 7) == k ends up owning value k ----
-        // slot order k: 0 mx, 1 my, 2 cxx, 3 cxy, 4 cyy, 5 op, 6 r, 7 g   (+ b reduced on its own -> lane 8)
-        const float w0 = pair_step<DPP_QUAD_XOR1>(v[0], v[1], b0);
-        const float w1 = pair_step<DPP_QUAD_XOR1>(v[2], v[3], b0);
-        const float w2 = pair_step<DPP_QUAD_XOR1>(v[4], v[5], b0);
-        const float w3 = pair_step<DPP_QUAD_XOR1>(v[6], v[7], b0);
-        const float x0 = pair_step<DPP_QUAD_XOR2>(w0, w1, b1);
-        const float x1 = pair_step<DPP_QUAD_XOR2>(w2, w3, b1);
-        const float x1_dn = dpp_mov<DPP_ROW_SHR4>(x1), x0_up = dpp_mov<DPP_ROW_SHL4>(x0);
-        float y = b2 ? (x1 + x1_dn) : (x0 + x0_up);
+        // ---- transpose-reduce of v0..v7 over the wave: each step adds partner lanes AND halves the number of live
+        // registers.  Lane-half and row exchanges are gfx950's v_permlane{32,16}_swap (no select needed: the swap
+        // itself routes value a to one half and value b to the other), then one select step inside the row and three
+        // plain DPP adds.  Afterwards every lane of half-row (row r, half h) holds the total of slot_of_lane.
+        const float s0 = swap_add<32>(v[0], v[1]), s1 = swap_add<32>(v[2], v[3]);   // lanes 0-31: a, lanes 32-63: b
+        const float s2 = swap_add<32>(v[4], v[5]), s3 = swap_add<32>(v[6], v[7]);
+        const float t0 = swap_add<16>(s0, s1), t1 = swap_add<16>(s2, s3);           // rows: v0 v2 v1 v3 | v4 v6 v5 v7
+        float y = pair_step<DPP_ROW_ROR8>(t0, t1, b3);                              // lanes 0-7 of a row: t0, 8-15: t1
+        y += dpp_mov<DPP_ROW_HALF_MIRROR>(y);
+        y += dpp_mov<DPP_QUAD_XOR2>(y);
+        y += dpp_mov<DPP_QUAD_XOR1>(y);
+        // v8 (blue): plain reduction; the classic gfx9 row broadcasts leave the wave total in row 3
         float vb = v[8] + dpp_mov<DPP_QUAD_XOR1>(v[8]);
         vb += dpp_mov<DPP_QUAD_XOR2>(vb);
-        const float vb_dn = dpp_mov<DPP_ROW_SHR4>(vb), vb_up = dpp_mov<DPP_ROW_SHL4>(vb);
-        vb += b2 ? vb_dn : vb_up;
-        y += dpp_mov<DPP_ROW_ROR8>(y);
-        vb += dpp_mov<DPP_ROW_ROR8>(vb);
-        y += __shfl_xor(y, 16, 64);
-        vb += __shfl_xor(vb, 16, 64);
-        y += __shfl_xor(y, 32, 64);
-        vb += __shfl_xor(vb, 32, 64);
-        // lanes 0..8 add the nine totals into the Gaussian's accumulator record with one atomic instruction
-        if (lane < 9) atomicAdd(grad_accum + (size_t)(val & GID_MASK) * 12u + lane, lane == 8 ? vb : y);
+        vb += dpp_mov<DPP_ROW_HALF_MIRROR>(vb);
+        vb += dpp_mov<DPP_ROW_MIRROR>(vb);
+        vb += dpp_mov_rows<DPP_ROW_BCAST15, 0xA>(vb);
+        vb += dpp_mov_rows<DPP_ROW_BCAST31, 0xC>(vb);
+        // eight half-row leaders + lane 63 add the nine totals into the Gaussian's accumulator record with one
+        // atomic instruction
+        if (slot_of_lane >= 0) atomicAdd(grad_accum + (size_t)(val & GID_MASK) * 12u + slot_of_lane, lane == 63 ? vb : y);
     };
 
     // pair p = entries top[-2p-2] (shallower) and top[-2p-1] (deeper); the front pad of `act` makes the read

@@ -88,23 +88,52 @@ struct ProfScope {
     }
 };
 
-// Pinned 4-byte host slots (+ an event each) for the N read-back; a small ring so concurrent calls do not collide.
-struct PinnedSlot { uint32_t* host; hipEvent_t ev; };
-PinnedSlot pinned_slot()
+// The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes (ticket << 32 | N) and the
+// host polls: a ring of slots so that calls from several threads / streams do not collide.
+struct HostSlot { volatile unsigned long long* word; uint32_t ticket; };
+HostSlot host_slot()
 {
-    constexpr int RING = 64;
+    constexpr unsigned RING = 64;
     static std::mutex mu;
-    static uint32_t* base = nullptr;
-    static hipEvent_t evs[RING];
-    static unsigned next = 0;
+    static unsigned long long* base = nullptr;
+    static uint32_t next = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (!base) {
-        if (hipHostMalloc((void**)&base, RING * 64, hipHostMallocDefault) != hipSuccess) return {nullptr, nullptr};
-        for (int i = 0; i < RING; ++i)
-            if (hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) return {nullptr, nullptr};
+        if (hipHostMalloc((void**)&base, RING * 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            base = nullptr;
+            return {nullptr, 0};
+        }
+        memset(base, 0, RING * 64);
     }
-    const unsigned k = next++ % RING;
-    return {base + 16 * k, evs[k]};
+    ++next;
+    if (next == 0) ++next;  // ticket 0 is the initial content of a slot
+    return {base + 8 * (next % RING), next};
+}
+
+// Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
+// (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
+int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out)
+{
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long v = *hs.word;
+        if ((uint32_t)(v >> 32) == hs.ticket) {
+            *n_out = (uint32_t)v;
+            return HGS_OK;
+        }
+        if ((spins & 0x3FFF) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {
+                const unsigned long long v2 = *hs.word;
+                if ((uint32_t)(v2 >> 32) == hs.ticket) {
+                    *n_out = (uint32_t)v2;
+                    return HGS_OK;
+                }
+                return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
+            }
+            if (q != hipErrorNotReady) return fail(HGS_ERR_HIP, "HIP error while waiting for tile_scan: %s", hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
@@ -236,16 +265,12 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
     const uint32_t cap32 = hint > 0 ? (uint32_t)(hint > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : hint) : 0xFFFFFFFFu;
+    const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
+    if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
       launch_count(a.P, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, cap32, st); }
+      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
-
-    // N travels to a pinned host slot; the event marks its arrival
-    PinnedSlot slot = pinned_slot();
-    if (!slot.host || !slot.ev) return fail(HGS_ERR_HIP, "pinned host buffer / event creation failed");
-    HIP_TRY(hipMemcpyAsync(slot.host, n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(slot.ev, st));
 
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
     const uint32_t* gate = n_total + 1;
@@ -272,8 +297,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     if (hint > 0)
         if (int rc = enqueue_frame(hint)) return rc;  // optimistic: the GPU runs on while the host waits for N below
-    HIP_TRY(hipEventSynchronize(slot.ev));
-    const int64_t N = (int64_t)*slot.host;
+    uint32_t n32 = 0;
+    if (int rc = wait_for_slot(slot, st, &n32)) return rc;
+    const int64_t N = (int64_t)n32;
     state->num_rendered = N;
     if (hint <= 0 || N > hint) {
         // exact size known now; after a too-small guess the gated kernels above did nothing, and the emit cursors are

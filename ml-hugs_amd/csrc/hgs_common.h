@@ -95,7 +95,7 @@ void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* p
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t capacity, hipStream_t st);
+                      uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
                  hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)

@@ -226,10 +226,25 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    // accumulator record written by the blend-backward atomics: mx my cxx cxy | cyy op r g | b - - -
-    const float4 acc0 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i];
-    const float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
+    // accumulator record written by the blend-backward atomics, raw moments of u = G dL/dalpha over the pixels:
+    //   sum u dx, sum u dy, sum u dx^2, sum u dx dy | sum u dy^2, sum u, dL/dr, dL/dg | dL/db - - -
+    // turned here, once per Gaussian, into dL/dmean2D (pixel units -> NDC-scaled, A.6 quirk 3), dL/dconic and
+    // dL/dopacity with the Gaussian's own opacity and half-conic (A, B, C) = -(conic.x/2, conic.y, conic.z/2):
+    //   dG/ddx = G (2A dx + B dy),  dG/dconic.x = -G dx^2 / 2,  dalpha/dG = opacity.
+    float4 acc0 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i];
+    float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
     const float acc_b = grad_accum[12 * (size_t)i + 8];
+    {
+        const float4 h0 = reinterpret_cast<const float4*>(splats + i)[0];
+        const float4 h1 = reinterpret_cast<const float4*>(splats + i)[1];
+        const bool live = __float_as_int(reinterpret_cast<const float4*>(splats + i)[2].z) > 0;  // else: record unset
+        const float A = live ? h0.z : 0.0f, B = live ? h0.w : 0.0f, C = live ? h1.x : 0.0f, op = live ? h1.y : 0.0f;
+        const float sx = acc0.x, sy = acc0.y;
+        const float half_op = -0.5f * op;
+        acc0.x = op * (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);
+        acc0.y = op * (0.5f * (float)cam.H) * (2.0f * C * sy + B * sx);
+        acc0.z = half_op * acc0.z, acc0.w = half_op * acc0.w, acc1.x = half_op * acc1.x;
+    }
     dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
     dL_dopacity[i] = acc1.y;
     dL_dcolors[3 * (size_t)i] = acc1.z, dL_dcolors[3 * (size_t)i + 1] = acc1.w, dL_dcolors[3 * (size_t)i + 2] = acc_b;

@@ -208,6 +208,29 @@ def _capacity_hint(key):
     return 0 if n is None else n + n // 8 + 4096
 
 
+def _grad_slab(P, M, dev):
+    """One allocation carved into the [P,12] atomic accumulator (the only part that must be zeroed -- the
+    library overwrites every other element) followed by the eight gradient tensors."""
+    sizes = [12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+    slab[:max(offs[1], 1)].zero_()
+    view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
+    return (view(0, P, 12), view(1, P, 3), view(2, P, 1), view(3, P, 3), view(4, P, 3), view(5, P, 6),
+            view(6, P, M, 3), view(7, P, 3), view(8, P, 4))
+
+
+def _point_at_grads(a, grads, M):
+    g_accum, g_means2D, g_opacity, g_colors, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
+    a.grad_accum, a.dL_dmeans2D, a.dL_dopacity = g_accum.data_ptr(), g_means2D.data_ptr(), g_opacity.data_ptr()
+    a.dL_dcolors, a.dL_dmeans3D, a.dL_dcov3D = g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr()
+    a.dL_dsh = g_sh.data_ptr() if M else None
+    a.dL_dscales, a.dL_drotations = g_scales.data_ptr(), g_rot.data_ptr()
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -237,21 +260,30 @@ class _RasterizeGaussians(torch.autograd.Function):
             return t.data_ptr()
 
         cb = _ALLOC_FN(_alloc)
-        args, state = _ForwardArgs(), _ForwardState()
+        # The backward call's argument block is built here, around the forward's: forward fills `bw.fwd` and
+        # `bw.state` in place, and -- when a gradient will be asked for -- the gradient slab is allocated and its
+        # accumulator zeroed now, ahead of the rasterizer's kernels, so that backward() itself is one library call.
+        bw = _BackwardArgs()
+        args, state = bw.fwd, bw.state
         _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
+        M = int(args.M)
+        grads = None
+        if P > 0 and any(ctx.needs_input_grad):
+            grads = _grad_slab(P, M, dev)
+            _point_at_grads(bw, grads, M)
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint = _capacity_hint(hint_key)
         with torch.cuda.device(dev):
-            n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), _stream_ptr(dev))
+            stream = _stream_ptr(dev)
+            n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), stream)
         if n < 0:
             _raise_last(lib, "rasterize_gaussians")
 
-        ctx.raster_settings = rs
         ctx.num_rendered = int(n)
         ctx.binning_capacity = int(state.binning_capacity)
         _last_num_rendered[hint_key] = int(n)
-        ctx.state = (state.geom_bytes, state.binning_bytes, state.image_bytes)
+        ctx.bw, ctx.grads, ctx.keep, ctx.dims = bw, grads, keep, (P, M)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D,
                               sh if sh is not None else empty,
@@ -267,47 +299,23 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         lib = _load()
-        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
-         image) = ctx.saved_tensors
-        rs = ctx.raster_settings
+        # the saved tensors are what `ctx.bw` points into: unpacking them also runs autograd's in-place-modification check
+        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, _radii, _geom, _binning,
+         _image) = ctx.saved_tensors
         dev = means3D.device
-        P = means3D.shape[0]
-        M = sh.shape[1] if sh.numel() else 0
-        none_if_empty = lambda t: t if t.numel() else None
-
-        # one slab carved into the gradient tensors; only its head (the [P,12] atomic accumulator) needs
-        # zeroing -- the library overwrites every other element
-        sizes = [12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
-        offs, total = [], 0
-        for s in sizes:
-            offs.append(total)
-            total += (s + 63) // 64 * 64
-        slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
-        slab[:max(offs[1], 1)].zero_()
-        view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
-        g_accum, g_means2D, g_opacity = view(0, P, 12), view(1, P, 3), view(2, P, 1)
-        g_colors, g_means3D, g_cov3D = view(3, P, 3), view(4, P, 3), view(5, P, 6)
-        g_sh, g_scales, g_rot = view(6, P, M, 3), view(7, P, 3), view(8, P, 4)
+        P, M = ctx.dims
+        bw, grads = ctx.bw, ctx.grads
+        if grads is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
+            grads = _grad_slab(P, M, dev)
+            _point_at_grads(bw, grads, M)
+        ctx.grads = None
+        g_accum, g_means2D, g_opacity, g_colors, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
 
         if P > 0:
-            keep = {"device": dev}
-            a = _BackwardArgs()
-            _fill_forward(a.fwd, rs, means3D, none_if_empty(sh), none_if_empty(colors_precomp),
-                          none_if_empty(opacities), none_if_empty(scales), none_if_empty(rotations),
-                          none_if_empty(cov3Ds_precomp), keep)
-            a.fwd.radii = _ptr(radii)
-            a.state.geom, a.state.binning, a.state.image = _ptr(geom), _ptr(binning), _ptr(image)
-            a.state.geom_bytes, a.state.binning_bytes, a.state.image_bytes = ctx.state
-            a.state.num_rendered = ctx.num_rendered
-            a.state.binning_capacity = ctx.binning_capacity
             grad_out_color = _f32c(grad_out_color)
-            a.dL_dout_color = grad_out_color.data_ptr()
-            a.grad_accum, a.dL_dmeans2D, a.dL_dopacity = g_accum.data_ptr(), g_means2D.data_ptr(), g_opacity.data_ptr()
-            a.dL_dcolors, a.dL_dmeans3D, a.dL_dcov3D = g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr()
-            a.dL_dsh = g_sh.data_ptr() if M else None
-            a.dL_dscales, a.dL_drotations = g_scales.data_ptr(), g_rot.data_ptr()
+            bw.dL_dout_color = grad_out_color.data_ptr()
             with torch.cuda.device(dev):
-                rc = lib.hgs_rasterize_backward(C.byref(a), _stream_ptr(dev))
+                rc = lib.hgs_rasterize_backward(C.byref(bw), _stream_ptr(dev))
             if rc < 0:
                 _raise_last(lib, "rasterize_gaussians_backward")
 

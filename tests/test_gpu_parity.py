@@ -210,6 +210,24 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
             assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= 1e-5, k
 
 
+def test_second_backward_through_a_retained_graph(device):
+    """forward prepares the first backward's gradient slab; a second backward must not reuse (and overwrite) it."""
+    sc = make_scene(**CASES["basic_d3"])
+    t, color, _ = run_gpu(sc, device)
+    g = to_dev(sc["dL_dpix"], device)
+    color.backward(g, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in t.items() if v is not None and v.grad is not None}
+    held = {k: v.grad for k, v in t.items() if v is not None and v.grad is not None}  # aliases of the first slab
+    for v in t.values():
+        if v is not None:
+            v.grad = None
+    color.backward(g)
+    torch.cuda.synchronize()
+    for k, v in first.items():
+        assert torch.equal(held[k], v), f"{k}: the first backward's gradient was overwritten"
+        assert rel_l2(t[k].grad.cpu().numpy(), v.cpu().numpy()) <= 1e-5, k
+
+
 def test_api_errors(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(**CASES["single"])

@@ -88,6 +88,9 @@ typedef struct hgs_forward_args {
      * never waits for the host; if the frame needs more than the guess, binning + blending are enqueued again with
      * the exact size (results are identical either way). */
     int64_t binning_capacity_hint;
+    /* Optional [P,12] floats: the `grad_accum` the caller is going to hand to hgs_rasterize_backward for this frame.
+     * When non-NULL forward zeroes it (inside its first kernel, for free), so the caller need not. */
+    float *grad_accum_to_zero;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -103,10 +106,11 @@ typedef struct hgs_forward_state {
 int64_t hgs_rasterize_forward(const hgs_forward_args *args, hgs_alloc_fn alloc, void *alloc_ctx,
                               hgs_forward_state *state_out, void *stream);
 
-/* Replaces _C.rasterize_gaussians_backward.  `grad_accum` ([P,12] floats: dL/d{mean2D.x, mean2D.y,
- * conic xx, xy, yy, opacity, r, g, b}, 3 pad) is scratch that must be ZERO-INITIALISED by the caller: the
- * blend-backward kernel accumulates into it with float atomics.  Every dL_* output is fully overwritten
- * (zeros for culled Gaussians and for SH coefficients above the active degree); no pre-zeroing needed. */
+/* Replaces _C.rasterize_gaussians_backward.  `grad_accum` ([P,12] floats per Gaussian: nine raw sums over the pixels
+ * -- u dx, u dy, u dx^2, u dx dy, u dy^2, u (u = G dL/dalpha), dL/dr, dL/dg, dL/db -- and 3 pad) is scratch that must
+ * be ZERO on entry (zeroed by the caller, or by forward through fwd.grad_accum_to_zero): the blend-backward kernel
+ * accumulates into it with float atomics.  Every dL_* output is fully overwritten (zeros for culled Gaussians and
+ * for SH coefficients above the active degree); no pre-zeroing needed. */
 typedef struct hgs_backward_args {
     hgs_forward_args fwd;       /* same inputs as forward (out_color unused; radii = forward's output) */
     hgs_forward_state state;    /* as returned by forward */

@@ -54,12 +54,17 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
 // that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
 // too small (hgs_api.hip).  N is also published to the host, straight from this kernel, as ONE 64-bit system-scope
 // store (ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
+constexpr int SORT_CAP_SMALL = 1024, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
+
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t capacity,
-                 unsigned long long* __restrict__ host_slot, uint32_t ticket)
+                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t* __restrict__ large_tiles,
+                 uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t n_large;
+    if (threadIdx.x == 0) n_large = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (int base = 0; base < num_tiles; base += 1024) {
@@ -80,21 +85,24 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
             const uint32_t start = carry + before + inc - c;
             ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
             cursor[t] = start;
+            if (c > (uint32_t)SORT_CAP_SMALL) large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)t;  // rare
         }
         carry += total;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u;
+        n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u, n_total[2] = n_large;
         __hip_atomic_store(host_slot, ((unsigned long long)ticket << 32) | carry, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
+                      uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
+                      hipStream_t st)
 {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total,
-                       capacity, host_slot, ticket);
+                       large_tiles, capacity, host_slot, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,7 +321,6 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
 // compacted per-quad lists the blend kernels stream (no bitmaps, no global prefix sum, no extra kernels).
 // Sort key: (depth bits << 32) | (gaussian << 4) | mask: depth first, then Gaussian index (the mask rides along).
 // Output: list[i] = (pos1 << 32) | (mask << 28 | gaussian), pos1 = 1-based position inside the tile.
-constexpr int SORT_CAP_SMALL = 1024, SORT_CAP_LARGE = 8192;
 
 __device__ __forceinline__ uint64_t list_entry(uint64_t key, uint32_t pos1)
 {
@@ -453,13 +460,16 @@ template <int CAP>
 __global__ void __launch_bounds__(256)
 tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
                        uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
-                       uint32_t* __restrict__ act_count, const uint32_t* __restrict__ gate)
+                       uint32_t* __restrict__ act_count, const uint32_t* __restrict__ large_tiles,
+                       const uint32_t* __restrict__ n_total)
 {
     __shared__ uint64_t sh[CAP];
-    if (*gate) return;
-    const uint2 rg = ranges[blockIdx.x];
+    if (n_total[1]) return;  // gate
+    // a fixed, small grid walks the (usually empty) list of long tiles that tile_scan_kernel made
+    for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
+    const uint32_t tile = large_tiles[li];
+    const uint2 rg = ranges[tile];
     const uint32_t s = rg.x, n = rg.y - rg.x;
-    if (n <= (uint32_t)SORT_CAP_SMALL) return;  // the small kernel's tile
     if (n <= (uint32_t)CAP) {
         uint32_t m = 2;
         while (m < n) m <<= 1;
@@ -496,16 +506,19 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     }
 #pragma unroll
     for (int q = 0; q < NUM_LISTS; ++q)
-        if (threadIdx.x == 0) act_count[blockIdx.x * NUM_LISTS + q] = carry[q];
+        if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
+    __syncthreads();  // sh is reused by the next tile
+    }
 }
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* gate, hipStream_t st)
+                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
+                      const uint32_t* n_total, hipStream_t st)
 {
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                       gate);
-    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, scratch,
-                       act, stride, act_count, gate);
+                       n_total + 1);
+    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(256), 0, st, ranges,
+                       keys, list, scratch, act, stride, act_count, large_tiles, n_total);
 }
 
 }  // namespace hgs

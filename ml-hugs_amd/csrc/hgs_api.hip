@@ -256,11 +256,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t* tile_count = (uint32_t*)(image + il.tile_count);
     uint32_t* cursor = (uint32_t*)(image + il.cursor);
     uint32_t* n_total = (uint32_t*)(image + il.n_total);
+    uint32_t* large_tiles = (uint32_t*)(image + il.large_tiles);
     const int num_tiles = cam.gx * cam.gy;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
-      HIP_TRY(hipMemsetAsync(tile_count, 0, il.counters_bytes, st));
-      launch_preprocess(a, cam, splats, tiles_touched, st); }
+      launch_preprocess(a, cam, splats, tiles_touched, tile_count, st); }
     STAGE_CHECK(dbg, st, "preprocess");
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
@@ -269,7 +269,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
       launch_count(a.P, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
+      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, large_tiles, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
 
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
@@ -286,7 +286,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
-          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, gate, st); }
+          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total, st); }
         STAGE_CHECK(dbg, st, "tile_sort");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
           launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,

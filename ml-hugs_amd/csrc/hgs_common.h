@@ -53,8 +53,7 @@ struct GeomLayout {
 constexpr int ACT_PAD = 16;
 constexpr int NUM_LISTS = 5;  // four per-quad lists + one "any quad" list per tile
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, act_count, tile_count, cursor, n_total, total;
-    size_t counters_bytes;  // tile_count .. n_total are contiguous: one memset before the preprocess kernel
+    size_t final_T, n_contrib, ranges, act_count, tile_count, cursor, large_tiles, n_total, total;
     ImageLayout(int H, int W) {
         size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
         size_t o = 0;
@@ -62,10 +61,10 @@ struct ImageLayout {
         n_contrib = o;  o = align_up(o + 4 * S);
         ranges = o;     o = align_up(o + 8 * T);
         act_count = o;  o = align_up(o + 4 * T * NUM_LISTS);   // entries in each tile's compacted lists
-        tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (count kernel)
+        tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (zeroed by K1, count kernel adds)
         cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
-        n_total = o;    o = align_up(o + 64);
-        counters_bytes = o - tile_count;
+        large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
+        n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles
         total = o;
     }
 };
@@ -89,18 +88,20 @@ struct BinningLayout {
 
 // kernels / launchers (defined in the .hip files)
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       hipStream_t st);
+                       uint32_t* tile_count, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
 void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, hipStream_t st);
+                      uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
+                      hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
                  hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
-                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* gate, hipStream_t st);
+                      uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
+                      const uint32_t* n_total, hipStream_t st);
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,

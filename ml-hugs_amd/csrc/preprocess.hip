@@ -103,9 +103,19 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                   const float* __restrict__ scales, const float* __restrict__ rots,
                   const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
-                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii)
+                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
+                  uint32_t* __restrict__ tile_count, int num_tiles, float4* __restrict__ zero_accum)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Housekeeping that would otherwise be two more launches: the per-tile counters the count kernel adds into, and
+    // (when the caller will run backward) the [P,12] gradient accumulator, are zeroed here, fully coalesced.
+    for (int j = i; j < num_tiles; j += gridDim.x * 256) tile_count[j] = 0u;
+    if (zero_accum) {
+        const size_t base = (size_t)blockIdx.x * 768, end = (size_t)P * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (base + k * 256 + threadIdx.x < end) zero_accum[base + k * 256 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (i >= P) return;
 
     Splat out;
@@ -203,12 +213,13 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
 }
 
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       hipStream_t st)
+                       uint32_t* tile_count, hipStream_t st)
 {
     int blocks = (a.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
                        a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
-                       a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii);
+                       a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, cam.gx * cam.gy,
+                       (float4*)a.grad_accum_to_zero);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ class _ForwardArgs(C.Structure):
     _fields_ = [("s", _Settings), ("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
-                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64)]
+                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
+                ("grad_accum_to_zero", C.c_void_p)]
 
 
 class _ForwardState(C.Structure):
@@ -208,16 +209,17 @@ def _capacity_hint(key):
     return 0 if n is None else n + n // 8 + 4096
 
 
-def _grad_slab(P, M, dev):
-    """One allocation carved into the [P,12] atomic accumulator (the only part that must be zeroed -- the
-    library overwrites every other element) followed by the eight gradient tensors."""
+def _grad_slab(P, M, dev, zero):
+    """One allocation carved into the [P,12] atomic accumulator (the only part that must be zero -- the library
+    overwrites every other element; `zero=False` when forward is asked to zero it) and the eight gradient tensors."""
     sizes = [12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
     offs, total = [], 0
     for n in sizes:
         offs.append(total)
         total += (n + 63) // 64 * 64
     slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
-    slab[:max(offs[1], 1)].zero_()
+    if zero:
+        slab[:max(offs[1], 1)].zero_()
     view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
     return (view(0, P, 12), view(1, P, 3), view(2, P, 1), view(3, P, 3), view(4, P, 3), view(5, P, 6),
             view(6, P, M, 3), view(7, P, 3), view(8, P, 4))
@@ -270,8 +272,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = int(args.M)
         grads = None
         if P > 0 and any(ctx.needs_input_grad):
-            grads = _grad_slab(P, M, dev)
+            grads = _grad_slab(P, M, dev, zero=False)
             _point_at_grads(bw, grads, M)
+            args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint = _capacity_hint(hint_key)
         with torch.cuda.device(dev):
@@ -294,6 +297,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               cov3Ds_precomp if cov3Ds_precomp is not None else empty,
                               radii, bufs.get(0, empty), bufs.get(1, empty), bufs.get(2, empty))
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zero-filled int32 "gradient" for radii
         return color, radii
 
     @staticmethod
@@ -305,8 +309,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         P, M = ctx.dims
         bw, grads = ctx.bw, ctx.grads
+        if grad_out_color is None:  # colour did not take part in the loss
+            ctx.grads = None
+            return (None,) * 9
         if grads is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
-            grads = _grad_slab(P, M, dev)
+            grads = _grad_slab(P, M, dev, zero=True)
             _point_at_grads(bw, grads, M)
         ctx.grads = None
         g_accum, g_means2D, g_opacity, g_colors, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads

@@ -171,9 +171,9 @@ __device__ __forceinline__ void stage_wave(int P, const Camera& cam, const Splat
             r0 = make_float4(px, py, head.z, head.w);
             if (with_mask_inputs) {
                 const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
-                // contributes iff opacity * exp(power) >= 1/255  <=>  power >= -(ln 255 + ln opacity); 0.05 of
-                // slack covers the blend kernels' rounding (and makes the mask a strict superset)
-                const float thr = -(5.5412635f + __logf(mid.y)) - 0.05f;
+                // log2 domain (hgs_common.h): contributes iff exp2(power + L) >= 1/255  <=>  power >= -(log2 255 + L);
+                // 0.07 of slack covers the blend kernels' rounding (and makes the mask a strict superset)
+                const float thr = -(7.9943534f + mid.y) - 0.07f;
                 r1 = make_float4(mid.x, thr, tail.y, 0.f);  // C, threshold, depth
             }
             r2 = make_float4(__int_as_float(minx), __int_as_float(miny), __int_as_float(maxx - minx), 0.f);

@@ -34,8 +34,8 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
 typedef const __attribute__((address_space(4))) uint64_t* const_u64p;
 typedef const __attribute__((address_space(4))) v2u* const_u2p;
 
-struct SplatRec {  // wave-uniform (lives in SGPRs)
-    float x, y, A, B, C, op, r, g, b;
+struct SplatRec {  // wave-uniform (lives in SGPRs); log2 domain: alpha = exp2(A dx^2 + B dx dy + C dy^2 + L)
+    float x, y, A, B, C, L, r, g, b;
 };
 
 // `entry_low` = low word of a list entry (mask << 28 | gaussian); the index is clamped because the software
@@ -49,16 +49,17 @@ __device__ __forceinline__ SplatRec load_rec(const Splat* splats, uint32_t entry
     const float b = ((const_f32p)p)[8];
     SplatRec s;
     s.x = h0.x, s.y = h0.y;
-    s.A = h0.z, s.B = h0.w, s.C = h1.x;  // half-conic form: power = A dx^2 + B dx dy + C dy^2
-    s.op = h1.y, s.r = h1.z, s.g = h1.w, s.b = b;
+    s.A = h0.z, s.B = h0.w, s.C = h1.x;
+    s.L = h1.y, s.r = h1.z, s.g = h1.w, s.b = b;
     return s;
 }
 
-__device__ __forceinline__ float gauss_power(const SplatRec& s, float dx, float dy)
+// log2 of the uncapped alpha: (A dx^2 + B dx dy + C dy^2) + L, five VALU ops
+__device__ __forceinline__ float log2_alpha(const SplatRec& s, float dx, float dy)
 {
     float t = __builtin_fmaf(s.A, dx, s.B * dy);
     float u = s.C * dy;
-    return __builtin_fmaf(dx, t, u * dy);
+    return __builtin_fmaf(dx, t, __builtin_fmaf(u, dy, s.L));
 }
 
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, so give each
@@ -87,9 +88,9 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
                                                float& C0, float& C1, float& C2, uint32_t& last)
 {
     const float dx = s.x - pxf, dy = s.y - pyf;
-    const float power = gauss_power(s, dx, dy);
-    const float alpha = fminf(ALPHA_MAX, s.op * __expf(power));
-    const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
+    const float e = log2_alpha(s, dx, dy);
+    const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(e));
+    const bool ok = e <= s.L && alpha >= ALPHA_MIN;  // e <= L: the exponent of the Gaussian is not positive
     const float test_T = T * (1.0f - alpha);
     const bool upd = ok && test_T >= T_STOP;
     const float wgt = upd ? alpha * T : 0.0f;
@@ -221,10 +222,10 @@ struct PixBwd {
 __device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9])
 {
     const float dx = s.x - p.pxf, dy = s.y - p.pyf;
-    const float power = gauss_power(s, dx, dy);
-    const float G = __expf(power);
-    const float alpha = fminf(ALPHA_MAX, s.op * G);
-    const bool act_lane = pos1 <= p.last_contributor && power <= 0.0f && alpha >= ALPHA_MIN;
+    const float e = log2_alpha(s, dx, dy);
+    const float alpha_uncapped = __builtin_amdgcn_exp2f(e);  // = opacity * G
+    const float alpha = fminf(ALPHA_MAX, alpha_uncapped);
+    const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
     if (__ballot(act_lane) == 0ull) return false;
     if (act_lane) {
         const float one_m = 1.0f - alpha;
@@ -239,11 +240,11 @@ __device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
         p.last_alpha = alpha;
         // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
         const float dL_dalpha = __builtin_fmaf(p.neg_Tf_bg, inv, (cg - p.behind_g) * p.T);
-        // The geometry sums are kept in raw-moment form, u = G dL/dalpha:
+        // The geometry sums are kept in raw-moment form, u = opacity G dL/dalpha (straight-through alpha cap):
         //   v0 = sum u dx, v1 = sum u dy, v2 = sum u dx^2, v3 = sum u dx dy, v4 = sum u dy^2, v5 = sum u;
         // the per-Gaussian factors (opacity, conic, viewport scale, -1/2) are applied once per Gaussian by
         // preprocess_backward_kernel instead of once per pixel here.
-        const float u = G * dL_dalpha;
+        const float u = alpha_uncapped * dL_dalpha;
         const float ux = u * dx, uy = u * dy;
         v[0] += ux;
         v[1] += uy;

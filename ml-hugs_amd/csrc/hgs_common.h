@@ -13,6 +13,7 @@ constexpr float NEAR_Z = 0.2f;  // near cull
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // Sorted list values: low 28 bits = Gaussian index, top 4 bits = quad coverage mask (bit q: the splat may
 // reach alpha >= 1/255 somewhere in the tile's 8x8 quad q = qx + 2 qy; conservative, see binning.hip).
@@ -23,8 +24,10 @@ constexpr uint32_t GID_MASK = (1u << GID_BITS) - 1u;
 // 48 bytes, 16-byte aligned: three dwordx4 (scalar or vector) loads.
 struct alignas(16) Splat {
     float x, y;        // pixel-space mean
-    float ca, cb, cc;  // half-conic (A,B,C) = (-conic.xx/2, -conic.xy, -conic.yy/2): power = A dx^2 + B dx dy + C dy^2
-    float opacity;
+    // The blend kernels work in the log2 domain: alpha = exp2(A dx^2 + B dx dy + C dy^2 + L), one v_exp_f32 with no
+    // multiply before or after.  (A,B,C) = fl(LOG2E * (-conic.xx/2, -conic.xy, -conic.yy/2)); L = log2(opacity).
+    float ca, cb, cc;
+    float log2_opacity;
     float r, g, b;     // view-dependent colour after +0.5 / clamp
     float depth;       // view-space z; its raw bits are the low half of the sort key
     int32_t radius;    // 0 => culled

@@ -119,7 +119,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     if (i >= P) return;
 
     Splat out;
-    out.x = out.y = out.ca = out.cb = out.cc = out.opacity = out.r = out.g = out.b = out.depth = 0.0f;
+    out.x = out.y = out.ca = out.cb = out.cc = out.log2_opacity = out.r = out.g = out.b = out.depth = 0.0f;
     out.radius = 0;
     out.clamped = 0;
     uint32_t touched = 0;
@@ -167,12 +167,12 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
             if (alive) {
                 out.x = px;
                 out.y = py;
-                // stored in half-conic form (A, B, C) = (-conic.x/2, -conic.y, -conic.z/2): exact rescale, so the
-                // blend kernels evaluate power = A dx^2 + B dx dy + C dy^2 without per-splat fix-ups
-                out.ca = -0.5f * (e.c * det_inv);
-                out.cb = -(-e.b * det_inv);
-                out.cc = -0.5f * (e.a * det_inv);
-                out.opacity = opacities[i];
+                // stored for the log2 domain (hgs_common.h): the half-conic (-conic.x/2, -conic.y, -conic.z/2) -- an exact
+                // rescale -- times LOG2E (one rounding), and log2(opacity)
+                out.ca = (-0.5f * (e.c * det_inv)) * LOG2E;
+                out.cb = (-(-e.b * det_inv)) * LOG2E;
+                out.cc = (-0.5f * (e.a * det_inv)) * LOG2E;
+                out.log2_opacity = __log2f(opacities[i]);
                 out.depth = pv[2];
                 out.radius = (int32_t)radf;
                 touched = (uint32_t)((maxx - minx) * (maxy - miny));
@@ -201,12 +201,12 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
         }
     }
     if (!alive) {
-        out.x = out.y = out.ca = out.cb = out.cc = out.opacity = out.depth = 0.0f;
+        out.x = out.y = out.ca = out.cb = out.cc = out.log2_opacity = out.depth = 0.0f;
         out.radius = 0;
     }
     float4* dst = reinterpret_cast<float4*>(splats + i);
     dst[0] = make_float4(out.x, out.y, out.ca, out.cb);
-    dst[1] = make_float4(out.cc, out.opacity, out.r, out.g);
+    dst[1] = make_float4(out.cc, out.log2_opacity, out.r, out.g);
     dst[2] = make_float4(out.b, out.depth, __int_as_float(out.radius), __uint_as_float(out.clamped));
     tiles_touched[i] = touched;
     radii[i] = out.radius;
@@ -226,7 +226,7 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // K8+K9 fused: one thread per Gaussian, only radius > 0 does work.  Outputs are pre-zeroed by the caller.
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
-                           const float* __restrict__ scales, const float* __restrict__ rots,
+                           const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rots,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                            const float* __restrict__ F, const float* __restrict__ campos,
                            const Splat* __restrict__ splats, const float* __restrict__ grad_accum,
@@ -239,9 +239,10 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
     if (i >= P) return;
     // accumulator record written by the blend-backward atomics, raw moments of u = G dL/dalpha over the pixels:
     //   sum u dx, sum u dy, sum u dx^2, sum u dx dy | sum u dy^2, sum u, dL/dr, dL/dg | dL/db - - -
-    // turned here, once per Gaussian, into dL/dmean2D (pixel units -> NDC-scaled, A.6 quirk 3), dL/dconic and
-    // dL/dopacity with the Gaussian's own opacity and half-conic (A, B, C) = -(conic.x/2, conic.y, conic.z/2):
-    //   dG/ddx = G (2A dx + B dy),  dG/dconic.x = -G dx^2 / 2,  dalpha/dG = opacity.
+    // with u = opacity G dL/dalpha (the uncapped alpha times dL/dalpha).  Turned here, once per Gaussian, into
+    // dL/dmean2D (pixel units -> NDC-scaled, A.6 quirk 3), dL/dconic and dL/dopacity with the Gaussian's own opacity
+    // and half-conic (A, B, C) = -(conic.x/2, conic.y, conic.z/2) (the record holds LOG2E times it):
+    //   dG/ddx = G (2A dx + B dy),  dG/dconic.x = -G dx^2 / 2,  dalpha/dopacity = G.
     float4 acc0 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i];
     float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
     const float acc_b = grad_accum[12 * (size_t)i + 8];
@@ -249,12 +250,13 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         const float4 h0 = reinterpret_cast<const float4*>(splats + i)[0];
         const float4 h1 = reinterpret_cast<const float4*>(splats + i)[1];
         const bool live = __float_as_int(reinterpret_cast<const float4*>(splats + i)[2].z) > 0;  // else: record unset
-        const float A = live ? h0.z : 0.0f, B = live ? h0.w : 0.0f, C = live ? h1.x : 0.0f, op = live ? h1.y : 0.0f;
+        const float A = live ? h0.z * LN2 : 0.0f, B = live ? h0.w * LN2 : 0.0f, C = live ? h1.x * LN2 : 0.0f;
+        const float op = live ? opacities[i] : 0.0f;
         const float sx = acc0.x, sy = acc0.y;
-        const float half_op = -0.5f * op;
-        acc0.x = op * (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);
-        acc0.y = op * (0.5f * (float)cam.H) * (2.0f * C * sy + B * sx);
-        acc0.z = half_op * acc0.z, acc0.w = half_op * acc0.w, acc1.x = half_op * acc1.x;
+        acc0.x = (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);
+        acc0.y = (0.5f * (float)cam.H) * (2.0f * C * sy + B * sx);
+        acc0.z = -0.5f * acc0.z, acc0.w = -0.5f * acc0.w, acc1.x = -0.5f * acc1.x;
+        acc1.y = op > 0.0f ? acc1.y / op : 0.0f;  // sum of G dL/dalpha
     }
     dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
     dL_dopacity[i] = acc1.y;
@@ -462,7 +464,7 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
     const hgs_forward_args& f = a.fwd;
     int blocks = (f.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, f.P, cam, f.means3D, f.shs,
-                       f.scales, f.rotations, f.cov3D_precomp, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
+                       f.opacities, f.scales, f.rotations, f.cov3D_precomp, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
                        a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
                        a.dL_drotations, a.dL_dcov3D);
 }

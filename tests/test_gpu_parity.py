@@ -92,15 +92,21 @@ def test_forward_stages_and_image(name, device):
     sp = st["splats"].cpu().numpy()
     vis = ref["radii"] > 0
     assert np.array_equal(sp[:, 10].view(np.int32), ref["radii"])
-    # the device record keeps the conic in half-conic form (-x/2, -y, -z/2): an exact power-of-two rescale
-    half = np.float32(-0.5)
+    # the device record keeps the conic for the log2 domain: the half-conic form (-x/2, -y, -z/2), an exact
+    # power-of-two rescale, times fl32(log2 e) -- one more fp32 rounding, reproduced here -- and log2(opacity)
+    # in place of the opacity (v_log_f32: ~1 ulp, the one field that is not bit-exact)
+    half, log2e = np.float32(-0.5), np.float32(1.4426950408889634)
     for col, (refarr, label) in {0: (ref["xy"][:, 0], "x"), 1: (ref["xy"][:, 1], "y"),
-                                 2: (half * ref["conic_opacity"][:, 0], "conic.x"), 3: (-ref["conic_opacity"][:, 1], "conic.y"),
-                                 4: (half * ref["conic_opacity"][:, 2], "conic.z"), 5: (ref["conic_opacity"][:, 3], "opacity"),
+                                 2: (half * ref["conic_opacity"][:, 0] * log2e, "conic.x"),
+                                 3: (-ref["conic_opacity"][:, 1] * log2e, "conic.y"),
+                                 4: (half * ref["conic_opacity"][:, 2] * log2e, "conic.z"),
                                  6: (ref["rgb"][:, 0], "r"), 7: (ref["rgb"][:, 1], "g"), 8: (ref["rgb"][:, 2], "b"),
                                  9: (ref["depths"], "depth")}.items():
+        assert refarr.dtype == np.float32
         a, b = sp[vis, col].view(np.uint32), np.ascontiguousarray(refarr[vis]).view(np.uint32)
         assert np.array_equal(a, b), f"{name}: splat field {label} not bit-exact ({(a != b).sum()} of {vis.sum()})"
+    l2 = np.log2(ref["conic_opacity"][vis, 3].astype(np.float64))
+    assert np.abs(sp[vis, 5] - l2).max() <= 4e-7 * np.maximum(1.0, np.abs(l2)).max(), f"{name}: log2(opacity)"
     clamp_bits = ref["clamped"][:, 0] | (ref["clamped"][:, 1] << 1) | (ref["clamped"][:, 2] << 2)
     assert np.array_equal(sp[vis, 11].view(np.uint32), clamp_bits[vis].astype(np.uint32))
     # ---- K2..K5 exact

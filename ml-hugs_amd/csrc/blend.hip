@@ -217,17 +217,18 @@ struct PixBwd {
     uint32_t last_contributor;
 };
 
-// Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9].
-// Returns (wave-uniform) whether any lane contributed.
-__device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9])
+// Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9] and raises
+// the lane's `contributed` flag.  The body is one exec-masked region: a quad none of whose pixels takes the splat
+// costs the alpha evaluation and a branch.
+__device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9], uint32_t& contributed)
 {
     const float dx = s.x - p.pxf, dy = s.y - p.pyf;
     const float e = log2_alpha(s, dx, dy);
     const float alpha_uncapped = __builtin_amdgcn_exp2f(e);  // = opacity * G
     const float alpha = fminf(ALPHA_MAX, alpha_uncapped);
     const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
-    if (__ballot(act_lane) == 0ull) return false;
     if (act_lane) {
+        contributed = 1u;
         const float one_m = 1.0f - alpha;
         const float inv = __builtin_amdgcn_rcpf(one_m);
         p.T = p.T * inv;
@@ -256,7 +257,6 @@ __device__ __forceinline__ bool bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
         v[7] = __builtin_fmaf(dch, p.g1, v[7]);
         v[8] = __builtin_fmaf(dch, p.g2, v[8]);
     }
-    return true;
 }
 
 // One wave per tile (four tiles per 256-thread workgroup, no LDS, no barrier).  A lane's four pixels sit in
@@ -320,11 +320,11 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     auto backward_entry = [&](const SplatRec& s, uint32_t val, uint32_t pos1) {
         if (pos1 > wmax) return;
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        bool any = false;
+        uint32_t contributed = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if ((val >> (GID_BITS + k)) & 1u) any |= bwd_pixel(s, pos1, p[k], v);
-        if (!any) return;
+            if ((val >> (GID_BITS + k)) & 1u) bwd_pixel(s, pos1, p[k], v, contributed);
+        if (__builtin_amdgcn_ballot_w64(contributed != 0u) == 0ull) return;
         // ---- transpose-reduce of v0..v7 over the wave: each step adds partner lanes AND halves the number of live
         // registers.  Lane-half and row exchanges are gfx950's v_permlane{32,16}_swap (no select needed: the swap
         // itself routes value a to one half and value b to the other), then one select step inside the row and three

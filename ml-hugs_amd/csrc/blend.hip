@@ -212,8 +212,10 @@ __device__ __forceinline__ float pair_step(float a, float b, bool hi)
 // (same (lx, ly) offset inside every quad), so that one wave covers the whole 16x16 tile.
 struct PixBwd {
     float pxf, pyf;
-    float T, behind_g, last_cg, last_alpha;  // running transmittance; (colour behind).g; previous splat's c.g, alpha
-    float g0, g1, g2, neg_Tf_bg;             // dL/dpixel, and -T_final * (bg . dL/dpixel)
+    float T;           // running transmittance (in front of the entry being processed, once divided by 1 - alpha)
+    float S;           // everything composited behind that entry, dotted with dL/dpixel:
+                       //   T_final (bg . g) + sum over deeper entries j of (c_j . g) alpha_j T_j
+    float g0, g1, g2;  // g = dL/dpixel
     uint32_t last_contributor;
 };
 
@@ -229,18 +231,14 @@ __device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
     const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
     if (act_lane) {
         contributed = 1u;
-        const float one_m = 1.0f - alpha;
-        const float inv = __builtin_amdgcn_rcpf(one_m);
-        p.T = p.T * inv;
-        const float dch = alpha * p.T;
-        // "colour behind" only ever enters through its dot product with dL/dpixel, so carry that scalar:
-        // behind_g = last_alpha * (last_colour . g) + (1 - last_alpha) * behind_g
-        p.behind_g = __builtin_fmaf(p.last_alpha, p.last_cg, (1.0f - p.last_alpha) * p.behind_g);
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        p.T = p.T * inv;  // transmittance in front of this entry
         const float cg = __builtin_fmaf(s.r, p.g0, __builtin_fmaf(s.g, p.g1, s.b * p.g2));
-        p.last_cg = cg;
-        p.last_alpha = alpha;
-        // dL/dalpha = T (c.g - behind.g) - T_final/(1-alpha) * (bg.g)
-        const float dL_dalpha = __builtin_fmaf(p.neg_Tf_bg, inv, (cg - p.behind_g) * p.T);
+        // pixel = sum_j c_j alpha_j T_j + T_final bg and every T_j behind this entry carries a factor (1 - alpha):
+        //   dL/dalpha = T (c . g) - S / (1 - alpha)
+        const float dL_dalpha = __builtin_fmaf(p.T, cg, -(p.S * inv));
+        const float dch = alpha * p.T;
+        p.S = __builtin_fmaf(cg, dch, p.S);
         // The geometry sums are kept in raw-moment form, u = opacity G dL/dalpha (straight-through alpha cap):
         //   v0 = sum u dx, v1 = sum u dy, v2 = sum u dx^2, v3 = sum u dx dy, v4 = sum u dy^2, v5 = sum u;
         // the per-Gaussian factors (opacity, conic, viewport scale, -1/2) are applied once per Gaussian by
@@ -292,11 +290,10 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
         const float Tf = inside ? final_T[pix] : 0.0f;
         p[k].pxf = (float)px, p[k].pyf = (float)py;
         p[k].T = Tf;
-        p[k].behind_g = 0.0f, p[k].last_cg = 0.0f, p[k].last_alpha = 0.0f;
         p[k].g0 = inside ? dL_dpix[pix] : 0.0f;
         p[k].g1 = inside ? dL_dpix[HW + pix] : 0.0f;
         p[k].g2 = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-        p[k].neg_Tf_bg = -Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
+        p[k].S = Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
         p[k].last_contributor = inside ? n_contrib[pix] : 0u;
         wmax = max(wmax, p[k].last_contributor);
     }

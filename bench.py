@@ -184,11 +184,13 @@ def main():
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs of this same
     # command; collected and corrected as MI355X_MICROARCH.md prescribes) -- only for the workload they were taken on
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")))
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]  # named per round: r1f < r1h < r2a
+        pmc = json.load(open(newest))
         wl = pmc["workload"]
         if (wl["gaussians"], wl["height"], wl["width"], wl["sh_degree"]) == (P, H, W, D):
             out["roofline"]["traffic"] = pmc["kernels"][dominant + "_kernel"]["hbm_bytes_corrected"]
-            out["roofline"]["traffic_source"] = "profiles/r1f_pmc_traffic.json"
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(newest)
     except Exception:
         pass
 

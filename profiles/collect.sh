@@ -1,0 +1,29 @@
+#!/bin/bash
+# One gpurun call that refreshes everything under profiles/ for a round tag:
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r1h'
+# kernel-trace/stats and each PMC set are separate rocprofv3 runs (never --pmc together with other trace domains).
+set -u
+TAG=${1:?tag}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o $TAG -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline \
+    > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/trace.err"
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"; do
+    name=$(echo $set | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_$name" -o p -- python3 bench.py --steps 5 --warmup 2 \
+        --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err"
+done
+python3 profiles/summarize_rocprof.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_kernel_stats.txt"
+python3 profiles/timeline_gaps.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_timeline.txt"
+F=$(find "$OUT/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
+Wc=$(find "$OUT/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
+python3 profiles/pmc_traffic.py "$F" "$Wc" $TAG 200000 1080 1920 3 > "$OUT/${TAG}_pmc_traffic.json"
+python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
+python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
+find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete
+ls -la "$OUT"
+cat "$OUT/${TAG}_timeline.txt"

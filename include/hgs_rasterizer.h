@@ -141,6 +141,20 @@ int32_t hgs_densification_stats(int32_t n, const float *viewspace_grad, const in
                                 const uint8_t *visibility_filter, float *max_radii2D, float *xyz_gradient_accum,
                                 float *denom, void *stream);
 
+/* SURVEY.md 8f row f-2 -- the K nearest template vertices of every query point: replaces pytorch3d.ops.knn_points for
+ * batch size 1 as called at /root/reference/hugs/models/hugs_wo_trimlp.py:60,99 (points [n,3], template_points [m,3],
+ * 1 <= K <= 8, K <= m).  dists [n,K] = squared L2 distances in ascending order, idx [n,K] int64; equal distances keep
+ * the lower template index first.  template_points must be 16-byte aligned. */
+int32_t hgs_knn_points(int32_t n, const float *points, int32_t m, const float *template_points, int32_t K,
+                       float *dists, int64_t *idx, void *stream);
+
+/* Replaces smpl_lbsweight_top_k (hugs_wo_trimlp.py:88-119; called on every training step at hugs_trimlp.py:318,480)
+ * for batch size 1, search and blending fused: lbs_weights [m,J] (J = 24 for SMPL), out_dist [n] (xyz_dist),
+ * out_weights [n,J] (the K-neighbour blend of the template's LBS weights, confidence-gated as upstream). */
+int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, const float *template_points,
+                                 const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
+                                 void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

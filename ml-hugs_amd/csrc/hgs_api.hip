@@ -22,6 +22,13 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+}  // namespace
+
+// for the other translation units (densify.hip, knn.hip): message behind hgs_last_error() on this thread
+void hgs::set_last_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+
+namespace {
+
 #define HIP_TRY(expr)                                                                                    \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \

@@ -90,6 +90,8 @@ struct BinningLayout {
 };
 
 // kernels / launchers (defined in the .hip files)
+void set_last_error(const char* msg);  // hgs_api.hip
+
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
                        uint32_t* tile_count, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);

@@ -241,6 +241,51 @@ def main():
                                                                                  state.xyz_gradient_accum.numpy().copy(),
                                                                                  state.denom.numpy().copy())
 
+    # ---- SMPL neighbour-blended LBS quantities: the reference's own statements, executed ----
+    # hugs/models/hugs_wo_trimlp.py:39-44 (batch_index_select), :47-85 (smpl_lbsmap_top_k), :88-119 (smpl_lbsweight_top_k),
+    # compiled from the source file (the module imports pytorch3d, smplx, trimesh ...).  pytorch3d.ops.knn_points is a
+    # pip dependency that is not in /root/reference: the functions are fed oracle/knn_oracle.py's restatement of its
+    # contract, so these vectors pin every statement AFTER the search (and the search's inputs/outputs are recorded).
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), "..", ".."))
+    from oracle import knn_oracle
+
+    def _function_from_source(path, name, ns):
+        tree = ast.parse(open(path).read())
+        node = next(f for f in tree.body if isinstance(f, ast.FunctionDef) and f.name == name)
+        exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        return ns[name]
+
+    def _knn_points(p1, p2, K=1):
+        d, i = knn_oracle.knn_points(p1[0].numpy(), p2[0].numpy(), K)
+        return types.SimpleNamespace(dists=torch.from_numpy(d)[None], idx=torch.from_numpy(i)[None])
+
+    kns = {"torch": torch, "knn_points": _knn_points}
+    src = os.path.join(REF, "hugs/models/hugs_wo_trimlp.py")
+    _function_from_source(src, "batch_index_select", kns)
+    ref_lbsmap = _function_from_source(src, "smpl_lbsmap_top_k", kns)
+    ref_lbsweight = _function_from_source(src, "smpl_lbsweight_top_k", kns)
+    kr = np.random.default_rng(11)
+    m, npts, J = 400, 250, 24
+    templ = (kr.standard_normal((m, 3)) * np.array([0.25, 0.6, 0.15])).astype(np.float32)       # a body-shaped blob
+    joints = templ[kr.choice(m, J, replace=False)]
+    logits = -np.linalg.norm(templ[:, None, :] - joints[None], axis=-1) / 0.01                   # SMPL-like: near one-hot inside a part
+    lbsw = np.exp(logits - logits.max(1, keepdims=True))
+    lbsw = (lbsw / lbsw.sum(1, keepdims=True)).astype(np.float32)
+    pts = (templ[kr.integers(0, m, npts)] + 0.02 * kr.standard_normal((npts, 3))).astype(np.float32)
+    pts[:5] = templ[:5]                                                                          # exact hits: distance 0
+    vT = np.tile(np.eye(4, dtype=np.float32), (m, 1, 1))
+    vT[:, :3, :] += 0.1 * kr.standard_normal((m, 3, 4)).astype(np.float32)
+    info = kr.standard_normal((m, 3)).astype(np.float32)
+    kd, ki = knn_oracle.knn_points(pts, templ, 6)
+    with torch.no_grad():
+        d1, w1 = ref_lbsweight(torch.from_numpy(lbsw), torch.from_numpy(pts)[None], torch.from_numpy(templ)[None])
+        d2, T2, i2 = ref_lbsmap(torch.from_numpy(lbsw), torch.from_numpy(vT)[None], torch.from_numpy(pts)[None],
+                                torch.from_numpy(templ)[None], K=6, addition_info=torch.from_numpy(info)[None])
+    out.update(knn_template=templ, knn_points=pts, knn_lbs_weights=lbsw, knn_verts_transform=vT, knn_addition_info=info,
+               knn_search_dists=kd, knn_search_idx=ki,
+               knn_lbsweight_dist=d1[0].numpy(), knn_lbsweight_weights=w1[0].numpy(),
+               knn_lbsmap_dist=d2[0].numpy(), knn_lbsmap_transform=T2[0].numpy(), knn_lbsmap_info=i2[0].numpy())
+
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT) / 1024:.1f} KiB")
 

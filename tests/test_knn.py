@@ -1,0 +1,124 @@
+"""SURVEY.md 8f row f-2 -- K nearest template vertices + the SMPL neighbour-blended LBS quantities.
+CPU: the numpy oracle against vectors produced by the reference's own statements (hugs_wo_trimlp.py:47-119, compiled
+from /root/reference by tests/golden/make_golden.py; the pytorch3d search itself is absent from the reference, so the
+search is pinned only by its published contract -- brute force, checked here independently in float64).
+GPU: the HIP kernels (through the C ABI and the drop-in Python functions) against the oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_oracle as ko
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_substeps.npz"))
+FLOAT_TOL = 2e-6   # relative, on fp32 sums of <= 6 products (order of summation differs between torch, numpy and the kernel)
+
+
+def body(n, m, J, seed):
+    r = np.random.default_rng(seed)
+    templ = (r.standard_normal((m, 3)) * np.array([0.25, 0.6, 0.15])).astype(np.float32)
+    joints = templ[r.choice(m, J, replace=False)]
+    logits = -np.linalg.norm(templ[:, None, :] - joints[None], axis=-1) / 0.01
+    w = np.exp(logits - logits.max(1, keepdims=True))
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    pts = (templ[r.integers(0, m, n)] + 0.02 * r.standard_normal((n, 3))).astype(np.float32)
+    return templ, w, pts
+
+
+def test_oracle_search_is_the_brute_force_k_smallest():
+    templ, _, pts = body(300, 500, 24, 1)
+    pts[:7] = templ[:7]                                   # exact hits
+    templ[100] = templ[3]                                 # a duplicated template vertex: a genuine tie
+    d, i = ko.knn_points(pts, templ, 6)
+    d64 = ((pts[:, None, :].astype(np.float64) - templ[None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.sort(d64, axis=1)[:, :6]
+    np.testing.assert_allclose(d, ref, rtol=1e-5, atol=1e-12)
+    assert (np.diff(d, axis=1) >= 0).all() and d[3, 0] == 0 and d[3, 1] == 0
+    assert i[3, 0] == 3 and i[3, 1] == 100                # tie -> lower index first
+    assert np.array_equal(np.take_along_axis(((pts[:, None] - templ[None]) ** 2).astype(np.float32).sum(-1) * 0 +
+                                             ((pts[:, None, 0] - templ[None, :, 0]) ** 2 + (pts[:, None, 1] - templ[None, :, 1]) ** 2 +
+                                              (pts[:, None, 2] - templ[None, :, 2]) ** 2), i, axis=1), d)
+
+
+def test_oracle_matches_reference_statements():
+    d, i = ko.knn_points(G["knn_points"], G["knn_template"], 6)
+    assert np.array_equal(d, G["knn_search_dists"]) and np.array_equal(i, G["knn_search_idx"])
+    xd, w = ko.smpl_lbsweight_top_k(G["knn_lbs_weights"], G["knn_points"], G["knn_template"], K=6)
+    np.testing.assert_allclose(xd, G["knn_lbsweight_dist"], rtol=FLOAT_TOL, atol=1e-9)
+    np.testing.assert_allclose(w, G["knn_lbsweight_weights"], rtol=FLOAT_TOL, atol=1e-8)
+    xd2, T, info = ko.smpl_lbsmap_top_k(G["knn_lbs_weights"], G["knn_verts_transform"], G["knn_points"], G["knn_template"],
+                                        K=6, addition_info=G["knn_addition_info"])
+    np.testing.assert_allclose(xd2, G["knn_lbsmap_dist"], rtol=FLOAT_TOL, atol=1e-9)
+    np.testing.assert_allclose(T, G["knn_lbsmap_transform"], rtol=FLOAT_TOL, atol=1e-7)
+    np.testing.assert_allclose(info, G["knn_lbsmap_info"], rtol=FLOAT_TOL, atol=1e-7)
+    # the fixture exercises the confidence gate both ways, and the blended weights still sum to one
+    nb = G["knn_lbs_weights"][i]
+    conf = np.exp(-np.abs(nb - nb[:, :1]).sum(-1) / 0.02) > 0.9
+    assert conf[:, 0].all() and 0.05 < conf[:, 1:].mean() < 0.95
+    np.testing.assert_allclose(w.sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_vectors(device):
+    from hugs_amd.knn import knn_points, smpl_lbsmap_top_k, smpl_lbsweight_top_k
+    t = lambda k: torch.from_numpy(G[k].copy()).to(device)
+    res = knn_points(t("knn_points")[None], t("knn_template")[None], K=6)
+    assert res.dists.shape == (1, 250, 6) and res.idx.dtype == torch.int64 and res.knn is None
+    assert np.array_equal(res.dists[0].cpu().numpy(), G["knn_search_dists"])
+    assert np.array_equal(res.idx[0].cpu().numpy(), G["knn_search_idx"])
+    xd, w = smpl_lbsweight_top_k(t("knn_lbs_weights"), t("knn_points")[None], t("knn_template")[None])
+    np.testing.assert_allclose(xd[0].cpu().numpy(), G["knn_lbsweight_dist"], rtol=FLOAT_TOL, atol=1e-9)
+    np.testing.assert_allclose(w[0].cpu().numpy(), G["knn_lbsweight_weights"], rtol=FLOAT_TOL, atol=1e-8)
+    vT = t("knn_verts_transform")[None].requires_grad_(True)
+    xd2, T, info = smpl_lbsmap_top_k(t("knn_lbs_weights"), vT, t("knn_points")[None], t("knn_template")[None], K=6,
+                                     addition_info=t("knn_addition_info")[None])
+    np.testing.assert_allclose(xd2[0].cpu().numpy(), G["knn_lbsmap_dist"], rtol=FLOAT_TOL, atol=1e-9)
+    np.testing.assert_allclose(T[0].detach().cpu().numpy(), G["knn_lbsmap_transform"], rtol=FLOAT_TOL, atol=1e-7)
+    np.testing.assert_allclose(info[0].cpu().numpy(), G["knn_lbsmap_info"], rtol=FLOAT_TOL, atol=1e-7)
+    T.sum().backward()                                   # gradients reach verts_transform as upstream
+    assert vT.grad is not None and float(vT.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,K", [(1, 8, 1), (63, 6, 6), (1000, 6890, 6), (4097, 1023, 8), (20011, 6890, 6), (300, 501, 3)])
+def test_hip_search_is_bit_exact_against_the_oracle(n, m, K, device):
+    from hugs_amd.knn import knn_points
+    templ, _, pts = body(n, m, min(24, m), seed=n + m)
+    if m > 200:
+        templ[m // 2] = templ[5]                          # tie
+        pts[0] = templ[5]
+    res = knn_points(torch.from_numpy(pts)[None].to(device), torch.from_numpy(templ)[None].to(device), K=K, return_nn=True)
+    d, i = ko.knn_points(pts, templ, K)
+    assert np.array_equal(res.idx[0].cpu().numpy(), i)
+    assert np.array_equal(res.dists[0].cpu().numpy().view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(res.knn[0].cpu().numpy(), templ[i])
+
+
+@pytest.mark.gpu
+def test_hip_lbsweight_full_size_against_the_oracle(device):
+    """SMPL-sized template (6 890 vertices, 24 joints), 50k Gaussians: the shape of hugs_trimlp.py:480-484."""
+    from hugs_amd.knn import smpl_lbsweight_top_k
+    templ, w, pts = body(50_000, 6890, 24, seed=5)
+    xd, out = smpl_lbsweight_top_k(torch.from_numpy(w).to(device), torch.from_numpy(pts)[None].to(device),
+                                   torch.from_numpy(templ)[None].to(device))
+    rd, rw = ko.smpl_lbsweight_top_k(w, pts, templ, K=6)
+    # a neighbour whose confidence exp(.) sits within rounding of the 0.9 threshold may flip: allow a handful of rows
+    bad = (np.abs(out[0].cpu().numpy() - rw) > FLOAT_TOL * np.maximum(np.abs(rw), 1e-3)).any(-1)
+    assert bad.sum() <= 3, f"{bad.sum()} of {len(bad)} rows differ"
+    good = ~bad
+    np.testing.assert_allclose(xd[0].cpu().numpy()[good], rd[good], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(out[0].sum(-1).cpu().numpy(), 1.0, atol=1e-5)   # hugs_trimlp.py:486-489's sanity check
+
+
+@pytest.mark.gpu
+def test_hip_knn_errors(device):
+    from hugs_amd.knn import knn_points
+    p = torch.zeros(1, 4, 3, device=device)
+    with pytest.raises(RuntimeError):
+        knn_points(p, torch.zeros(1, 3, 3, device=device), K=6)        # fewer template points than K
+    with pytest.raises(RuntimeError):
+        knn_points(p, torch.zeros(1, 30, 3, device=device), K=9)       # K beyond the compiled range
+    with pytest.raises(RuntimeError):
+        knn_points(torch.zeros(1, 4, 3), torch.zeros(1, 30, 3), K=2)   # CPU tensors: no fallback
+    assert knn_points(torch.zeros(1, 0, 3, device=device), torch.zeros(1, 30, 3, device=device), K=2).idx.shape == (1, 0, 2)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Measurement for SURVEY.md 8f row f-2 on one MI355X: smpl_lbsweight_top_k / knn_points at the shape the reference runs
+every training step (hugs_trimlp.py:480-484: N_gs Gaussians x 6 890 SMPL vertices, K = 6), HIP events on the launch
+stream.  Prints one JSON line.  The kernel is VALU-bound (n*m distance evaluations, 9 fp32 ops each); the figure of
+merit is distance evaluations per second.   python tools/bench_knn.py [--points 110000] [--iters 20]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=110_000)
+    ap.add_argument("--verts", type=int, default=6890)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--cpu-points", type=int, default=2000)
+    a = ap.parse_args()
+    from hugs_amd.knn import knn_points, smpl_lbsweight_top_k
+    from oracle import knn_oracle as ko
+    r = np.random.default_rng(0)
+    templ = (r.standard_normal((a.verts, 3)) * np.array([0.25, 0.6, 0.15])).astype(np.float32)
+    w = r.random((a.verts, 24)).astype(np.float32)
+    w /= w.sum(1, keepdims=True)
+    pts = (templ[r.integers(0, a.verts, a.points)] + 0.02 * r.standard_normal((a.points, 3))).astype(np.float32)
+    dev = torch.device("cuda:0")
+    tp, tt, tw = torch.from_numpy(pts)[None].to(dev), torch.from_numpy(templ)[None].to(dev), torch.from_numpy(w).to(dev)
+    out = {}
+    for name, fn in (("smpl_lbsweight_top_k", lambda: smpl_lbsweight_top_k(tw, tp, tt)), ("knn_points", lambda: knn_points(tp, tt, K=6))):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        out[name] = {"ms": round(ms, 4), "distance_evals_per_s": round(a.points * a.verts / (ms * 1e-3), 1)}
+    t0 = time.perf_counter()
+    ko.smpl_lbsweight_top_k(w, pts[:a.cpu_points], templ)
+    cpu_s = time.perf_counter() - t0
+    out["cpu_oracle"] = {"points": a.cpu_points, "s": round(cpu_s, 3),
+                         "distance_evals_per_s": round(a.cpu_points * a.verts / cpu_s, 1), "kind": "port (numpy)"}
+    print(json.dumps({"workload": f"{a.points} points x {a.verts} template vertices, K=6, J=24", **out}))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,11 +6,13 @@
 // pytorch3d is not in /root/reference (pip dependency); its published contract is restated: squared L2 distances,
 // the K smallest per query in ascending order, int64 indices.  Ties go to the lower template index (oracle/knn_oracle.py).
 //
-// Shape of the problem: n ~ 1e5 queries x m = 6 890 template vertices, K = 6: brute force, 1 query per lane.  The
-// template vertex of an iteration is the same for every lane, so it is fetched through the scalar cache
-// (s_load_dwordx4, 4 vertices per 3 loads) and used as the scalar operand of the VALU math -- no LDS, no barrier.  A
-// lane keeps its K best (distance, index) pairs sorted in registers; the insertion code runs under the exec mask of
-// the few lanes that found a closer vertex (after the first few hundred vertices most iterations skip it).
+// Shape of the problem: n ~ 1e5 queries x m = 6 890 template vertices, K = 6: brute force.  A workgroup owns 64 queries
+// (one per lane) and its four waves each scan a quarter of the template -- n/64 waves would leave most SIMDs with one or
+// two waves and nothing to hide latency with.  The template vertex of an iteration is the same for every lane of a
+// wave, so it is fetched through the scalar cache (s_load_dwordx4, 4 vertices per 3 loads) and used as the scalar
+// operand of the VALU math.  A lane keeps its K best (distance, index) pairs sorted in registers; the insertion code
+// runs under the exec mask of the few lanes that found a closer vertex.  The four partial lists meet in LDS and wave 0
+// merges them in segment order, which preserves the tie rule.
 #include <cstdio>
 
 #include "hgs_common.h"
@@ -53,38 +55,71 @@ __device__ __forceinline__ float sqdist(float px, float py, float pz, float tx, 
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+constexpr int KNN_SPLIT = 4;  // waves per workgroup = template segments
+
+// scans template vertices [j0, j1), j0 a multiple of 4
 template <int K>
-__device__ __forceinline__ void scan_template(float px, float py, float pz, const float* __restrict__ templ, int m, Best<K>& best)
+__device__ __forceinline__ void scan_template(float px, float py, float pz, const float* __restrict__ templ, int j0, int j1,
+                                              Best<K>& best)
 {
     best.init();
-    const int m4 = m & ~3;
-    for (int j = 0; j < m4; j += 4) {  // 4 vertices = 12 floats = three aligned 16-byte scalar loads
+    const int j4 = j0 + ((j1 - j0) & ~3);
+    for (int j = j0; j < j4; j += 4) {  // 4 vertices = 12 floats = three aligned 16-byte scalar loads
         const_f4p q = (const_f4p)(templ + 3 * (size_t)j);
         const v4f a = q[0], b = q[1], c = q[2];
-        best.offer(sqdist(px, py, pz, a.x, a.y, a.z), j);
-        best.offer(sqdist(px, py, pz, a.w, b.x, b.y), j + 1);
-        best.offer(sqdist(px, py, pz, b.z, b.w, c.x), j + 2);
-        best.offer(sqdist(px, py, pz, c.y, c.z, c.w), j + 3);
+        // four independent distance chains and one wave-level test for "nobody improves", the usual case
+        const float d0 = sqdist(px, py, pz, a.x, a.y, a.z), d1 = sqdist(px, py, pz, a.w, b.x, b.y);
+        const float d2 = sqdist(px, py, pz, b.z, b.w, c.x), d3 = sqdist(px, py, pz, c.y, c.z, c.w);
+        const float dmin = fminf(fminf(d0, d1), fminf(d2, d3));
+        if (__builtin_amdgcn_ballot_w64(dmin < best.d[K - 1]) == 0ull) continue;
+        best.offer(d0, j);
+        best.offer(d1, j + 1);
+        best.offer(d2, j + 2);
+        best.offer(d3, j + 3);
     }
-    for (int j = m4; j < m; ++j) {
+    for (int j = j4; j < j1; ++j) {
         const_f32p q = (const_f32p)(templ + 3 * (size_t)j);
         best.offer(sqdist(px, py, pz, q[0], q[1], q[2]), j);
     }
 }
 
+// The workgroup's search: returns (in wave 0 only, `true`) the K nearest template vertices of point blockIdx.x*64+lane.
 template <int K>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ bool workgroup_knn(int n, const float* __restrict__ points, int m, const float* __restrict__ templ,
+                                              Best<K>& best, int& point)
+{
+    __shared__ float sh_d[KNN_SPLIT - 1][K][64];
+    __shared__ int sh_i[KNN_SPLIT - 1][K][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    point = blockIdx.x * 64 + lane;
+    const int pc = point < n ? point : n - 1;  // every lane scans (wave-uniform loads); only valid lanes store
+    const int seg = (((m + KNN_SPLIT - 1) / KNN_SPLIT) + 3) & ~3;
+    const int j0 = min(w * seg, m), j1 = min(j0 + seg, m);
+    scan_template<K>(points[3 * (size_t)pc], points[3 * (size_t)pc + 1], points[3 * (size_t)pc + 2], templ, j0, j1, best);
+    if (w > 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sh_d[w - 1][k][lane] = best.d[k], sh_i[w - 1][k][lane] = best.i[k];
+    }
+    __syncthreads();
+    if (w > 0) return false;
+    // segments in index order, each list ascending: an equal distance from a later segment stays behind (tie rule)
+#pragma unroll
+    for (int q = 0; q < KNN_SPLIT - 1; ++q)
+#pragma unroll
+        for (int k = 0; k < K; ++k) best.offer(sh_d[q][k][lane], sh_i[q][k][lane]);
+    return true;
+}
+
+template <int K>
+__global__ void __launch_bounds__(64 * KNN_SPLIT)
 knn_kernel(int n, const float* __restrict__ points, int m, const float* __restrict__ templ, float* __restrict__ dists,
            int64_t* __restrict__ idx)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ic = i < n ? i : n - 1;  // every lane scans (wave-uniform loads); only valid lanes store
     Best<K> best;
-    scan_template<K>(points[3 * (size_t)ic], points[3 * (size_t)ic + 1], points[3 * (size_t)ic + 2], templ, m, best);
-    if (i < n) {
+    int i;
+    if (!workgroup_knn<K>(n, points, m, templ, best, i) || i >= n) return;
 #pragma unroll
-        for (int k = 0; k < K; ++k) dists[(size_t)i * K + k] = best.d[k], idx[(size_t)i * K + k] = (int64_t)best.i[k];
-    }
+    for (int k = 0; k < K; ++k) dists[(size_t)i * K + k] = best.d[k], idx[(size_t)i * K + k] = (int64_t)best.i[k];
 }
 
 // smpl_lbsweight_top_k fused behind the search (hugs_wo_trimlp.py:101-119):
@@ -92,16 +127,14 @@ knn_kernel(int n, const float* __restrict__ points, int m, const float* __restri
 //   wgt_k  = exp(-dist_k) * conf_k;  wgt_k /= sum_k wgt_k
 //   out_weights[j] = sum_k wgt_k * w[idx_k][j];  out_dist = sum_k wgt_k * dist_k
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * KNN_SPLIT)
 lbsweight_top_k_kernel(int n, const float* __restrict__ points, int m, const float* __restrict__ templ,
                        const float* __restrict__ lbs_weights, int J, float* __restrict__ out_dist,
                        float* __restrict__ out_weights)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ic = i < n ? i : n - 1;
     Best<K> best;
-    scan_template<K>(points[3 * (size_t)ic], points[3 * (size_t)ic + 1], points[3 * (size_t)ic + 2], templ, m, best);
-    if (i >= n) return;
+    int i;
+    if (!workgroup_knn<K>(n, points, m, templ, best, i) || i >= n) return;
     const float weight_std2 = (float)(2.0 * 0.1 * 0.1);
     const float* w0 = lbs_weights + (size_t)best.i[0] * J;
     float wgt[K], sum = 0.0f;
@@ -155,7 +188,7 @@ template <int K>
 struct LaunchKnn {
     static int go(int n, const float* p, int m, const float* t, float* d, int64_t* idx, hipStream_t st)
     {
-        hipLaunchKernelGGL(knn_kernel<K>, dim3((n + 255) / 256), dim3(256), 0, st, n, p, m, t, d, idx);
+        hipLaunchKernelGGL(knn_kernel<K>, dim3((n + 63) / 64), dim3(64 * KNN_SPLIT), 0, st, n, p, m, t, d, idx);
         return HGS_OK;
     }
 };
@@ -163,7 +196,7 @@ template <int K>
 struct LaunchLbs {
     static int go(int n, const float* p, int m, const float* t, const float* w, int J, float* od, float* ow, hipStream_t st)
     {
-        hipLaunchKernelGGL(lbsweight_top_k_kernel<K>, dim3((n + 255) / 256), dim3(256), 0, st, n, p, m, t, w, J, od, ow);
+        hipLaunchKernelGGL(lbsweight_top_k_kernel<K>, dim3((n + 63) / 64), dim3(64 * KNN_SPLIT), 0, st, n, p, m, t, w, J, od, ow);
         return HGS_OK;
     }
 };

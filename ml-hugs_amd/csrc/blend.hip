@@ -222,10 +222,12 @@ struct PixBwd {
 // Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9] and raises
 // the lane's `contributed` flag.  The body is one exec-masked region: a quad none of whose pixels takes the splat
 // costs the alpha evaluation and a branch.
-__device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float (&v)[9], uint32_t& contributed)
+// (dy, bdy = B dy, q = C dy^2 + L: the row terms of log2_alpha, shared by the two quads of a tile row)
+__device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float dy, float bdy, float q,
+                                          float (&v)[9], uint32_t& contributed)
 {
-    const float dx = s.x - p.pxf, dy = s.y - p.pyf;
-    const float e = log2_alpha(s, dx, dy);
+    const float dx = s.x - p.pxf;
+    const float e = __builtin_fmaf(dx, __builtin_fmaf(s.A, dx, bdy), q);  // == log2_alpha(s, dx, dy), same rounding
     const float alpha_uncapped = __builtin_amdgcn_exp2f(e);  // = opacity * G
     const float alpha = fminf(ALPHA_MAX, alpha_uncapped);
     const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
@@ -319,8 +321,12 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         uint32_t contributed = 0u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((val >> (GID_BITS + k)) & 1u) bwd_pixel(s, pos1, p[k], v, contributed);
+        for (int r = 0; r < 2; ++r) {
+            if (((val >> (GID_BITS + 2 * r)) & 3u) == 0u) continue;
+            const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
+            if ((val >> (GID_BITS + 2 * r)) & 1u) bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v, contributed);
+            if ((val >> (GID_BITS + 2 * r + 1)) & 1u) bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v, contributed);
+        }
         if (__builtin_amdgcn_ballot_w64(contributed != 0u) == 0ull) return;
         // ---- transpose-reduce of v0..v7 over the wave: each step adds partner lanes AND halves the number of live
         // registers.  Lane-half and row exchanges are gfx950's v_permlane{32,16}_swap (no select needed: the swap

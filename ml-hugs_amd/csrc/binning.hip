@@ -330,49 +330,122 @@ __device__ __forceinline__ uint64_t list_entry(uint64_t key, uint32_t pos1)
 
 // Small tiles (n <= 1024, i.e. practically all of them): the bitonic network runs in REGISTERS.  Thread t holds
 // elements i = e * 256 + t (e < E = m / 256).  A compare-exchange distance j >= 256 pairs two registers of the
-// same thread, j < 64 pairs two lanes of a wave (ds_bpermute shuffles, no barrier), and only j = 64 / 128 go
-// through LDS with barriers -- 3 of the 36 steps at m = 256.
+// same thread; j = 64 / 128 go through LDS with barriers (3 of the 36 steps at m = 256); j < 64 pairs two lanes of a
+// wave: DPP moves for j = 1, 2 (quad_perm), 4 (row_shl:4 / row_shr:4 into complementary banks), 8 (row_ror:8),
+// ds_bpermute with precomputed addresses for 16 and 32.
+// The kernel is instruction-issue bound, so a step is kept to: fetch partner, ONE 64-bit compare, two selects.
+// Which of the pair a lane keeps depends only on (lane bit j) == (element bit k), a compile-time lane pattern or a
+// wave-uniform value: it lives in an SGPR pair, is combined with the compare's lane mask by s_xnor on the scalar
+// unit, and drives VOP3 selects directly.
+__device__ __forceinline__ uint32_t select32(unsigned long long m, uint32_t if_set, uint32_t if_clear)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp32(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK_MASK, false);
+}
+// the key held by lane ^ J (J < 64); every lane of the wave must be active
+template <uint32_t J>
+__device__ __forceinline__ uint64_t partner_key(uint64_t key, uint32_t addr16, uint32_t addr32)
+{
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t plo, phi;
+    if constexpr (J == 1) plo = dpp32<0xB1>(lo, lo), phi = dpp32<0xB1>(hi, hi);           // quad_perm:[1,0,3,2]
+    else if constexpr (J == 2) plo = dpp32<0x4E>(lo, lo), phi = dpp32<0x4E>(hi, hi);      // quad_perm:[2,3,0,1]
+    else if constexpr (J == 4) {
+        // banks 0,2 of each row read lane+4 (row_shl:4), banks 1,3 read lane-4 (row_shr:4)
+        plo = dpp32<0x114, 0xA>(dpp32<0x104, 0x5>(lo, lo), lo);
+        phi = dpp32<0x114, 0xA>(dpp32<0x104, 0x5>(hi, hi), hi);
+    } else if constexpr (J == 8) plo = dpp32<0x128>(lo, lo), phi = dpp32<0x128>(hi, hi);  // row_ror:8
+    else {
+        const uint32_t addr = J == 16 ? addr16 : addr32;
+        plo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)lo);
+        phi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)hi);
+    }
+    return ((uint64_t)phi << 32) | plo;
+}
+// lanes whose index has bit J set
+template <uint32_t J>
+constexpr unsigned long long lane_bit_pattern()
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (l & J) m |= 1ull << l;
+    return m;
+}
+// one compare-exchange of a lane's key with its partner's: keep_min_mask = lanes that keep the smaller key
+__device__ __forceinline__ uint64_t keep_one(uint64_t a, uint64_t b, unsigned long long keep_min_mask)
+{
+    const unsigned long long lt = __builtin_amdgcn_uicmpl(a, b, 36);  // a < b (unsigned)
+    const unsigned long long take_a = ~(lt ^ keep_min_mask);
+    return ((uint64_t)select32(take_a, (uint32_t)(a >> 32), (uint32_t)(b >> 32)) << 32) |
+           select32(take_a, (uint32_t)a, (uint32_t)b);
+}
+
+template <int E, uint32_t K, uint32_t J>
+__device__ __forceinline__ void bitonic_step(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
+{
+    const uint32_t tid = threadIdx.x;
+    if constexpr (J >= 256u) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int f = e | (int)(J >> 8);
+            if (f != e && f < E) {
+                const bool asc = (((uint32_t)e * 256u + tid) & K) == 0u;
+                const uint64_t a = key[e], b = key[f];
+                if ((a > b) == asc) key[e] = b, key[f] = a;
+            }
+        }
+    } else if constexpr (J >= 64u) {
+        uint64_t other[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) sh[e * 256 + tid] = key[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) other[e] = sh[e * 256 + (tid ^ J)];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = (uint32_t)e * 256u + tid;
+            // bits J and K of i are both wave-uniform here (J, K >= 64)
+            const bool keep_min = ((i & J) == 0u) == ((i & K) == 0u);
+            key[e] = keep_one(key[e], other[e], __builtin_amdgcn_readfirstlane(keep_min) ? ~0ull : 0ull);
+        }
+    } else {
+        constexpr unsigned long long PJ = lane_bit_pattern<J>();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            unsigned long long pk;  // lanes whose element index has bit K set
+            if constexpr (K < 64u) pk = lane_bit_pattern<K>();
+            else pk = __builtin_amdgcn_readfirstlane((((uint32_t)e * 256u + tid) & K) != 0u) ? ~0ull : 0ull;
+            const unsigned long long keep_min = ~(PJ ^ pk);  // bit J == bit K
+            key[e] = keep_one(key[e], partner_key<J>(key[e], addr16, addr32), keep_min);
+        }
+    }
+}
+
+template <int E, uint32_t K, uint32_t J>
+__device__ __forceinline__ void bitonic_merge(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
+{
+    bitonic_step<E, K, J>(key, sh, addr16, addr32);
+    if constexpr (J > 1u) bitonic_merge<E, K, (J >> 1)>(key, sh, addr16, addr32);
+}
+template <int E, uint32_t K>
+__device__ __forceinline__ void bitonic_phases(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
+{
+    if constexpr (K > 2u) bitonic_phases<E, (K >> 1)>(key, sh, addr16, addr32);
+    bitonic_merge<E, K, (K >> 1)>(key, sh, addr16, addr32);
+}
+
 template <int E>
 __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_t* sh)
 {
-    const uint32_t tid = threadIdx.x;
-#pragma unroll
-    for (uint32_t k = 2; k <= 256u * E; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 256u) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int f = e | (int)(j >> 8);
-                    if (f != e && f < E) {
-                        const bool asc = (((uint32_t)e * 256u + tid) & k) == 0u;
-                        const uint64_t a = key[e], b = key[f];
-                        if ((a > b) == asc) key[e] = b, key[f] = a;
-                    }
-                }
-            } else {
-                uint64_t other[E];
-                if (j >= 64u) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) sh[e * 256 + tid] = key[e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < E; ++e) other[e] = sh[e * 256 + (tid ^ j)];
-                    __syncthreads();
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) other[e] = __shfl_xor((unsigned long long)key[e], (int)j, 64);
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t i = (uint32_t)e * 256u + tid;
-                    const bool want_min = ((i & j) == 0u) == ((i & k) == 0u);
-                    const uint64_t a = key[e], b = other[e];
-                    key[e] = want_min ? (a < b ? a : b) : (a > b ? a : b);
-                }
-            }
-        }
-    }
+    const uint32_t lane = threadIdx.x & 63u;
+    bitonic_phases<E, 256u * E>(key, sh, (lane ^ 16u) << 2, (lane ^ 32u) << 2);
 }
 
 // Appends up to 256 consecutive sorted entries of a tile (one per thread, `valid` when it exists) to the tile's

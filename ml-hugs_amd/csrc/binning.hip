@@ -106,11 +106,7 @@ void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// emit: bucket scatter, wave-balanced, plus a per-entry quad coverage mask.
-//
-// A wave owns 64 consecutive Gaussians; their tile counts are prefix-summed in registers and the wave's
-// (Gaussian, tile) pairs are dealt to lanes 64 at a time (each pair finds its Gaussian by a 6-step search over
-// the wave's prefix sums), so a single huge splat no longer serialises one lane.
+// count / emit: bucket scatter plus a per-entry quad coverage mask.
 //
 // The value's top 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on
 // some pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never
@@ -120,7 +116,9 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
 {
     const float dxl = sx - (x0 + 7.0f), dxh = sx - x0, dyl = sy - (y0 + 7.0f), dyh = sy - y0;
     if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;  // centre inside the quad
-    const float hA = -0.5f / A, hC = -0.5f / C;  // vertex of the 1-D restriction: d* = -B d_other / (2 A|C)
+    // vertex of the 1-D restriction: d* = -B d_other / (2 A|C).  v_rcp_f32 (1 ulp) instead of an IEEE divide: an error
+    // eps in the vertex position lowers the value found by ~A eps^2, far inside the threshold's slack
+    const float hA = -0.5f * __builtin_amdgcn_rcpf(A), hC = -0.5f * __builtin_amdgcn_rcpf(C);
     float best = -3.0e38f;
     {
         float dy = fminf(dyh, fmaxf(dyl, B * dxl * hC));
@@ -135,27 +133,29 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
     return best;
 }
 
-// Both binning kernels below walk the (Gaussian, tile) pairs the same way.  A workgroup owns BIN_GROUP Gaussians;
-// wave w takes them 64 at a time, stages their rectangles in LDS, prefix-sums the tile counts in registers and
-// deals the pairs to lanes 64 at a time.  Atomics are aggregated per workgroup in an LDS array indexed by tile
-// and touch global memory once per (workgroup, tile) with coalesced vector atomics: scattered global atomics cost
-// ~15 G cache-line transactions/s on this chip, i.e. more than everything else in the binning phase together.
+// Both binning kernels below walk the (Gaussian, tile) pairs the same way.  A workgroup owns BIN_GROUP Gaussians, one
+// per thread, and a thread walks its own rectangle, record in registers (a typical splat touches 9-16 tiles, so the
+// lanes of a wave finish together) -- no staging, no cross-lane search.  A splat with more than BIN_SOLO_MAX tiles is
+// not walked by its lane: afterwards the wave takes such splats one at a time (record broadcast with v_readlane), 64
+// tiles per step, so one huge splat cannot serialise a lane.  Atomics are aggregated per workgroup in an LDS array
+// indexed by tile and touch global memory once per (workgroup, tile) with coalesced vector atomics: scattered global
+// atomics cost ~15 G cache-line transactions/s on this chip, more than everything else in the binning phase together.
 constexpr int BIN_GROUP = 1024;           // Gaussians per workgroup
-constexpr int BIN_THREADS = 1024;         // 16 waves: one 64-Gaussian group each
-constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to 48 KB of staging
+constexpr int BIN_THREADS = 1024;         // one Gaussian per thread
+constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to emit's 48 KB of staging
+constexpr uint32_t BIN_SOLO_MAX = 48;     // tiles a lane walks on its own
 
-struct PairStage {  // one wave's 64 staged Gaussians
-    float4 (*rec)[3];
-    uint32_t incl, total;
+struct SplatRect {  // what the walk needs of one Gaussian
+    float x, y, A, B, C, thr;  // centre, log2-domain half-conic, threshold on the exponent (emit only)
+    uint32_t depth_bits;
+    int minx, miny, width;
+    uint32_t cnt;  // tiles touched (0: culled)
 };
 
-__device__ __forceinline__ void stage_wave(int P, const Camera& cam, const Splat* __restrict__ splats, int g0,
-                                           bool with_mask_inputs, PairStage& st)
+__device__ __forceinline__ SplatRect load_rect(int P, const Camera& cam, const Splat* __restrict__ splats, int g, bool with_mask_inputs)
 {
-    const int lane = threadIdx.x & 63;
-    const int g = g0 + lane;
-    uint32_t cnt = 0;
-    float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = make_float4(-1.f, 3.0e38f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+    SplatRect r;
+    r.x = r.y = 0.f, r.A = r.C = -1.f, r.B = 0.f, r.thr = 3.0e38f, r.depth_bits = 0, r.minx = r.miny = 0, r.width = 1, r.cnt = 0;
     if (g < P) {
         const float4 tail = reinterpret_cast<const float4*>(splats + g)[2];
         const int radius = __float_as_int(tail.z);
@@ -167,29 +167,79 @@ __device__ __forceinline__ void stage_wave(int P, const Camera& cam, const Splat
             const int maxx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
             const int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
             const int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
-            cnt = (uint32_t)((maxx - minx) * (maxy - miny));
-            r0 = make_float4(px, py, head.z, head.w);
+            r.cnt = (uint32_t)((maxx - minx) * (maxy - miny));
+            r.x = px, r.y = py, r.A = head.z, r.B = head.w;
+            r.minx = minx, r.miny = miny, r.width = maxx - minx;
+            r.depth_bits = __float_as_uint(tail.y);
             if (with_mask_inputs) {
                 const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
+                r.C = mid.x;
                 // log2 domain (hgs_common.h): contributes iff exp2(power + L) >= 1/255  <=>  power >= -(log2 255 + L);
                 // 0.07 of slack covers the blend kernels' rounding (and makes the mask a strict superset)
-                const float thr = -(7.9943534f + mid.y) - 0.07f;
-                r1 = make_float4(mid.x, thr, tail.y, 0.f);  // C, threshold, depth
+                r.thr = -(7.9943534f + mid.y) - 0.07f;
             }
-            r2 = make_float4(__int_as_float(minx), __int_as_float(miny), __int_as_float(maxx - minx), 0.f);
         }
     }
-    st.incl = wave_inclusive_scan(cnt);
-    r1.w = __uint_as_float(st.incl - cnt);
-    __builtin_amdgcn_wave_barrier();  // the previous group's readers are done (same wave, in-order LDS)
-    st.rec[lane][0] = r0, st.rec[lane][1] = r1, st.rec[lane][2] = r2;
-    __builtin_amdgcn_wave_barrier();
-    st.total = (uint32_t)__shfl((int)st.incl, 63, 64);
+    return r;
 }
 
+// f(owner_lane, tx, ty, rect of the owner) for every tile of every rectangle held by the wave's lanes
+template <class F>
+__device__ __forceinline__ void for_each_pair(const SplatRect& mine, F&& f)
+{
+    const int lane = threadIdx.x & 63;
+    const bool big = mine.cnt > BIN_SOLO_MAX;
+    if (!big && mine.cnt) {
+        int tx = mine.minx, ty = mine.miny;
+        const int endx = mine.minx + mine.width;
+        for (uint32_t k = 0; k < mine.cnt; ++k) {
+            f(lane, tx, ty, mine);
+            if (++tx == endx) tx = mine.minx, ++ty;
+        }
+    }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
+    while (todo) {  // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        SplatRect r;
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), src));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), src));
+        r.A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.A), src));
+        r.B = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.B), src));
+        r.C = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.C), src));
+        r.thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.thr), src));
+        r.depth_bits = (uint32_t)__builtin_amdgcn_readlane((int)mine.depth_bits, src);
+        r.minx = __builtin_amdgcn_readlane(mine.minx, src);
+        r.miny = __builtin_amdgcn_readlane(mine.miny, src);
+        r.width = __builtin_amdgcn_readlane(mine.width, src);
+        r.cnt = (uint32_t)__builtin_amdgcn_readlane((int)mine.cnt, src);
+        for (uint32_t k = (uint32_t)lane; k < r.cnt; k += 64u) {
+            const uint32_t ry = k / (uint32_t)r.width, rx = k - ry * (uint32_t)r.width;
+            f(src, r.minx + (int)rx, r.miny + (int)ry, r);
+        }
+    }
+}
+
+// The same walk, evenly dealt: the wave's rectangles are staged in LDS, their tile counts prefix-summed, and the pairs
+// handed to lanes 64 at a time (each pair finds its owner by a 6-step search over the wave's prefix sums).  Worth its
+// staging and shuffles only when the body is heavy -- emit's coverage-mask computation -- where idle lanes would cost more.
+struct PairStage {  // one wave's 64 staged Gaussians
+    float4 (*rec)[3];
+    uint32_t incl, total;
+};
+__device__ __forceinline__ void stage_rects(const SplatRect& m, PairStage& st)
+{
+    const int lane = threadIdx.x & 63;
+    st.incl = wave_inclusive_scan(m.cnt);
+    st.rec[lane][0] = make_float4(m.x, m.y, m.A, m.B);
+    st.rec[lane][1] = make_float4(m.C, m.thr, __uint_as_float(m.depth_bits), __uint_as_float(st.incl - m.cnt));
+    st.rec[lane][2] = make_float4(__int_as_float(m.minx), __int_as_float(m.miny), __int_as_float(m.width), 0.f);
+    __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: the reads below see the writes above
+    st.total = (uint32_t)__shfl((int)st.incl, 63, 64);
+}
 // calls f(owner_lane, tx, ty, rec0, rec1) for every pair of the staged wave, 64 pairs per trip
 template <class F>
-__device__ __forceinline__ void for_each_pair(const PairStage& st, F&& f)
+__device__ __forceinline__ void for_each_pair_dealt(const PairStage& st, F&& f)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t s0 = 0; s0 < st.total; s0 += 64) {
@@ -217,21 +267,14 @@ __global__ void __launch_bounds__(BIN_THREADS)
 count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ tile_count)
 {
     extern __shared__ uint32_t hist[];
-    __shared__ float4 stage[BIN_THREADS / 64][64][3];
-    const int w = threadIdx.x >> 6, num_tiles = cam.gx * cam.gy;
+    const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : tile_count;
     if (USE_LDS) {
         for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
         __syncthreads();
     }
-    PairStage st;
-    st.rec = stage[w];
-    for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
-        const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
-        if (g0 >= P) break;
-        stage_wave(P, cam, splats, g0, false, st);
-        for_each_pair(st, [&](int, int tx, int ty, const float4&, const float4&) { atomicAdd(&bins[ty * cam.gx + tx], 1u); });
-    }
+    const SplatRect mine = load_rect(P, cam, splats, blockIdx.x * BIN_GROUP + threadIdx.x, false);
+    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&bins[ty * cam.gx + tx], 1u); });
     if (USE_LDS) {
         __syncthreads();
         for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) {
@@ -252,49 +295,52 @@ emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __res
 {
     if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     extern __shared__ uint32_t hist[];
-    __shared__ float4 stage[BIN_THREADS / 64][64][3];
-    const int w = threadIdx.x >> 6, num_tiles = cam.gx * cam.gy;
+    const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : cursor;
-    PairStage st;
-    st.rec = stage[w];
+    const int g0 = blockIdx.x * BIN_GROUP + (threadIdx.x & ~63);
+    const SplatRect mine = load_rect(P, cam, splats, g0 + (threadIdx.x & 63), true);
     if (USE_LDS) {
         // pass A: this workgroup's population of every tile; then ONE returning atomic per touched tile reserves
         // a contiguous run of the tile's segment, and bins[] becomes the workgroup-private cursor into it
         for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
         __syncthreads();
-        for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
-            const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
-            if (g0 >= P) break;
-            stage_wave(P, cam, splats, g0, false, st);
-            for_each_pair(st, [&](int, int tx, int ty, const float4&, const float4&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
-        }
+        for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
         __syncthreads();
-        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) {
-            const uint32_t c = hist[t];
-            if (c) hist[t] = atomicAdd(&cursor[t], c);
-        }
-        __syncthreads();
-    }
-    for (int grp = w; grp < BIN_GROUP / 64; grp += BIN_THREADS / 64) {
-        const int g0 = blockIdx.x * BIN_GROUP + grp * 64;
-        if (g0 >= P) break;
-        stage_wave(P, cam, splats, g0, true, st);
-        for_each_pair(st, [&](int lo, int tx, int ty, const float4& a, const float4& b) {
-            const float A = a.z, B = a.w, C = b.x, thr = b.y;
-            uint32_t mask = 0xFu;
-            if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
-                mask = 0;
-                const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+        // eight tiles per thread and round: the returning atomics of a round are all in flight together
+        for (int t0 = threadIdx.x; t0 < num_tiles; t0 += 8 * BIN_THREADS) {
+            uint32_t c[8], base[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
-                        mask |= 1u << q;
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * BIN_THREADS;
+                c[u] = t < num_tiles ? hist[t] : 0u;
             }
-            const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
-            // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
-            keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + lo) << 4) | mask);
-        });
+#pragma unroll
+            for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&cursor[t0 + u * BIN_THREADS], c[u]) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c[u]) hist[t0 + u * BIN_THREADS] = base[u];
+        }
+        __syncthreads();
     }
+    __shared__ float4 stage[BIN_THREADS / 64][64][3];
+    PairStage st;
+    st.rec = stage[threadIdx.x >> 6];
+    stage_rects(mine, st);
+    for_each_pair_dealt(st, [&](int owner, int tx, int ty, const float4& a, const float4& b) {
+        const float A = a.z, B = a.w, C = b.x, thr = b.y;
+        uint32_t mask = 0xFu;
+        if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
+            mask = 0;
+            const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
+                    mask |= 1u << q;
+        }
+        const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
+        // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
+        keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + owner) << 4) | mask);
+    });
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)

@@ -147,6 +147,25 @@ def main():
     stages = {k: round(v[0] / 10.0, 4) for k, v in profile_read().items()}  # ms per frame (a stage may have >1 timed span)
     profile_enable(())
 
+    # secondary figure (single process only): the same frames with two in flight on two HIP streams -- independent frames
+    # (validation / animation loops, or the reference's separate human + scene renders) can overlap one frame's
+    # latency-bound binning with another's VALU-bound blending.  `value` above stays the serial number.
+    fps_two_streams = None
+    if world == 1 and not args.forward_only:
+        side = [torch.cuda.Stream(device) for _ in range(2)]
+        for st_ in side:
+            st_.wait_stream(torch.cuda.current_stream(device))
+        for k in range(20):
+            with torch.cuda.stream(side[k & 1]):
+                step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            with torch.cuda.stream(side[k & 1]):
+                step()
+        torch.cuda.synchronize()
+        fps_two_streams = args.steps / (time.perf_counter() - t0)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -180,6 +199,9 @@ def main():
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
         "stages_ms": stages,
     }
+    if fps_two_streams is not None:
+        out["two_frames_in_flight"] = {"value": round(fps_two_streams, 2), "unit": "frames/s",
+                                       "note": "same workload, frames alternate between two HIP streams of one process"}
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs of this same
     # command; collected and corrected as MI355X_MICROARCH.md prescribes) -- only for the workload they were taken on

@@ -234,6 +234,31 @@ def test_second_backward_through_a_retained_graph(device):
         assert rel_l2(t[k].grad.cpu().numpy(), v.cpu().numpy()) <= 1e-5, k
 
 
+def test_two_frames_in_flight_on_two_streams(device):
+    """Independent frames may be enqueued on different HIP streams (bench.py's `two_frames_in_flight`): scratch, the
+    pinned N slots and the capacity guesses must not be shared between them."""
+    scenes = [make_scene(**CASES["basic_d3"]), make_scene(**CASES["rotcam_d2"])]
+    serial = []
+    for sc in scenes:
+        t, c, r = run_gpu(sc, device)
+        c.backward(to_dev(sc["dL_dpix"], device))
+        serial.append((c.detach().clone(), r.clone(), t["means3D"].grad.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device) for _ in scenes]
+    for rep in range(3):
+        out = []
+        for sc, st in zip(scenes, streams):
+            st.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(st):
+                t, c, r = run_gpu(sc, device)
+                c.backward(to_dev(sc["dL_dpix"], device))
+                out.append((c, r, t["means3D"]))
+        torch.cuda.synchronize()
+        for (c, r, m), (c0, r0, g0) in zip(out, serial):
+            assert torch.equal(c, c0) and torch.equal(r, r0)
+            assert rel_l2(m.grad.cpu().numpy(), g0.cpu().numpy()) <= 1e-5
+
+
 def test_api_errors(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(**CASES["single"])

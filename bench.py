@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-frames-in-flight figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
 
@@ -151,7 +152,7 @@ def main():
     # (validation / animation loops, or the reference's separate human + scene renders) can overlap one frame's
     # latency-bound binning with another's VALU-bound blending.  `value` above stays the serial number.
     fps_two_streams = None
-    if world == 1 and not args.forward_only:
+    if world == 1 and not args.forward_only and not args.no_two_streams:
         side = [torch.cuda.Stream(device) for _ in range(2)]
         for st_ in side:
             st_.wait_stream(torch.cuda.current_stream(device))

@@ -9,13 +9,13 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o $TAG -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o $TAG -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-two-streams \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/trace.err"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"; do
     name=$(echo $set | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_$name" -o p -- python3 bench.py --steps 5 --warmup 2 \
-        --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err"
+        --no-cpu-baseline --no-two-streams > /dev/null 2> "$OUT/pmc_$name.err"
 done
 python3 profiles/summarize_rocprof.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_kernel_stats.txt"
 python3 profiles/timeline_gaps.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_timeline.txt"

@@ -155,6 +155,11 @@ int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, cons
                                  const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
                                  void *stream);
 
+/* SURVEY.md 8f row f-4 -- replaces simple_knn._C.distCUDA2 (/root/reference/hugs/models/scene.py:20,181): mean_dist2[i]
+ * = mean of the squared distances from points[i] to its three nearest OTHER points of the same cloud ([n,3], n >= 4,
+ * 16-byte aligned).  Exact (brute force), fp32. */
+int32_t hgs_dist_cuda2(int32_t n, const float *points, float *mean_dist2, void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

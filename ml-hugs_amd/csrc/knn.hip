@@ -57,10 +57,11 @@ __device__ __forceinline__ float sqdist(float px, float py, float pz, float tx, 
 
 constexpr int KNN_SPLIT = 4;  // waves per workgroup = template segments
 
-// scans template vertices [j0, j1), j0 a multiple of 4
+// scans template vertices [j0, j1), j0 a multiple of 4; vertex `skip` (or -1) is never offered (a cloud searched
+// against itself: a point is not its own neighbour)
 template <int K>
 __device__ __forceinline__ void scan_template(float px, float py, float pz, const float* __restrict__ templ, int j0, int j1,
-                                              Best<K>& best)
+                                              int skip, Best<K>& best)
 {
     best.init();
     const int j4 = j0 + ((j1 - j0) & ~3);
@@ -68,8 +69,12 @@ __device__ __forceinline__ void scan_template(float px, float py, float pz, cons
         const_f4p q = (const_f4p)(templ + 3 * (size_t)j);
         const v4f a = q[0], b = q[1], c = q[2];
         // four independent distance chains and one wave-level test for "nobody improves", the usual case
-        const float d0 = sqdist(px, py, pz, a.x, a.y, a.z), d1 = sqdist(px, py, pz, a.w, b.x, b.y);
-        const float d2 = sqdist(px, py, pz, b.z, b.w, c.x), d3 = sqdist(px, py, pz, c.y, c.z, c.w);
+        float d0 = sqdist(px, py, pz, a.x, a.y, a.z), d1 = sqdist(px, py, pz, a.w, b.x, b.y);
+        float d2 = sqdist(px, py, pz, b.z, b.w, c.x), d3 = sqdist(px, py, pz, c.y, c.z, c.w);
+        if ((skip & ~3) == j) {  // at most one trip per lane
+            const float inf = __builtin_inff();
+            d0 = skip == j ? inf : d0, d1 = skip == j + 1 ? inf : d1, d2 = skip == j + 2 ? inf : d2, d3 = skip == j + 3 ? inf : d3;
+        }
         const float dmin = fminf(fminf(d0, d1), fminf(d2, d3));
         if (__builtin_amdgcn_ballot_w64(dmin < best.d[K - 1]) == 0ull) continue;
         best.offer(d0, j);
@@ -79,12 +84,12 @@ __device__ __forceinline__ void scan_template(float px, float py, float pz, cons
     }
     for (int j = j4; j < j1; ++j) {
         const_f32p q = (const_f32p)(templ + 3 * (size_t)j);
-        best.offer(sqdist(px, py, pz, q[0], q[1], q[2]), j);
+        if (j != skip) best.offer(sqdist(px, py, pz, q[0], q[1], q[2]), j);
     }
 }
 
 // The workgroup's search: returns (in wave 0 only, `true`) the K nearest template vertices of point blockIdx.x*64+lane.
-template <int K>
+template <int K, bool SKIP_SELF = false>
 __device__ __forceinline__ bool workgroup_knn(int n, const float* __restrict__ points, int m, const float* __restrict__ templ,
                                               Best<K>& best, int& point)
 {
@@ -95,7 +100,8 @@ __device__ __forceinline__ bool workgroup_knn(int n, const float* __restrict__ p
     const int pc = point < n ? point : n - 1;  // every lane scans (wave-uniform loads); only valid lanes store
     const int seg = (((m + KNN_SPLIT - 1) / KNN_SPLIT) + 3) & ~3;
     const int j0 = min(w * seg, m), j1 = min(j0 + seg, m);
-    scan_template<K>(points[3 * (size_t)pc], points[3 * (size_t)pc + 1], points[3 * (size_t)pc + 2], templ, j0, j1, best);
+    scan_template<K>(points[3 * (size_t)pc], points[3 * (size_t)pc + 1], points[3 * (size_t)pc + 2], templ, j0, j1,
+                     SKIP_SELF ? pc : -1, best);
     if (w > 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) sh_d[w - 1][k][lane] = best.d[k], sh_i[w - 1][k][lane] = best.i[k];
@@ -160,6 +166,18 @@ lbsweight_top_k_kernel(int n, const float* __restrict__ points, int m, const flo
         for (int k = 0; k < K; ++k) acc += wgt[k] * lbs_weights[(size_t)best.i[k] * J + j];
         out_weights[(size_t)i * J + j] = acc;
     }
+}
+
+// simple_knn's distCUDA2 -- mean squared distance of every point of a cloud to its three nearest
+// OTHER points (scene.py:181, initial scales).  Upstream sorts by Morton code and searches boxes; at initialisation
+// sizes (1e5 points) the brute-force scan above does the n^2 distances in a few milliseconds, exactly.
+__global__ void __launch_bounds__(64 * KNN_SPLIT)
+mean_dist3_kernel(int n, const float* __restrict__ points, float* __restrict__ mean_dist2)
+{
+    Best<3> best;
+    int i;
+    if (!workgroup_knn<3, true>(n, points, n, points, best, i) || i >= n) return;
+    mean_dist2[i] = ((best.d[0] + best.d[1]) + best.d[2]) / 3.0f;
 }
 
 int fail_knn(const char* what)
@@ -229,6 +247,21 @@ extern "C" int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float* points, int3
     if (int rc = dispatch_k<LaunchLbs>(K, n, points, m, template_points, lbs_weights, J, out_dist, out_weights, (hipStream_t)stream)) return rc;
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("smpl_lbsweight_top_k: kernel launch failed");
+        return HGS_ERR_HIP;
+    }
+    return HGS_OK;
+}
+
+extern "C" int32_t hgs_dist_cuda2(int32_t n, const float* points, float* mean_dist2, void* stream)
+{
+    if (n < 0) return fail_knn("distCUDA2: n < 0");
+    if (n == 0) return HGS_OK;
+    if (n < 4) return fail_knn("distCUDA2: needs at least 4 points (three neighbours besides the point itself)");
+    if (!points || !mean_dist2) return fail_knn("distCUDA2: null pointer");
+    if (((uintptr_t)points & 15) != 0) return fail_knn("distCUDA2: points must be 16-byte aligned");
+    hipLaunchKernelGGL(mean_dist3_kernel, dim3((n + 63) / 64), dim3(64 * KNN_SPLIT), 0, (hipStream_t)stream, n, points, mean_dist2);
+    if (hipGetLastError() != hipSuccess) {
+        hgs::set_last_error("distCUDA2: kernel launch failed");
         return HGS_ERR_HIP;
     }
     return HGS_OK;

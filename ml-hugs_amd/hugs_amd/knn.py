@@ -5,6 +5,7 @@ Drop-ins, with the reference's names, argument order and return values, for
     pytorch3d.ops.knn_points(p1, p2, K=K)                    used at /root/reference/hugs/models/hugs_wo_trimlp.py:60,99
     smpl_lbsweight_top_k(lbs_weights, points, template_points, K=6)             hugs_wo_trimlp.py:88-119
     smpl_lbsmap_top_k(lbs_weights, verts_transform, points, template_points, K=6, addition_info=None)    :47-85
+    simple_knn._C.distCUDA2(points)                         used at /root/reference/hugs/models/scene.py:20,181  (row f-4)
 
 The search (and, for smpl_lbsweight_top_k -- the one on the every-training-step path, hugs_trimlp.py:318,480 -- the whole
 function) runs in hand-written HIP (csrc/knn.hip) behind the C ABI; smpl_lbsmap_top_k keeps the reference's torch
@@ -105,3 +106,20 @@ def smpl_lbsmap_top_k(lbs_weights, verts_transform, points, template_points, K=6
         nb_info = batch_index_select(addition_info, neighbs)
         return xyz_dist, xyz_transform, torch.sum(wgt.unsqueeze(-1) * nb_info, dim=2)
     return xyz_dist, xyz_transform
+
+
+def distCUDA2(points):
+    """points [n,3] (cuda, fp32) -> [n]: mean squared distance to the three nearest other points (scene.py:181 clamps
+    it and takes log(sqrt(.)) as the initial scale).  Brute force in HIP, exact."""
+    lib = _load()
+    lib.hgs_dist_cuda2.restype = C.c_int32
+    lib.hgs_dist_cuda2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    if points.ndim != 2 or points.shape[1] != 3:
+        raise ValueError("distCUDA2: expected points [n,3]")
+    p = _prep(points, "points")
+    out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = lib.hgs_dist_cuda2(p.shape[0], p.data_ptr(), out.data_ptr(), _stream_ptr(p.device))
+    if rc < 0:
+        _raise_last(lib, "distCUDA2")
+    return out

@@ -67,3 +67,24 @@ def smpl_lbsmap_top_k(lbs_weights, verts_transform, points, template_points, K=6
         info = np.ascontiguousarray(addition_info, dtype=np.float32)[idx]   # :81
         return xyz_dist, xyz_transform, (wgt[:, :, None] * info).sum(1, dtype=np.float32)
     return xyz_dist, xyz_transform
+
+
+def dist_cuda2(points):
+    """simple_knn._C.distCUDA2 (called at /root/reference/hugs/models/scene.py:181; the simple-knn submodule is NOT in
+    /root/reference: PARITY UNPINNED, restated from its published behaviour): for every point the mean of the squared
+    distances to its three nearest OTHER points of the same cloud.  points [n,3] float32 -> [n] float32."""
+    p = np.ascontiguousarray(points, dtype=np.float32)
+    n = p.shape[0]
+    assert n >= 4
+    out = np.empty(n, np.float32)
+    step = max(1, (1 << 24) // n)
+    for s in range(0, n, step):
+        q = p[s:s + step]
+        dx = q[:, None, 0] - p[None, :, 0]
+        dy = q[:, None, 1] - p[None, :, 1]
+        dz = q[:, None, 2] - p[None, :, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        d[np.arange(q.shape[0]), np.arange(s, s + q.shape[0])] = np.inf      # a point is not its own neighbour
+        b = np.sort(d, axis=1)[:, :3]
+        out[s:s + step] = ((b[:, 0] + b[:, 1]) + b[:, 2]) / np.float32(3.0)
+    return out

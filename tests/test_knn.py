@@ -122,3 +122,31 @@ def test_hip_knn_errors(device):
     with pytest.raises(RuntimeError):
         knn_points(torch.zeros(1, 4, 3), torch.zeros(1, 30, 3), K=2)   # CPU tensors: no fallback
     assert knn_points(torch.zeros(1, 0, 3, device=device), torch.zeros(1, 30, 3, device=device), K=2).idx.shape == (1, 0, 2)
+
+
+def test_oracle_dist_cuda2_small_known_answer():
+    """unit grid: every interior point of a 4x4x4 lattice has 6 neighbours at distance 1 -> mean of the 3 nearest = 1"""
+    g = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    d = ko.dist_cuda2(g)
+    assert np.all(d == 1.0)
+    g2 = np.concatenate([g, g[:1]])                        # a duplicated point: its twin is at distance 0
+    d2 = ko.dist_cuda2(g2)
+    assert d2[0] == d2[-1] == np.float32(2.0 / 3.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 65, 1000, 30011])
+def test_hip_dist_cuda2_is_bit_exact_against_the_oracle(n, device):
+    """row f-4: the initial-scale statistic of scene.py:181, including the reference's use of it"""
+    from hugs_amd.knn import distCUDA2
+    r = np.random.default_rng(n)
+    pts = r.standard_normal((n, 3)).astype(np.float32)
+    if n > 100:
+        pts[7] = pts[3]                                    # duplicate
+    got = distCUDA2(torch.from_numpy(pts).to(device))
+    ref = ko.dist_cuda2(pts)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    scales = torch.log(torch.sqrt(torch.clamp_min(got, 0.0000001)))[..., None].repeat(1, 3)   # scene.py:181-182
+    assert torch.isfinite(scales).all()
+    with pytest.raises(RuntimeError):
+        distCUDA2(torch.zeros(3, 3, device=device))

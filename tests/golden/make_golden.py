@@ -286,6 +286,14 @@ def main():
                knn_lbsweight_dist=d1[0].numpy(), knn_lbsweight_weights=w1[0].numpy(),
                knn_lbsmap_dist=d2[0].numpy(), knn_lbsmap_transform=T2[0].numpy(), knn_lbsmap_info=i2[0].numpy())
 
+    # ---- PLY attribute order: SceneGS.construct_list_of_attributes, scene.py:229-241, executed ----
+    # (save_ply / load_ply themselves need the `plyfile` package, which is not installed: only the attribute list,
+    # which fixes the on-disk column order, can be produced by the reference here)
+    cla = _method_from_source(os.path.join(REF, "hugs/models/scene.py"), "SceneGS", "construct_list_of_attributes", {})
+    fake = types.SimpleNamespace(_features_dc=torch.zeros(2, 1, 3), _features_rest=torch.zeros(2, 15, 3),
+                                 _scaling=torch.zeros(2, 3), _rotation=torch.zeros(2, 4))
+    out["ply_attribute_names_json"] = np.frombuffer(json.dumps(cla(fake)).encode(), dtype=np.uint8)
+
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT) / 1024:.1f} KiB")
 

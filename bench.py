@@ -216,6 +216,15 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(newest)
     except Exception:
         pass
+    # ... and its VALU issue utilisation from the SQ counter passes of the same round: the bound that actually holds
+    try:
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_utilization.json")))[-1]
+        vu = json.load(open(newest))["kernels"][dominant + "_kernel"]
+        out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": vu["valu_busy_frac"],
+                             "wave_instructions_per_launch": vu["valu_wave_instructions"],
+                             "source": "profiles/" + os.path.basename(newest) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
+    except Exception:
+        pass
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)

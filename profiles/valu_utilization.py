@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""VALU issue utilisation of the kernels from the two SQ PMC summaries of a round:
+    busy fraction = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)
+(SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).
+
+    python profiles/valu_utilization.py profiles/<tag>_pmc_sq_set1.txt profiles/<tag>_pmc_sq_set2.txt > profiles/<tag>_valu_utilization.json"""
+import json
+import re
+import sys
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"(\w+)\s+\(dispatches", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+        elif cur is not None and line.startswith("    "):
+            k, v = line.split()
+            cur[k] = float(v)
+    return out
+
+
+def main(set1, set2):
+    a, b = parse(set1), parse(set2)
+    res = {"source": [set1, set2], "formula": "SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)", "kernels": {}}
+    for k in sorted(set(a) & set(b)):
+        if "SQ_ACTIVE_INST_VALU" in a[k] and "GRBM_GUI_ACTIVE" in b[k]:
+            cyc = b[k]["GRBM_GUI_ACTIVE"] / 8.0
+            res["kernels"][k] = {"valu_busy_frac": round(a[k]["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 4),
+                                 "valu_wave_instructions": a[k].get("SQ_INSTS_VALU"), "kernel_cycles": round(cyc)}
+    json.dump(res, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

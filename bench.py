@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--cluster", type=float, default=0.0, help="fraction of the Gaussians in a central blob (not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-frames-in-flight figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
@@ -80,7 +81,7 @@ def main():
 
     P, H, W, D = args.gaussians, args.height, args.width, args.sh_degree
     cam0 = syn.pinhole_camera(H, W)
-    g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0)
+    g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0, cluster=args.cluster)
     # frame r of the batch: the same scene seen from a slightly yawed camera (frame 0 = identity pose)
     yaw = math.radians(1.5) * rank
     w2c = np.eye(4)

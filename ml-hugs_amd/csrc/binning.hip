@@ -497,7 +497,9 @@ __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_
 // Appends up to 256 consecutive sorted entries of a tile (one per thread, `valid` when it exists) to the tile's
 // NUM_LISTS compacted lists: list q < 4 keeps the entries covering quad q, list 4 those covering any quad.  List q
 // of a tile lives at act[q * stride + s ...] (same offsets as the tile's segment of the sorted list, so no global
-// prefix sum is needed).  carry[q] = entries already appended.  sh32: >= 4 * NUM_LISTS words of LDS.
+// prefix sum is needed).  carry[q] = entries already appended.  NW = waves in the workgroup (a chunk is 64 NW entries);
+// sh32: >= NW * NUM_LISTS words of LDS.
+template <int NW = 4>
 __device__ __forceinline__ void compact_chunk(uint64_t entry, bool valid, uint32_t (&carry)[NUM_LISTS], uint32_t s,
                                               uint64_t* __restrict__ act, size_t stride, uint32_t* sh32)
 {
@@ -511,15 +513,15 @@ __device__ __forceinline__ void compact_chunk(uint64_t entry, bool valid, uint32
         flag[q] = q < 4 ? ((mask >> q) & 1u) != 0u : mask != 0u;
         const uint64_t m = __ballot(flag[q]);
         wrank[q] = (uint32_t)__popcll(m & lt);
-        if (lane == 0) sh32[q * 4 + w] = (uint32_t)__popcll(m);
+        if (lane == 0) sh32[q * NW + w] = (uint32_t)__popcll(m);
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NUM_LISTS; ++q) {
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t c = sh32[q * 4 + k];
+        for (uint32_t k = 0; k < (uint32_t)NW; ++k) {
+            const uint32_t c = sh32[q * NW + k];
             if (k < w) before += c;
             total += c;
         }
@@ -575,8 +577,9 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
 
 // Tiles with more than CAP_SMALL entries: bitonic in LDS up to CAP entries, brute-force ranking through global
 // scratch beyond that (slow, but only for absurdly dense tiles).
+constexpr int SORT_LARGE_THREADS = 1024;  // a long tile is one workgroup's job: make it a big one
 template <int CAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SORT_LARGE_THREADS)
 tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
                        uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
                        uint32_t* __restrict__ act_count, const uint32_t* __restrict__ large_tiles,
@@ -592,23 +595,23 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     if (n <= (uint32_t)CAP) {
         uint32_t m = 2;
         while (m < n) m <<= 1;
-        for (uint32_t i = threadIdx.x; i < m; i += 256) sh[i] = i < n ? keys[s + i] : ~0ull;
+        for (uint32_t i = threadIdx.x; i < m; i += SORT_LARGE_THREADS) sh[i] = i < n ? keys[s + i] : ~0ull;
         __syncthreads();
         for (uint32_t k = 2; k <= m; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
+                for (uint32_t c = threadIdx.x; c < (m >> 1); c += SORT_LARGE_THREADS) {
                     const uint32_t l = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), r = l | j;
                     const uint64_t a = sh[l], b = sh[r];
                     if ((a > b) == ((l & k) == 0u)) sh[l] = b, sh[r] = a;
                 }
                 __syncthreads();
             }
-        for (uint32_t i = threadIdx.x; i < n; i += 256) list[s + i] = list_entry(sh[i], i + 1u);
+        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) list[s + i] = list_entry(sh[i], i + 1u);
     } else {
         // rank every key against all others (keys are distinct: they embed the Gaussian index)
-        for (uint32_t i = threadIdx.x; i < n; i += 256) scratch[s + i] = keys[s + i];
+        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) scratch[s + i] = keys[s + i];
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) {
             const uint64_t ki = scratch[s + i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; ++j) rank += scratch[s + j] < ki ? 1u : 0u;
@@ -618,10 +621,10 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     // the segment is sorted in global memory (written by this workgroup): compact it chunk by chunk
     __syncthreads();
     uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
-    for (uint32_t base = 0; base < n; base += 256) {
+    for (uint32_t base = 0; base < n; base += SORT_LARGE_THREADS) {
         const uint32_t i = base + threadIdx.x;
         const uint64_t entry = i < n ? __builtin_nontemporal_load(&list[s + i]) : 0ull;
-        compact_chunk(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
+        compact_chunk<SORT_LARGE_THREADS / 64>(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
     }
 #pragma unroll
     for (int q = 0; q < NUM_LISTS; ++q)
@@ -636,7 +639,7 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
 {
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
                        n_total + 1);
-    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(256), 0, st, ranges,
+    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(SORT_LARGE_THREADS), 0, st, ranges,
                        keys, list, scratch, act, stride, act_count, large_tiles, n_total);
 }
 

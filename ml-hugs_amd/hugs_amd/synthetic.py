@@ -68,12 +68,13 @@ def rotating_camera(i, nframes, dist=5.0, fov=0.4, img_size=512):
     return camera_from_w2c(w2c, fov, fov, img_size, img_size)
 
 
-def scene_gaussians(P, cam, seed=0, sh_coeffs=16, sigma_px=4.5, nonunit_quat=False, ref_P=200_000):
+def scene_gaussians(P, cam, seed=0, sh_coeffs=16, sigma_px=4.5, nonunit_quat=False, ref_P=200_000, cluster=0.0):
     """Random Gaussians filling the view frustum of `cam` (camera must be the identity pose).
 
     Screen-space size is controlled: the world scale of each Gaussian is proportional to its
     depth so that its projected sigma is ~ sigma_px * lognormal(0.5) pixels, divided by
-    sqrt(P / ref_P) so total coverage stays comparable across the P sweep.
+    sqrt(P / ref_P) so total coverage stays comparable across the P sweep.  `cluster` = fraction of the Gaussians
+    packed into a person-sized blob in the middle of the view (a human in front of a scene) instead of spread uniformly.
     """
     rng = np.random.default_rng(seed)
     H, W = cam["image_height"], cam["image_width"]
@@ -81,6 +82,11 @@ def scene_gaussians(P, cam, seed=0, sh_coeffs=16, sigma_px=4.5, nonunit_quat=Fal
     z = rng.uniform(1.0, 20.0, P)
     x = rng.uniform(-1.1, 1.1, P) * z * tanx
     y = rng.uniform(-1.1, 1.1, P) * z * tany
+    if cluster > 0.0:
+        nc = int(P * cluster)
+        z[:nc] = rng.uniform(4.0, 5.0, nc)
+        x[:nc] = 0.18 * rng.standard_normal(nc) * z[:nc] * tanx
+        y[:nc] = 0.45 * rng.standard_normal(nc) * z[:nc] * tany
     means = np.stack([x, y, z], 1).astype(np.float32)
     f = W / (2.0 * tanx)
     base = z[:, None] * (sigma_px / f) / math.sqrt(max(P, 1) / ref_P)

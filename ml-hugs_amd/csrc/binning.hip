@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
 // that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
 // too small (hgs_api.hip).  N is also published to the host, straight from this kernel, as ONE 64-bit system-scope
 // store (ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
-constexpr int SORT_CAP_SMALL = 1024, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
+constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
 
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
@@ -374,7 +374,7 @@ __device__ __forceinline__ uint64_t list_entry(uint64_t key, uint32_t pos1)
     return ((uint64_t)pos1 << 32) | (uint64_t)(((low & 15u) << GID_BITS) | (low >> 4));
 }
 
-// Small tiles (n <= 1024, i.e. practically all of them): the bitonic network runs in REGISTERS.  Thread t holds
+// Small tiles (n <= 2048, i.e. practically all of them): the bitonic network runs in REGISTERS.  Thread t holds
 // elements i = e * 256 + t (e < E = m / 256).  A compare-exchange distance j >= 256 pairs two registers of the
 // same thread; j = 64 / 128 go through LDS with barriers (3 of the 36 steps at m = 256); j < 64 pairs two lanes of a
 // wave: DPP moves for j = 1, 2 (quad_perm), 4 (row_shl:4 / row_shr:4 into complementary banks), 8 (row_ror:8),
@@ -572,7 +572,8 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     if (n > (uint32_t)SORT_CAP_SMALL) return;
     if (n <= 256u) tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
     else if (n <= 512u) tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
-    else tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
+    else if (n <= 1024u) tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
+    else tile_sort_small<8>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
 }
 
 // Tiles with more than CAP_SMALL entries: bitonic in LDS up to CAP entries, brute-force ranking through global

@@ -459,7 +459,8 @@ def test_full_size_workload_parity_and_properties(device):
 
 def _stacked_scene(P, H, W, seed, spread_px):
     """P small Gaussians whose centres all project into a few neighbouring tiles in the image centre: exercises the
-    tile-sort paths for long lists (LDS bitonic for 1024 < n <= 8192, rank fallback beyond) and heavy atomics."""
+    tile-sort paths for long lists (eight keys per thread in registers for 1024 < n <= 2048, LDS bitonic up to 8192,
+    rank fallback beyond) and heavy atomics."""
     import math
     from hugs_amd import synthetic as syn
     rng = np.random.default_rng(seed)
@@ -482,14 +483,14 @@ def _stacked_scene(P, H, W, seed, spread_px):
     return sc
 
 
-@pytest.mark.parametrize("P,longest_at_least", [(3000, 1025), (20000, 8193)])
-def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, device):
+@pytest.mark.parametrize("P,longest_at_least,longest_at_most", [(2000, 1025, 2048), (6000, 2049, 8192), (20000, 8193, 10 ** 9)])
+def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, longest_at_most, device):
     from diff_gaussian_rasterization import _debug_forward_state
     sc = _stacked_scene(P, 64, 64, seed=40 + P, spread_px=6.0)
     inp = oracle_inputs(sc)
     ref = ho.forward(inp)
     lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
-    assert lens.max() >= longest_at_least, f"scene not dense enough: longest tile list {lens.max()}"
+    assert longest_at_least <= lens.max() <= longest_at_most, f"scene misses the intended path: longest tile list {lens.max()}"
     t = gpu_tensors(sc, device, grad=False)
     color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
                                             scales=t["scales"], rotations=t["rotations"])

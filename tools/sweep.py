@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The headline curve of BASELINE.json / SURVEY.md 8d: rasterizer FPS at 1080p against the number of Gaussians, forward
+only and forward+backward, one MI355X -- plus the measured stream-copy bandwidth of the box next to the datasheet
+figure.  Runs bench.py once per point (its JSON line is the measurement) and prints one JSON document.
+    python tools/sweep.py > gpurun_out/sweep.json"""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stream_copy_gbps(nbytes=1 << 30, iters=20):
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9   # read + write
+
+
+def main():
+    out = {"hbm_stream_copy_GBps_measured": round(stream_copy_gbps(), 1), "hbm_peak_GBps_datasheet": 8000.0, "points": []}
+    for P in (50_000, 100_000, 200_000, 300_000, 500_000, 1_000_000):
+        row = {"gaussians": P}
+        for mode, flag in (("fwd", ["--forward-only"]), ("fwd_bwd", [])):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--steps", "100", "--warmup", "15",
+                                "--no-cpu-baseline", "--no-two-streams"] + flag, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            row[mode] = {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]}
+            row["num_rendered_N"], row["visible"] = d["config"]["num_rendered_N"], d["config"]["visible"]
+            row[mode]["whole_frame_GBps"] = d["whole_frame"]["GB_per_s"]
+        out["points"].append(row)
+        print(f"P={P}: fwd {row['fwd']['fps']:.0f} FPS, fwd+bwd {row['fwd_bwd']['fps']:.0f} FPS, N={row['num_rendered_N']}", file=sys.stderr)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -171,15 +171,6 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_ROR8 = 0x128;  // lane i <- lane i^8 (rotate by half a row)
 constexpr int DPP_ROW_MIRROR = 0x140;       // lane i <- lane 15-i of its row
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i of its half-row
-constexpr int DPP_ROW_BCAST15 = 0x142;      // lane 15 of each row -> every lane of the next row
-constexpr int DPP_ROW_BCAST31 = 0x143;      // lane 31 -> every lane of rows 2 and 3
-
-// DPP move applied to the rows in ROW_MASK only; the other rows read 0
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov_rows(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
 
 // a and b are exchanged across the wave halves (W = 32) or across odd/even rows of 16 (W = 16) and added:
 // W = 32: lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l];
@@ -341,8 +332,10 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
         vb += dpp_mov<DPP_QUAD_XOR2>(vb);
         vb += dpp_mov<DPP_ROW_HALF_MIRROR>(vb);
         vb += dpp_mov<DPP_ROW_MIRROR>(vb);
-        vb += dpp_mov_rows<DPP_ROW_BCAST15, 0xA>(vb);
-        vb += dpp_mov_rows<DPP_ROW_BCAST31, 0xC>(vb);
+        // rows 1,3 += lane 15 of the row before; rows 2,3 += lane 31.  Spelled out: a masked-row DPP add leaves the other
+        // rows untouched in ONE instruction; through the builtin it becomes v_mov 0 + v_mov_dpp + v_add.
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(vb));
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(vb));
         // eight half-row leaders + lane 63 add the nine totals into the Gaussian's accumulator record with one
         // atomic instruction
         if (slot_of_lane >= 0) atomicAdd(grad_accum + (size_t)(val & GID_MASK) * 12u + slot_of_lane, lane == 63 ? vb : y);

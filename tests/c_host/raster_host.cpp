@@ -1,0 +1,127 @@
+// A torch-free host for the C ABI of include/hgs_rasterizer.h: everything a C/C++ (or cgo / JNI / FFI) caller does.
+// Reads a scene from a flat binary file, runs hgs_rasterize_forward + hgs_rasterize_backward with plain hipMalloc'd
+// buffers and a hipMalloc allocation callback, and writes the results back for tests/test_c_host.py to compare with
+// the oracle.  Built by __graft_entry__.build():  hipcc -O2 raster_host.cpp -L<lib> -lhgs_rasterizer
+//
+//   in.bin : int32 P, M, H, W, D, use_hint | float tanfovx, tanfovy, scale_modifier | bg[3] view[16] proj[16] campos[3]
+//            means3D[3P] shs[3MP] opacities[P] scales[3P] rotations[4P] dL_dcolor[3HW]
+//   out.bin: int64 N | color[3HW] | int32 radii[P] | dL_dmeans3D[3P] dL_dmeans2D[3P] dL_dopacity[P] dL_dsh[3MP]
+//            dL_dscales[3P] dL_drotations[4P]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "hgs_rasterizer.h"
+
+#define CHECK(x)                                                                            \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                         \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+static std::vector<void*> g_scratch;
+static void* alloc_cb(void*, int, size_t bytes)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    g_scratch.push_back(p);
+    return p;
+}
+
+template <class T>
+static T* to_device(const std::vector<T>& h)
+{
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, h.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+template <class T>
+static T* device_buffer(size_t n)
+{
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(T) + 16) != hipSuccess) return nullptr;
+    return d;
+}
+template <class T>
+static bool read_vec(FILE* f, std::vector<T>& v, size_t n)
+{
+    v.resize(n);
+    return fread(v.data(), sizeof(T), n, f) == n;
+}
+template <class T>
+static void write_dev(FILE* f, const T* d, size_t n)
+{
+    std::vector<T> h(n);
+    (void)hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost);
+    fwrite(h.data(), sizeof(T), n, f);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 3) return fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]), 1;
+    if (hgs_abi_version() != HGS_ABI_VERSION) return fprintf(stderr, "ABI mismatch\n"), 1;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return perror(argv[1]), 1;
+    int32_t hdr[6];
+    float fl[3];
+    if (fread(hdr, 4, 6, f) != 6 || fread(fl, 4, 3, f) != 3) return 1;
+    const int P = hdr[0], M = hdr[1], H = hdr[2], W = hdr[3], D = hdr[4], use_hint = hdr[5];
+    std::vector<float> bg, view, proj, campos, means, shs, opac, scales, rots, dL;
+    if (!read_vec(f, bg, 3) || !read_vec(f, view, 16) || !read_vec(f, proj, 16) || !read_vec(f, campos, 3) ||
+        !read_vec(f, means, 3 * (size_t)P) || !read_vec(f, shs, 3 * (size_t)M * P) || !read_vec(f, opac, P) ||
+        !read_vec(f, scales, 3 * (size_t)P) || !read_vec(f, rots, 4 * (size_t)P) || !read_vec(f, dL, 3 * (size_t)H * W))
+        return fprintf(stderr, "short input file\n"), 1;
+    fclose(f);
+
+    hipStream_t stream;
+    CHECK(hipStreamCreate(&stream));
+    hgs_backward_args bw = {};          // embeds the forward arguments and the forward state
+    hgs_forward_args& a = bw.fwd;
+    a.s.image_height = H, a.s.image_width = W, a.s.tanfovx = fl[0], a.s.tanfovy = fl[1], a.s.scale_modifier = fl[2];
+    a.s.bg = to_device(bg), a.s.viewmatrix = to_device(view), a.s.projmatrix = to_device(proj), a.s.campos = to_device(campos);
+    a.s.sh_degree = D, a.s.prefiltered = 0, a.s.debug = 0;
+    a.P = P, a.M = M;
+    a.means3D = to_device(means), a.shs = to_device(shs), a.opacities = to_device(opac);
+    a.scales = to_device(scales), a.rotations = to_device(rots);
+    float* color = device_buffer<float>(3 * (size_t)H * W);
+    int32_t* radii = device_buffer<int32_t>(P);
+    a.out_color = color, a.radii = radii;
+    bw.grad_accum = device_buffer<float>((size_t)P * 12);
+    a.grad_accum_to_zero = bw.grad_accum;  // forward zeroes backward's accumulator
+    bw.dL_dmeans2D = device_buffer<float>(3 * (size_t)P), bw.dL_dopacity = device_buffer<float>(P);
+    bw.dL_dcolors = device_buffer<float>(3 * (size_t)P), bw.dL_dmeans3D = device_buffer<float>(3 * (size_t)P);
+    bw.dL_dcov3D = device_buffer<float>(6 * (size_t)P), bw.dL_dsh = device_buffer<float>(3 * (size_t)M * P);
+    bw.dL_dscales = device_buffer<float>(3 * (size_t)P), bw.dL_drotations = device_buffer<float>(4 * (size_t)P);
+    bw.dL_dout_color = to_device(dL);
+
+    int64_t N = -1;
+    for (int frame = 0; frame < (use_hint ? 2 : 1); ++frame) {   // second frame: capacity guessed from the first
+        a.binning_capacity_hint = frame == 0 ? 0 : N + N / 8 + 4096;
+        N = hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream);
+        if (N < 0) return fprintf(stderr, "forward: %s\n", hgs_last_error()), 3;
+    }
+    if (hgs_rasterize_backward(&bw, stream) < 0) return fprintf(stderr, "backward: %s\n", hgs_last_error()), 3;
+    CHECK(hipStreamSynchronize(stream));
+
+    FILE* o = fopen(argv[2], "wb");
+    if (!o) return perror(argv[2]), 1;
+    fwrite(&N, 8, 1, o);
+    write_dev(o, color, 3 * (size_t)H * W);
+    write_dev(o, radii, P);
+    write_dev(o, bw.dL_dmeans3D, 3 * (size_t)P);
+    write_dev(o, bw.dL_dmeans2D, 3 * (size_t)P);
+    write_dev(o, bw.dL_dopacity, P);
+    write_dev(o, bw.dL_dsh, 3 * (size_t)M * P);
+    write_dev(o, bw.dL_dscales, 3 * (size_t)P);
+    write_dev(o, bw.dL_drotations, 4 * (size_t)P);
+    fclose(o);
+    for (void* p : g_scratch) (void)hipFree(p);
+    printf("ok N=%lld binning_capacity=%lld\n", (long long)N, (long long)bw.state.binning_capacity);
+    return 0;
+}

@@ -1,0 +1,68 @@
+"""The C ABI driven by a torch-free C++ host (tests/c_host/raster_host.cpp): plain hipMalloc buffers, a hipMalloc
+allocation callback, its own stream -- the shape of a cgo / JNI / FFI binding.  Results must match the oracle exactly
+as they do through the Python binding."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import hgs_oracle as ho
+from scenes import CASES, make_scene, oracle_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "c_host", "raster_host")
+LIBDIR = os.path.join(ROOT, "ml-hugs_amd", "lib")
+
+
+def build_host():
+    src = HOST + ".cpp"
+    if not os.path.exists(HOST) or os.path.getmtime(HOST) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-L", LIBDIR,
+                               "-lhgs_rasterizer", f"-Wl,-rpath,{LIBDIR}", "-o", HOST])
+    return HOST
+
+
+def test_host_builds_against_the_header_and_library():
+    assert os.path.exists(build_host())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_hint", [0, 1])
+def test_c_host_matches_the_oracle(use_hint, device, tmp_path):
+    sc = make_scene(**CASES["basic_d3"])
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    P, M, H, W = sc["means3D"].shape[0], sc["shs"].shape[1], sc["H"], sc["W"]
+    cam = sc["cam"]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([P, M, H, W, sc["D"], use_hint], np.int32).tofile(f)
+        np.array([sc["tanfovx"], sc["tanfovy"], sc["scale_modifier"]], np.float32).tofile(f)
+        for a in (sc["bg"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], sc["means3D"], sc["shs"],
+                  sc["opacities"], sc["scales"], sc["rotations"], sc["dL_dpix"]):
+            np.ascontiguousarray(a, dtype=np.float32).tofile(f)
+    out = subprocess.run([build_host(), fin, fout], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert f"N={ref['N']}" in out.stdout
+    raw = open(fout, "rb").read()
+    assert int(np.frombuffer(raw, np.int64, 1)[0]) == ref["N"]
+    off = 8
+
+    def take(n, dt=np.float32):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += a.nbytes
+        return a
+
+    color = take(3 * H * W).reshape(3, H, W)
+    radii = take(P, np.int32)
+    assert np.array_equal(radii, ref["radii"])
+    d = np.abs(color.astype(np.float64) - ref["color"])
+    assert d.max() <= 2.0 / 255 and (d <= 1e-4).mean() >= 0.9998
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b.reshape(a.shape)) / max(np.linalg.norm(b), 1e-30)
+    for name, n, r in (("means3D", 3 * P, refg["means3D"]), ("means2D", 3 * P, refg["means2D"]), ("opacities", P, refg["opacities"]),
+                       ("shs", 3 * M * P, refg["shs"]), ("scales", 3 * P, refg["scales"]), ("rotations", 4 * P, refg["rotations"])):
+        assert rel(take(n), r) <= 1e-3, name
+    assert off == len(raw)

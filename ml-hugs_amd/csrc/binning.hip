@@ -1,15 +1,16 @@
 // Tile binning (scan, key emission, sort, tile ranges), restructured for MI355X:
 //
-//   K1 (preprocess.hip) counts, with fire-and-forget atomics, how many Gaussians touch every tile
-//   tile_scan   one workgroup: exclusive scan of the tile counts -> ranges[tile] = [start,end), N = total
-//   emit        wave-balanced: every (Gaussian, tile) pair takes a slot of its tile's segment with a returning
-//               atomic and stores (quad coverage mask << 28 | Gaussian index) there          -- a bucket scatter
-//   tile_sort   one workgroup per tile: bitonic sort of the segment in LDS by (fp32 depth bits, Gaussian index)
-//               ... and, while the segment is at hand, writes the tile's compacted per-quad lists for the blend kernels
+//   count       per-tile population: a 1024-Gaussian workgroup counts into an LDS array, flushed with coalesced atomics
+//   tile_scan   one workgroup: exclusive scan of the tile counts -> ranges[tile] = [start,end), N = total (published
+//               to the host from the kernel), the capacity gate, the list of long tiles
+//   emit        every (Gaussian, tile) pair takes a slot of its tile's segment and stores its 64-bit sort key
+//               (depth bits << 32 | Gaussian << 4 | quad coverage mask) there                     -- a bucket scatter
+//   tile_sort   one workgroup per tile: bitonic sort of the segment in registers (LDS for long tiles) by (fp32 depth
+//               bits, Gaussian index) and, while the segment is at hand, the tile's compacted per-quad lists
 //
 // The result is, for every tile, exactly the order a stable sort of the 64-bit keys (tile << 32 | depth bits)
 // produces (ties: ascending Gaussian index) -- bit-identical to the oracle's sorted list -- without ever moving a
-// 64-bit key through a multi-pass global radix sort: ~36 B per entry of HBM traffic instead of ~160 B, and 6 kernel
+// 64-bit key through a multi-pass global radix sort: ~36 B per entry of HBM traffic instead of ~160 B, and 5 kernel
 // launches instead of 20.  The slot order inside a segment before sorting is arbitrary (atomics); the per-tile
 // sort is on a total order, so the output is deterministic.
 #include "hgs_common.h"
@@ -27,25 +28,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
         if (lane >= d) v += n;
     }
     return v;
-}
-
-// inclusive scan over a 256-thread block of one value per thread; returns the inclusive value and the
-// block total through `total`. `wsum` is a 4-entry LDS array.
-__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wsum, uint32_t& total)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = wave_inclusive_scan(v);
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t s = wsum[k];
-        if (k < w) base += s;
-    }
-    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    return inc + base;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,17 +11,21 @@
 //  * The walk is software pipelined with two SGPR register sets: while one pair of entries is blended, the next
 //    pair's records and the pair of entries after that are in flight (scalar loads return out of order, so the
 //    single lgkmcnt(0) sits at the top of the half-iteration, before new loads are issued).
+//  * log2 domain: the record holds log2e-scaled half-conics and log2(opacity), so alpha is one v_exp_f32 of a five-op
+//    quadratic, with no multiply before or after the transcendental.
 //  * Forward: a 16x16 tile is one 256-thread workgroup = 4 independent wave64s, one per quad; the per-pixel
 //    update is fully predicated (v_cndmask), the "done" flag is the sign bit of T, early-out is per wave.
 //  * Backward: ONE wave per tile; a lane owns four pixels, one in each quad, and the entry's quad mask selects
-//    with scalar branches which of the four per-pixel evaluations run.  The nine partial sums of all covered
-//    quads are added in registers, so there is one cross-lane reduction -- a butterfly transpose-reduce (quad_perm
-//    / row_shl / row_shr / row_ror DPP + two cross-row shuffles) that leaves the nine totals in nine lanes -- and
-//    ONE global_atomic_add_f32 instruction per (tile, entry) into a contiguous [P][12] accumulator record.
+//    with scalar branches which of the four per-pixel evaluations run.  Per pixel only (T, S) are carried, S being
+//    everything composited behind the entry dotted with dL/dpixel; per Gaussian nine RAW sums are accumulated (moments
+//    of u = alpha_uncapped dL/dalpha, and the colour sums) -- the per-Gaussian factors are applied once per Gaussian by
+//    preprocess_backward_kernel.  The nine partial sums of all covered quads are added in registers, so there is one
+//    cross-lane reduction per (tile, entry) -- a transpose-reduce on gfx950's v_permlane32_swap / v_permlane16_swap
+//    plus DPP adds that leaves the nine totals in nine lanes -- and ONE global_atomic_add_f32 instruction into a
+//    contiguous [P][12] accumulator record.
 //
-// Compiled with -ffp-contract=off (and -fno-slp-vectorize: packed f32 ops issue at half rate on gfx950, so SLP
-// packing only adds register shuffles); the FMAs below are explicit so forward and backward evaluate alpha with
-// the identical instruction sequence (backward must re-take forward's skip decisions).
+// Compiled with -ffp-contract=off and -fno-slp-vectorize; the FMAs below are explicit so forward and backward
+// evaluate alpha with the identical instruction sequence (backward must re-take forward's skip decisions).
 #include "hgs_common.h"
 
 namespace hgs {

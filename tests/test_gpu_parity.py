@@ -259,6 +259,35 @@ def test_two_frames_in_flight_on_two_streams(device):
             assert rel_l2(m.grad.cpu().numpy(), g0.cpu().numpy()) <= 1e-5
 
 
+def test_non_finite_inputs_are_culled_like_the_oracle_and_poison_nothing(device):
+    """NaN / Inf in a few Gaussians (a diverged optimiser step): they must drop out exactly as in the oracle, and every
+    other Gaussian's image contribution and gradients must be untouched (no hang, no NaN leaking through atomics)."""
+    sc = make_scene(**CASES["basic_d3"])
+    P = sc["means3D"].shape[0]
+    sc["means3D"][5, 0] = np.nan
+    sc["means3D"][17] = np.inf
+    sc["scales"][33, 1] = np.nan
+    sc["rotations"][40] = 0.0                     # zero quaternion: zero covariance + the 0.3 dilation
+    sc["opacities"][50] = 0.0
+    sc["scales"][61] = 1.0e20                     # absurd radius
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    t, color, radii = run_gpu(sc, device)
+    color.backward(to_dev(sc["dL_dpix"], device))
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    for dead in (5, 17, 33):
+        assert int(radii[dead]) == 0
+    check_image(color.detach().cpu().numpy(), ref["color"], "non-finite inputs")
+    clean = np.ones(P, bool)
+    clean[[5, 17, 33, 61]] = False
+    for k, r in (("means3D", refg["means3D"]), ("opacities", refg["opacities"]), ("shs", refg["shs"]), ("scales", refg["scales"])):
+        g = t[k].grad.cpu().numpy()
+        assert np.isfinite(g[clean]).all(), k
+        assert rel_l2(g[clean], r.reshape(g.shape)[clean]) <= GRAD_REL_TOL, k
+
+
 def test_api_errors(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(**CASES["single"])

@@ -575,10 +575,11 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     const uint32_t tile = large_tiles[li];
     const uint2 rg = ranges[tile];
     const uint32_t s = rg.x, n = rg.y - rg.x;
-    if (n <= (uint32_t)CAP) {
+    // bitonic sort of up to CAP keys in LDS; `count` keys from `src`, result left in sh[0..count)
+    auto sort_in_lds = [&](const uint64_t* src, uint32_t count) {
         uint32_t m = 2;
-        while (m < n) m <<= 1;
-        for (uint32_t i = threadIdx.x; i < m; i += SORT_LARGE_THREADS) sh[i] = i < n ? keys[s + i] : ~0ull;
+        while (m < count) m <<= 1;
+        for (uint32_t i = threadIdx.x; i < m; i += SORT_LARGE_THREADS) sh[i] = i < count ? src[i] : ~0ull;
         __syncthreads();
         for (uint32_t k = 2; k <= m; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -589,15 +590,36 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                 }
                 __syncthreads();
             }
+    };
+    if (n <= (uint32_t)CAP) {
+        sort_in_lds(keys + s, n);
         for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) list[s + i] = list_entry(sh[i], i + 1u);
     } else {
-        // rank every key against all others (keys are distinct: they embed the Gaussian index)
-        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) scratch[s + i] = keys[s + i];
-        __syncthreads();
+        // Longer than LDS: sort CAP-sized chunks in LDS into `scratch`, then every key finds its final position as its
+        // index in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are
+        // distinct: they embed the Gaussian index).  O(n (n/CAP) log CAP) instead of a global merge network.
+        const uint32_t chunks = (n + CAP - 1u) / CAP;
+        for (uint32_t c = 0; c < chunks; ++c) {
+            const uint32_t c0 = c * CAP, cn = min((uint32_t)CAP, n - c0);
+            sort_in_lds(keys + s + c0, cn);
+            for (uint32_t i = threadIdx.x; i < cn; i += SORT_LARGE_THREADS) scratch[s + c0 + i] = sh[i];
+            __syncthreads();
+        }
+        __threadfence_block();
         for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) {
-            const uint64_t ki = scratch[s + i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) rank += scratch[s + j] < ki ? 1u : 0u;
+            const uint64_t ki = __builtin_nontemporal_load(&scratch[s + i]);
+            const uint32_t own = i / CAP;
+            uint32_t rank = i - own * CAP;
+            for (uint32_t c = 0; c < chunks; ++c) {
+                if (c == own) continue;
+                const uint64_t* ch = scratch + s + c * CAP;
+                uint32_t lo = 0, hi = min((uint32_t)CAP, n - c * CAP);  // first index whose key is >= ki
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (__builtin_nontemporal_load(&ch[mid]) < ki) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
             list[s + rank] = list_entry(ki, rank + 1u);
         }
     }

@@ -14,6 +14,7 @@ the behaviours the trainer relies on:
     per model                                                                    (:32-52,68-98)
 """
 import math
+import os
 
 import torch
 
@@ -37,19 +38,50 @@ def _gather(human_gs_out, scene_gs_out, render_mode):
     return out
 
 
+# The joint render and the separate human-only render of one training step (gs_renderer.py:56 and :69) are independent:
+# the second one goes to a side HIP stream, so that its latency-bound binning overlaps the first one's blending (forward
+# and, through autograd's stream bookkeeping, backward too).  Same results; HGS_CONCURRENT_RENDERS=0 turns it off.
+_CONCURRENT_RENDERS = os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    if device not in _side_streams:
+        _side_streams[device] = torch.cuda.Stream(device)
+    return _side_streams[device]
+
+
 def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_color=None, scaling_modifier=1.0,
                        render_mode="human_scene", render_human_separate=False):
     g = _gather(human_gs_out, scene_gs_out, render_mode)
+    separate = render_human_separate and render_mode == "human_scene"
+    human_pkg = None
+
+    def human_only():
+        h = _gather(human_gs_out, None, "human")
+        return render(means3D=h["means3D"], feats=h["feats"], opacity=h["opacity"], scales=h["scales"],
+                      rotations=h["rotations"], data=data, scaling_modifier=scaling_modifier,
+                      bg_color=human_bg_color if human_bg_color is not None else bg_color,
+                      active_sh_degree=h["active_sh_degree"])
+
+    device = g["means3D"].device
+    side = main = None
+    if separate and _CONCURRENT_RENDERS and device.type == "cuda":
+        main, side = torch.cuda.current_stream(device), _side_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            human_pkg = human_only()
     pkg = render(means3D=g["means3D"], feats=g["feats"], opacity=g["opacity"], scales=g["scales"],
                  rotations=g["rotations"], data=data, scaling_modifier=scaling_modifier, bg_color=bg_color,
                  active_sh_degree=g["active_sh_degree"])
 
-    if render_human_separate and render_mode == "human_scene":
-        h = _gather(human_gs_out, None, "human")
-        human_pkg = render(means3D=h["means3D"], feats=h["feats"], opacity=h["opacity"], scales=h["scales"],
-                           rotations=h["rotations"], data=data, scaling_modifier=scaling_modifier,
-                           bg_color=human_bg_color if human_bg_color is not None else bg_color,
-                           active_sh_degree=h["active_sh_degree"])
+    if separate:
+        if human_pkg is None:
+            human_pkg = human_only()
+        else:
+            main.wait_stream(side)
+            for t in (human_pkg["render"], human_pkg["radii"], human_pkg["visibility_filter"]):
+                t.record_stream(main)  # allocated on the side stream, consumed on the caller's
         pkg["human_img"] = human_pkg["render"]
         pkg["human_visibility_filter"] = human_pkg["visibility_filter"]
         pkg["human_radii"] = human_pkg["radii"]

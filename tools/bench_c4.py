@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BASELINE config C4 as a timing: one HUGS training step's rasterizer work -- the joint human+scene render (110 210 +
+200 000 Gaussians, 1080p, SH degree 0 taken from the human model) and the separate human-only render, one backward
+through both (gs_renderer.py:56,69; hugs_human_scene.yaml humansep_w).  Prints one JSON line.
+HGS_CONCURRENT_RENDERS=0/1 (read at import) selects whether the second render runs on a side stream."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+from hugs_amd import synthetic as syn                      # noqa: E402
+from hugs_amd.renderer import render_human_scene           # noqa: E402
+
+
+def main(steps=100, warmup=15):
+    dev = torch.device("cuda:0")
+    H, W = 1080, 1920
+    cam = syn.pinhole_camera(H, W)
+    rng = np.random.default_rng(7)
+    Ph, Ps = 110_210, 200_000
+    hm = {"xyz": (rng.standard_normal((Ph, 3)) * np.array([0.22, 0.55, 0.14]) + np.array([0, 0, 4.0])).astype(np.float32),
+          "scales": (0.035 / math.sqrt(Ph / 6890.0) * np.exp(0.3 * rng.standard_normal((Ph, 3)))).astype(np.float32),
+          "rotq": rng.standard_normal((Ph, 4)).astype(np.float32), "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32),
+          "opacity": rng.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
+    g = syn.scene_gaussians(Ps, cam, seed=8, sigma_px=4.0)
+    sm = {"xyz": g["means3D"], "scales": g["scales"], "rotq": g["rotations"], "shs": g["shs"], "opacity": g["opacities"]}
+    t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
+    human = {k: t(v, True) for k, v in hm.items()}
+    scene = {k: t(v, True) for k, v in sm.items()}
+    human["active_sh_degree"], scene["active_sh_degree"] = 0, 3
+    data = {k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    bg, hbg = torch.ones(3, device=dev), torch.zeros(3, device=dev)
+    w1 = t(rng.standard_normal((3, H, W)) * 1e-3)
+    w2 = t(rng.standard_normal((3, H, W)) * 1e-3)
+    leaves = [v for m in (human, scene) for v in m.values() if isinstance(v, torch.Tensor)]
+
+    def step():
+        pkg = render_human_scene(data, human, scene, bg_color=bg, human_bg_color=hbg, render_mode="human_scene",
+                                 render_human_separate=True)
+        ((pkg["render"] * w1).sum() + (pkg["human_img"] * w2).sum()).backward()
+        for x in leaves:
+            x.grad = None
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(json.dumps({"workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
+                      "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
+                      "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1)}))
+
+
+if __name__ == "__main__":
+    main()

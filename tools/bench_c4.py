@@ -26,8 +26,10 @@ def main(steps=100, warmup=15):
     Ph, Ps = 110_210, 200_000
     hm = {"xyz": (rng.standard_normal((Ph, 3)) * np.array([0.22, 0.55, 0.14]) + np.array([0, 0, 4.0])).astype(np.float32),
           "scales": (0.035 / math.sqrt(Ph / 6890.0) * np.exp(0.3 * rng.standard_normal((Ph, 3)))).astype(np.float32),
-          "rotq": rng.standard_normal((Ph, 4)).astype(np.float32), "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32),
+          "rotq": None, "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32),
           "opacity": rng.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
+    q = rng.standard_normal((Ph, 4))
+    hm["rotq"] = (q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.8, 1.2, (Ph, 1))).astype(np.float32)  # non-unit, as HUGS feeds
     g = syn.scene_gaussians(Ps, cam, seed=8, sigma_px=4.0)
     sm = {"xyz": g["means3D"], "scales": g["scales"], "rotq": g["rotations"], "shs": g["shs"], "opacity": g["opacities"]}
     t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
@@ -55,7 +57,14 @@ def main(steps=100, warmup=15):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({"workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
+    from diff_gaussian_rasterization import profile_enable, profile_read
+    profile_enable()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    stages = {k: round(v[0] / 5.0, 4) for k, v in profile_read().items()}
+    profile_enable(())
+    print(json.dumps({"stages_ms_both_renders": stages, "workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
                       "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
                       "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1)}))
 

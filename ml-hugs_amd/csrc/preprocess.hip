@@ -95,6 +95,17 @@ __device__ __forceinline__ void ewa_project(const float* pv, const Camera& cam, 
     e.c = (e.T10 * u10 + e.T11 * u11 + e.T12 * u12) + 0.3f;
 }
 
+// colour = sum_k B[k] * sh[k], the same left-to-right summation order for every K (bit-exact against the oracle)
+template <int K>
+__device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __restrict__ sh, float& a0, float& a1, float& a2)
+{
+    float c[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) c[k][0] = sh[3 * k], c[k][1] = sh[3 * k + 1], c[k][2] = sh[3 * k + 2];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a0 += B[k] * c[k][0], a1 += B[k] * c[k][1], a2 += B[k] * c[k][2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: one thread per Gaussian.
 __global__ void __launch_bounds__(256)
@@ -183,12 +194,14 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                     float B[16];
                     sh_basis(cam.D, dx, dy, dz, B);
                     const float* sh = shs + (size_t)i * cam.M * 3;
-                    const int K = (cam.D + 1) * (cam.D + 1);
                     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
-                    for (int k = 0; k < K; ++k) {
-                        acc0 += B[k] * sh[3 * k];
-                        acc1 += B[k] * sh[3 * k + 1];
-                        acc2 += B[k] * sh[3 * k + 2];
+                    // the number of coefficients is a compile-time constant inside each case, so all their loads are
+                    // issued before the first is waited for (a runtime trip count made it one round trip per coefficient)
+                    switch (cam.D) {
+                        case 0: sh_dot<1>(B, sh, acc0, acc1, acc2); break;
+                        case 1: sh_dot<4>(B, sh, acc0, acc1, acc2); break;
+                        case 2: sh_dot<9>(B, sh, acc0, acc1, acc2); break;
+                        default: sh_dot<16>(B, sh, acc0, acc1, acc2); break;
                     }
                     acc0 += 0.5f, acc1 += 0.5f, acc2 += 0.5f;
                     out.clamped = (acc0 < 0.0f ? 1u : 0u) | (acc1 < 0.0f ? 2u : 0u) | (acc2 < 0.0f ? 4u : 0u);

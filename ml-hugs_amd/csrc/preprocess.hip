@@ -95,6 +95,22 @@ __device__ __forceinline__ void ewa_project(const float* pv, const Camera& cam, 
     e.c = (e.T10 * u10 + e.T11 * u11 + e.T12 * u12) + 0.3f;
 }
 
+template <int K>
+__device__ __forceinline__ void sh_backward_rows(const float (&B)[16], const float* __restrict__ sh, float* __restrict__ dsh,
+                                                 float dr0, float dr1, float dr2, float (&shw)[16])
+{
+    float c[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) c[k][0] = sh[3 * k], c[k][1] = sh[3 * k + 1], c[k][2] = sh[3 * k + 2];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        shw[k] = c[k][0] * dr0 + c[k][1] * dr1 + c[k][2] * dr2;
+        dsh[3 * k] = B[k] * dr0, dsh[3 * k + 1] = B[k] * dr1, dsh[3 * k + 2] = B[k] * dr2;
+    }
+#pragma unroll
+    for (int k = K; k < 16; ++k) shw[k] = 0.0f;
+}
+
 // colour = sum_k B[k] * sh[k], the same left-to-right summation order for every K (bit-exact against the oracle)
 template <int K>
 __device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __restrict__ sh, float& a0, float& a1, float& a2)
@@ -374,14 +390,18 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         float B[16];
         sh_basis(D, X, Y, Z, B);
         const int K = (D + 1) * (D + 1);
-        for (int k = 0; k < K; ++k) {
-            dsh[3 * k] = B[k] * dr0;
-            dsh[3 * k + 1] = B[k] * dr1;
-            dsh[3 * k + 2] = B[k] * dr2;
+        // shw[k] = sh[k] . dL/dcolour for the direction gradient, and dL/dsh[k] = B[k] dL/dcolour: the coefficient count
+        // is a compile-time constant inside each case, so all loads are in flight together (see sh_dot)
+        float shw[16];
+        switch (D) {
+            case 0: sh_backward_rows<1>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+            case 1: sh_backward_rows<4>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+            case 2: sh_backward_rows<9>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+            default: sh_backward_rows<16>(B, sh, dsh, dr0, dr1, dr2, shw); break;
         }
         for (int k = 3 * K; k < 3 * cam.M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
-#define SHW(k) (sh[3 * (k)] * dr0 + sh[3 * (k) + 1] * dr1 + sh[3 * (k) + 2] * dr2)
+#define SHW(k) shw[k]
         if (D > 0) {
             const float c1 = (float)0.4886025119029199;
             ddy += -c1 * SHW(1);

@@ -275,20 +275,30 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
 
     PixBwd p[4];
     uint32_t wmax = 0;
+    // all twenty per-pixel loads are issued before any is consumed: out-of-image pixels read a clamped address and are
+    // masked afterwards (a load under `if (inside)` costs one memory round trip per branch)
+    float ld_T[4], ld_g[4][3];
+    uint32_t ld_n[4];
+    bool in_img[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = tx * TILE + (k & 1) * 8 + (lane & 7);
         const int py = ty * TILE + (k >> 1) * 8 + (lane >> 3);
-        const bool inside = px < cam.W && py < cam.H;
-        const size_t pix = (size_t)py * cam.W + px;
-        const float Tf = inside ? final_T[pix] : 0.0f;
+        in_img[k] = px < cam.W && py < cam.H;
+        const size_t pix = in_img[k] ? (size_t)py * cam.W + px : 0;
         p[k].pxf = (float)px, p[k].pyf = (float)py;
+        ld_T[k] = final_T[pix], ld_n[k] = n_contrib[pix];
+        ld_g[k][0] = dL_dpix[pix], ld_g[k][1] = dL_dpix[HW + pix], ld_g[k][2] = dL_dpix[2 * HW + pix];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float Tf = in_img[k] ? ld_T[k] : 0.0f;
         p[k].T = Tf;
-        p[k].g0 = inside ? dL_dpix[pix] : 0.0f;
-        p[k].g1 = inside ? dL_dpix[HW + pix] : 0.0f;
-        p[k].g2 = inside ? dL_dpix[2 * HW + pix] : 0.0f;
+        p[k].g0 = in_img[k] ? ld_g[k][0] : 0.0f;
+        p[k].g1 = in_img[k] ? ld_g[k][1] : 0.0f;
+        p[k].g2 = in_img[k] ? ld_g[k][2] : 0.0f;
         p[k].S = Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
-        p[k].last_contributor = inside ? n_contrib[pix] : 0u;
+        p[k].last_contributor = in_img[k] ? ld_n[k] : 0u;
         wmax = max(wmax, p[k].last_contributor);
     }
     // the wave starts at the deepest entry any of its pixels composited

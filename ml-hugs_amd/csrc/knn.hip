@@ -148,7 +148,8 @@ lbsweight_top_k_kernel(int n, const float* __restrict__ points, int m, const flo
     for (int k = 0; k < K; ++k) {
         const float* wk = lbs_weights + (size_t)best.i[k] * J;
         float l1 = 0.0f;
-        for (int j = 0; j < J; ++j) l1 += fabsf(wk[j] - w0[j]);
+#pragma unroll 8
+        for (int j = 0; j < J; ++j) l1 += fabsf(wk[j] - w0[j]);  // unrolled: eight rows' loads in flight per trip
         const float conf = expf(-l1 / weight_std2) > 0.9f ? 1.0f : 0.0f;
         wgt[k] = expf(-best.d[k]) * conf;
         sum += wgt[k];
@@ -160,6 +161,7 @@ lbsweight_top_k_kernel(int n, const float* __restrict__ points, int m, const flo
         dist += wgt[k] * best.d[k];
     }
     out_dist[i] = dist;
+#pragma unroll 4
     for (int j = 0; j < J; ++j) {
         float acc = 0.0f;
 #pragma unroll

@@ -65,12 +65,21 @@ __device__ __forceinline__ void scan_template(float px, float py, float pz, cons
 {
     best.init();
     const int j4 = j0 + ((j1 - j0) & ~3);
-    for (int j = j0; j < j4; j += 4) {  // 4 vertices = 12 floats = three aligned 16-byte scalar loads
-        const_f4p q = (const_f4p)(templ + 3 * (size_t)j);
-        const v4f a = q[0], b = q[1], c = q[2];
+    // 4 vertices = 12 floats = three aligned 16-byte scalar loads; the next trip's loads are issued before this trip's
+    // arithmetic (two register sets), so the scalar-cache latency runs under it
+    v4f a, b, c;
+    if (j0 < j4) {
+        const_f4p q = (const_f4p)(templ + 3 * (size_t)j0);
+        a = q[0], b = q[1], c = q[2];
+    }
+    for (int j = j0; j < j4; j += 4) {
+        const int jn = j + 4 < j4 ? j + 4 : j;  // last trip: reload the same vertices (harmless)
+        const_f4p qn = (const_f4p)(templ + 3 * (size_t)jn);
+        const v4f an = qn[0], bn = qn[1], cn = qn[2];
         // four independent distance chains and one wave-level test for "nobody improves", the usual case
         float d0 = sqdist(px, py, pz, a.x, a.y, a.z), d1 = sqdist(px, py, pz, a.w, b.x, b.y);
         float d2 = sqdist(px, py, pz, b.z, b.w, c.x), d3 = sqdist(px, py, pz, c.y, c.z, c.w);
+        a = an, b = bn, c = cn;
         if ((skip & ~3) == j) {  // at most one trip per lane
             const float inf = __builtin_inff();
             d0 = skip == j ? inf : d0, d1 = skip == j + 1 ? inf : d1, d2 = skip == j + 2 ? inf : d2, d3 = skip == j + 3 ? inf : d3;

@@ -26,6 +26,8 @@
 //
 // Compiled with -ffp-contract=off and -fno-slp-vectorize; the FMAs below are explicit so forward and backward
 // evaluate alpha with the identical instruction sequence (backward must re-take forward's skip decisions).
+#include <cstdlib>
+
 #include "hgs_common.h"
 
 namespace hgs {
@@ -251,10 +253,14 @@ __device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
     }
 }
 
-// One wave per tile (four tiles per 256-thread workgroup, no LDS, no barrier).  A lane's four pixels sit in
+// NQ = 4: one wave per tile (four tiles per 256-thread workgroup, no LDS, no barrier).  A lane's four pixels sit in
 // the four quads, so the quad coverage mask of a list entry decides -- with scalar branches -- which of the
 // four per-pixel evaluations run at all, while the nine partial sums of ALL covered quads are added up in
 // registers before the single cross-lane reduction + atomic of that (tile, entry) pair.
+// NQ = 1: one wave per QUAD (a tile is one workgroup), walking the quad's own compacted list: four times the waves,
+// one reduction per (quad, entry) instead of per (tile, entry) -- more instructions in total, so it only pays when the
+// frame has too few tiles to occupy the SIMDs (a 512x512 human-only render has 1 024 tiles for 1 024 SIMDs).
+template <int NQ>
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                       size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -264,26 +270,28 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     const int num_tiles = cam.gx * cam.gy;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int vbid = blockIdx.x * 4 + w;
+    const int vbid = NQ == 4 ? blockIdx.x * 4 + w : (int)blockIdx.x;
     if (vbid >= num_tiles) return;
     const int tile = remap_tile(vbid, num_tiles);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const v2u range = ((const_u2p)ranges)[tile];
     if (range.y <= range.x) return;
+    const int list_id = NQ == 4 ? 4 : w;  // the "any quad" list, or this wave's quad's
     const size_t HW = (size_t)cam.H * cam.W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    PixBwd p[4];
+    PixBwd p[NQ];
     uint32_t wmax = 0;
     // all twenty per-pixel loads are issued before any is consumed: out-of-image pixels read a clamped address and are
     // masked afterwards (a load under `if (inside)` costs one memory round trip per branch)
-    float ld_T[4], ld_g[4][3];
-    uint32_t ld_n[4];
-    bool in_img[4];
+    float ld_T[NQ], ld_g[NQ][3];
+    uint32_t ld_n[NQ];
+    bool in_img[NQ];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int px = tx * TILE + (k & 1) * 8 + (lane & 7);
-        const int py = ty * TILE + (k >> 1) * 8 + (lane >> 3);
+    for (int k = 0; k < NQ; ++k) {
+        const int quad = NQ == 4 ? k : w;
+        const int px = tx * TILE + (quad & 1) * 8 + (lane & 7);
+        const int py = ty * TILE + (quad >> 1) * 8 + (lane >> 3);
         in_img[k] = px < cam.W && py < cam.H;
         const size_t pix = in_img[k] ? (size_t)py * cam.W + px : 0;
         p[k].pxf = (float)px, p[k].pyf = (float)py;
@@ -291,7 +299,7 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
         ld_g[k][0] = dL_dpix[pix], ld_g[k][1] = dL_dpix[HW + pix], ld_g[k][2] = dL_dpix[2 * HW + pix];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const float Tf = in_img[k] ? ld_T[k] : 0.0f;
         p[k].T = Tf;
         p[k].g0 = in_img[k] ? ld_g[k][0] : 0.0f;
@@ -314,20 +322,25 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
 
     // entries of this tile that cover at least one quad (list 4), walked back to front; those beyond the deepest
     // position any pixel composited (pos1 > wmax) are skipped with a scalar branch
-    const uint32_t n = ((const_u32p)act_count)[tile * NUM_LISTS + 4];
+    const uint32_t n = ((const_u32p)act_count)[tile * NUM_LISTS + list_id];
     if (n == 0) return;
-    const uint64_t* top = act + 4 * act_stride + range.x + n;  // one past the deepest entry
+    const uint64_t* top = act + (size_t)list_id * act_stride + range.x + n;  // one past the deepest entry
 
     auto backward_entry = [&](const SplatRec& s, uint32_t val, uint32_t pos1) {
         if (pos1 > wmax) return;
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         uint32_t contributed = 0u;
+        if constexpr (NQ == 4) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (((val >> (GID_BITS + 2 * r)) & 3u) == 0u) continue;
-            const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
-            if ((val >> (GID_BITS + 2 * r)) & 1u) bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v, contributed);
-            if ((val >> (GID_BITS + 2 * r + 1)) & 1u) bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v, contributed);
+            for (int r = 0; r < 2; ++r) {
+                if (((val >> (GID_BITS + 2 * r)) & 3u) == 0u) continue;
+                const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
+                if ((val >> (GID_BITS + 2 * r)) & 1u) bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v, contributed);
+                if ((val >> (GID_BITS + 2 * r + 1)) & 1u) bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v, contributed);
+            }
+        } else {  // every entry of a quad's list covers the quad
+            const float dy = s.y - p[0].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
+            bwd_pixel(s, pos1, p[0], dy, bdy, q, v, contributed);
         }
         if (__builtin_amdgcn_ballot_w64(contributed != 0u) == 0ull) return;
         // ---- transpose-reduce of v0..v7 over the wave: each step adds partner lanes AND halves the number of live
@@ -379,8 +392,17 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
                            const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3((cam.gx * cam.gy + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
-                       act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+    // a wave per tile keeps the instruction count lowest; with fewer tiles than ~4 waves per SIMD the GPU would sit
+    // mostly idle, so small frames give every quad its own wave
+    const int num_tiles = cam.gx * cam.gy;
+    static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
+    const bool per_quad = force ? force[0] == '4' : num_tiles < 4096;
+    if (per_quad)
+        hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(num_tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
+                           act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((num_tiles + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
+                           act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
 }  // namespace hgs

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""BASELINE config C3 as a timing: the HUGS human-only workload -- 110 210 Gaussians (SMPL, n_subdivision 2) at 512x512,
+SH degree 0 on [P,16,3] storage, the canonical rotating-camera rig (dist 5, fov 0.4; gs_trainer.py:207-211), forward +
+backward through the renderer adapter.  Prints one JSON line with per-stage times."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+from diff_gaussian_rasterization import profile_enable, profile_read   # noqa: E402
+from hugs_amd import synthetic as syn                                    # noqa: E402
+from hugs_amd.renderer import render_human_scene                         # noqa: E402
+
+
+def main(P=110_210, steps=200, warmup=20):
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((P, 4))
+    m = {"xyz": (rng.standard_normal((P, 3)) * np.array([0.22, 0.55, 0.14])).astype(np.float32),
+         "scales": (0.035 / math.sqrt(P / 6890.0) * np.exp(0.3 * rng.standard_normal((P, 3)))).astype(np.float32),
+         "rotq": (q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.8, 1.2, (P, 1))).astype(np.float32),
+         "shs": (0.3 * rng.standard_normal((P, 16, 3))).astype(np.float32), "opacity": rng.uniform(0.05, 1.0, (P, 1)).astype(np.float32)}
+    t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
+    human = {k: t(v, True) for k, v in m.items()}
+    human["active_sh_degree"] = 0
+    cam = syn.rotating_camera(3, 10, dist=5.0, fov=0.4, img_size=512)
+    data = {k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    bg = torch.ones(3, device=dev)
+    w = t(rng.standard_normal((3, 512, 512)) * 1e-3)
+    leaves = [v for v in human.values() if isinstance(v, torch.Tensor)]
+
+    def step():
+        pkg = render_human_scene(data, human, None, bg_color=bg, render_mode="human")
+        pkg["render"].backward(w)
+        for x in leaves:
+            x.grad = None
+        return pkg
+
+    for _ in range(warmup):
+        pkg = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    profile_enable()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    stages = {k: round(v[0] / 10.0, 4) for k, v in profile_read().items()}
+    profile_enable(())
+    print(json.dumps({"workload": f"C3: {P} human Gaussians, 512x512, degree 0, rotating rig, fwd+bwd", "ms_per_step": round(ms, 4),
+                      "fps": round(1e3 / ms, 1), "num_rendered_N": int(pkg["render"].grad_fn is not None and 0) or None,
+                      "visible": int(pkg["visibility_filter"].sum()), "stages_ms": stages}))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 2
+#define HGS_ABI_VERSION 3
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
@@ -100,6 +100,8 @@ typedef struct hgs_forward_state {
     void *image;   size_t image_bytes;
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
+    int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad its own wave */
+    int32_t reserved;
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // oracle leaves them); cursor[t] = start of the tile's segment; n_total[0] = N; n_total[1] = (N > capacity), the gate
 // that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
 // too small (hgs_api.hip).  N is also published to the host, straight from this kernel, as ONE 64-bit system-scope
-// store (ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
+// store (sparse bit << 63 | ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
 constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
 
 __global__ void __launch_bounds__(1024)
@@ -44,8 +44,8 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
                  uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t n_large;
-    if (threadIdx.x == 0) n_large = 0;
+    __shared__ uint32_t n_large, n_nonempty;
+    if (threadIdx.x == 0) n_large = 0, n_nonempty = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
@@ -69,12 +69,18 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
             cursor[t] = start;
             if (c > (uint32_t)SORT_CAP_SMALL) large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)t;  // rare
         }
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(c != 0u);
+        if (lane == 0 && ne) atomicAdd(&n_nonempty, (uint32_t)__popcll(ne));
         carry += total;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u, n_total[2] = n_large;
-        __hip_atomic_store(host_slot, ((unsigned long long)ticket << 32) | carry, __ATOMIC_RELEASE,
+        // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
+        // the backward blend then splits long tiles over four waves
+        const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
+        n_total[3] = sparse;
+        __hip_atomic_store(host_slot, ((unsigned long long)((sparse << 31) | ticket) << 32) | carry, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

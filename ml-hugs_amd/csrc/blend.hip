@@ -261,21 +261,14 @@ __device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
 // one reduction per (quad, entry) instead of per (tile, entry) -- more instructions in total, so it only pays when the
 // frame has too few tiles to occupy the SIMDs (a 512x512 human-only render has 1 024 tiles for 1 024 SIMDs).
 template <int NQ>
-__global__ void __launch_bounds__(256)
-blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
-                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
-                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                      float* __restrict__ grad_accum)
+__device__ __forceinline__ void
+blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u range, const uint64_t* __restrict__ act,
+                    size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats,
+                    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                    const float* __restrict__ dL_dpix, float* __restrict__ grad_accum)
 {
-    const int num_tiles = cam.gx * cam.gy;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int vbid = NQ == 4 ? blockIdx.x * 4 + w : (int)blockIdx.x;
-    if (vbid >= num_tiles) return;
-    const int tile = remap_tile(vbid, num_tiles);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const v2u range = ((const_u2p)ranges)[tile];
-    if (range.y <= range.x) return;
     const int list_id = NQ == 4 ? 4 : w;  // the "any quad" list, or this wave's quad's
     const size_t HW = (size_t)cam.H * cam.W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -388,15 +381,33 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     }
 }
 
-void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
-                           const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
+// NQ = 4: workgroup b takes tiles 4b .. 4b+3, one wave each.  NQ = 1: workgroup b takes tile b, one wave per quad -- for
+// SPARSE frames, i.e. fewer non-empty tiles than would give each of the 1 024 SIMDs four waves (decided by
+// tile_scan_kernel, travels to the host with N): a 512x512 human-only render, a person in front of an empty background.
+template <int NQ>
+__global__ void __launch_bounds__(256)
+blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats,
+                      const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                      const float* __restrict__ dL_dpix, float* __restrict__ grad_accum)
 {
-    // a wave per tile keeps the instruction count lowest; with fewer tiles than ~4 waves per SIMD the GPU would sit
-    // mostly idle, so small frames give every quad its own wave
+    const int num_tiles = cam.gx * cam.gy;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int vbid = NQ == 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + w;
+    if (vbid >= num_tiles) return;
+    const int tile = remap_tile(vbid, num_tiles);
+    const v2u range = ((const_u2p)ranges)[tile];
+    if (range.y <= range.x) return;
+    blend_backward_wave<NQ>(cam, lastg, tile, w, range, act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+}
+
+void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
+                           const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
+{
     const int num_tiles = cam.gx * cam.gy;
     static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
-    const bool per_quad = force ? force[0] == '4' : num_tiles < 4096;
+    const bool per_quad = force ? force[0] == '4' : sparse_frame;
     if (per_quad)
         hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(num_tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                            act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);

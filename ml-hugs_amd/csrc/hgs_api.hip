@@ -95,8 +95,8 @@ struct ProfScope {
     }
 };
 
-// The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes (ticket << 32 | N) and the
-// host polls: a ring of slots so that calls from several threads / streams do not collide.
+// The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes -- (sparse-frame bit << 63 |
+// 31-bit ticket << 32 | N) -- and the host polls: a ring of slots so that calls from several threads / streams do not collide.
 struct HostSlot { volatile unsigned long long* word; uint32_t ticket; };
 HostSlot host_slot()
 {
@@ -112,27 +112,27 @@ HostSlot host_slot()
         }
         memset(base, 0, RING * 64);
     }
-    ++next;
+    next = (next + 1) & 0x7FFFFFFFu;
     if (next == 0) ++next;  // ticket 0 is the initial content of a slot
     return {base + 8 * (next % RING), next};
 }
 
 // Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
 // (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
-int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out)
+int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out)
 {
     for (unsigned spins = 1;; ++spins) {
         const unsigned long long v = *hs.word;
-        if ((uint32_t)(v >> 32) == hs.ticket) {
-            *n_out = (uint32_t)v;
+        if (((uint32_t)(v >> 32) & 0x7FFFFFFFu) == hs.ticket) {
+            *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0;
             return HGS_OK;
         }
         if ((spins & 0x3FFF) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess) {
                 const unsigned long long v2 = *hs.word;
-                if ((uint32_t)(v2 >> 32) == hs.ticket) {
-                    *n_out = (uint32_t)v2;
+                if (((uint32_t)(v2 >> 32) & 0x7FFFFFFFu) == hs.ticket) {
+                    *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0;
                     return HGS_OK;
                 }
                 return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
@@ -305,9 +305,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (hint > 0)
         if (int rc = enqueue_frame(hint)) return rc;  // optimistic: the GPU runs on while the host waits for N below
     uint32_t n32 = 0;
-    if (int rc = wait_for_slot(slot, st, &n32)) return rc;
+    bool sparse = false;
+    if (int rc = wait_for_slot(slot, st, &n32, &sparse)) return rc;
     const int64_t N = (int64_t)n32;
     state->num_rendered = N;
+    state->sparse_frame = sparse ? 1 : 0;
     if (hint <= 0 || N > hint) {
         // exact size known now; after a too-small guess the gated kernels above did nothing, and the emit cursors are
         // untouched, so the frame is simply enqueued again
@@ -344,8 +346,8 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
 
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
       launch_blend_backward(cam, f.P, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
-                            bl.act_stride, (const uint32_t*)(image + il.act_count), splats, f.s.bg,
-                            (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
+                            bl.act_stride, (const uint32_t*)(image + il.act_count), a.state.sparse_frame != 0, splats,
+                            f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
                             a.grad_accum, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }

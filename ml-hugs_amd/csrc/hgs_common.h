@@ -67,7 +67,7 @@ struct ImageLayout {
         tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (zeroed by K1, count kernel adds)
         cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
         large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
-        n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles
+        n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles, [3] sparse-frame flag
         total = o;
     }
 };
@@ -113,7 +113,7 @@ void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const u
                           float* final_T, uint32_t* n_contrib, const uint32_t* gate, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
-                           const uint32_t* act_count, const Splat* splats, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
+                           const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
 
 }  // namespace hgs

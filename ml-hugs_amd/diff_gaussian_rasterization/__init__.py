@@ -27,7 +27,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 2
+_ABI_VERSION = 3
 
 
 def library_path():
@@ -54,7 +54,8 @@ class _ForwardArgs(C.Structure):
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
-                ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64)]
+                ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class _BackwardArgs(C.Structure):

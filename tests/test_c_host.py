@@ -17,7 +17,8 @@ LIBDIR = os.path.join(ROOT, "ml-hugs_amd", "lib")
 
 def build_host():
     src = HOST + ".cpp"
-    if not os.path.exists(HOST) or os.path.getmtime(HOST) < os.path.getmtime(src):
+    deps = (src, os.path.join(ROOT, "include", "hgs_rasterizer.h"), os.path.join(LIBDIR, "libhgs_rasterizer.so"))
+    if not os.path.exists(HOST) or os.path.getmtime(HOST) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-L", LIBDIR,
                                "-lhgs_rasterizer", f"-Wl,-rpath,{LIBDIR}", "-o", HOST])
     return HOST

@@ -32,7 +32,7 @@ def main():
     for P in (50_000, 100_000, 200_000, 300_000, 500_000, 1_000_000):
         row = {"gaussians": P}
         for mode, flag in (("fwd", ["--forward-only"]), ("fwd_bwd", [])):
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--steps", "100", "--warmup", "15",
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--steps", "300", "--warmup", "40",
                                 "--no-cpu-baseline", "--no-two-streams"] + flag, capture_output=True, text=True, timeout=600)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             row[mode] = {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]}

@@ -13,6 +13,8 @@
 // 64-bit key through a multi-pass global radix sort: ~36 B per entry of HBM traffic instead of ~160 B, and 5 kernel
 // launches instead of 20.  The slot order inside a segment before sorting is arbitrary (atomics); the per-tile
 // sort is on a total order, so the output is deterministic.
+#include <type_traits>
+
 #include "hgs_common.h"
 
 namespace hgs {
@@ -363,8 +365,9 @@ __device__ __forceinline__ uint64_t list_entry(uint64_t key, uint32_t pos1)
 }
 
 // Small tiles (n <= 2048, i.e. practically all of them): the bitonic network runs in REGISTERS.  Thread t holds
-// elements i = e * 256 + t (e < E = m / 256).  A compare-exchange distance j >= 256 pairs two registers of the
-// same thread; j = 64 / 128 go through LDS with barriers (3 of the 36 steps at m = 256); j < 64 pairs two lanes of a
+// elements i = e * NT + t (e < E = m / NT; NT threads: 256 in the small-tile kernel, 1024 in the long-tile kernel).  A
+// compare-exchange distance j >= NT pairs two registers of the same thread; 64 <= j < NT goes through LDS with
+// barriers (3 of the 36 steps at m = NT = 256); j < 64 pairs two lanes of a
 // wave: DPP moves for j = 1, 2 (quad_perm), 4 (row_shl:4 / row_shr:4 into complementary banks), 8 (row_ror:8),
 // ds_bpermute with precomputed addresses for 16 and 32.
 // The kernel is instruction-issue bound, so a step is kept to: fetch partner, ONE 64-bit compare, two selects.
@@ -420,16 +423,16 @@ __device__ __forceinline__ uint64_t keep_one(uint64_t a, uint64_t b, unsigned lo
            select32(take_a, (uint32_t)a, (uint32_t)b);
 }
 
-template <int E, uint32_t K, uint32_t J>
+template <int E, uint32_t NT, uint32_t K, uint32_t J>
 __device__ __forceinline__ void bitonic_step(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
 {
     const uint32_t tid = threadIdx.x;
-    if constexpr (J >= 256u) {
+    if constexpr (J >= NT) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int f = e | (int)(J >> 8);
+            const int f = e | (int)(J / NT);
             if (f != e && f < E) {
-                const bool asc = (((uint32_t)e * 256u + tid) & K) == 0u;
+                const bool asc = (((uint32_t)e * NT + tid) & K) == 0u;
                 const uint64_t a = key[e], b = key[f];
                 if ((a > b) == asc) key[e] = b, key[f] = a;
             }
@@ -437,14 +440,14 @@ __device__ __forceinline__ void bitonic_step(uint64_t (&key)[E], uint64_t* sh, u
     } else if constexpr (J >= 64u) {
         uint64_t other[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) sh[e * 256 + tid] = key[e];
+        for (int e = 0; e < E; ++e) sh[e * NT + tid] = key[e];
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; ++e) other[e] = sh[e * 256 + (tid ^ J)];
+        for (int e = 0; e < E; ++e) other[e] = sh[e * NT + (tid ^ J)];
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * 256u + tid;
+            const uint32_t i = (uint32_t)e * NT + tid;
             // bits J and K of i are both wave-uniform here (J, K >= 64)
             const bool keep_min = ((i & J) == 0u) == ((i & K) == 0u);
             key[e] = keep_one(key[e], other[e], __builtin_amdgcn_readfirstlane(keep_min) ? ~0ull : 0ull);
@@ -455,31 +458,31 @@ __device__ __forceinline__ void bitonic_step(uint64_t (&key)[E], uint64_t* sh, u
         for (int e = 0; e < E; ++e) {
             unsigned long long pk;  // lanes whose element index has bit K set
             if constexpr (K < 64u) pk = lane_bit_pattern<K>();
-            else pk = __builtin_amdgcn_readfirstlane((((uint32_t)e * 256u + tid) & K) != 0u) ? ~0ull : 0ull;
+            else pk = __builtin_amdgcn_readfirstlane((((uint32_t)e * NT + tid) & K) != 0u) ? ~0ull : 0ull;
             const unsigned long long keep_min = ~(PJ ^ pk);  // bit J == bit K
             key[e] = keep_one(key[e], partner_key<J>(key[e], addr16, addr32), keep_min);
         }
     }
 }
 
-template <int E, uint32_t K, uint32_t J>
+template <int E, uint32_t NT, uint32_t K, uint32_t J>
 __device__ __forceinline__ void bitonic_merge(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
 {
-    bitonic_step<E, K, J>(key, sh, addr16, addr32);
-    if constexpr (J > 1u) bitonic_merge<E, K, (J >> 1)>(key, sh, addr16, addr32);
+    bitonic_step<E, NT, K, J>(key, sh, addr16, addr32);
+    if constexpr (J > 1u) bitonic_merge<E, NT, K, (J >> 1)>(key, sh, addr16, addr32);
 }
-template <int E, uint32_t K>
+template <int E, uint32_t NT, uint32_t K>
 __device__ __forceinline__ void bitonic_phases(uint64_t (&key)[E], uint64_t* sh, uint32_t addr16, uint32_t addr32)
 {
-    if constexpr (K > 2u) bitonic_phases<E, (K >> 1)>(key, sh, addr16, addr32);
-    bitonic_merge<E, K, (K >> 1)>(key, sh, addr16, addr32);
+    if constexpr (K > 2u) bitonic_phases<E, NT, (K >> 1)>(key, sh, addr16, addr32);
+    bitonic_merge<E, NT, K, (K >> 1)>(key, sh, addr16, addr32);
 }
 
-template <int E>
+template <int E, uint32_t NT = 256u>
 __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_t* sh)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    bitonic_phases<E, 256u * E>(key, sh, (lane ^ 16u) << 2, (lane ^ 32u) << 2);
+    bitonic_phases<E, NT, NT * E>(key, sh, (lane ^ 16u) << 2, (lane ^ 32u) << 2);
 }
 
 // Appends up to 256 consecutive sorted entries of a tile (one per thread, `valid` when it exists) to the tile's
@@ -598,8 +601,25 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
             }
     };
     if (n <= (uint32_t)CAP) {
-        sort_in_lds(keys + s, n);
-        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) list[s + i] = list_entry(sh[i], i + 1u);
+        // the register network of the small tiles with 1024 threads (4 or 8 keys each): lane distances below 64 by DPP,
+        // only distances 64..512 through LDS -- a fifth of the barriers of an all-LDS bitonic sort
+        auto in_registers = [&](auto e_tag) {
+            constexpr int E = decltype(e_tag)::value;
+            uint64_t key[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
+                key[e] = i < n ? keys[s + i] : ~0ull;
+            }
+            bitonic_in_registers<E, SORT_LARGE_THREADS>(key, sh);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
+                if (i < n) list[s + i] = list_entry(key[e], i + 1u);
+            }
+        };
+        if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
+        else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
     } else {
         // Longer than LDS: sort CAP-sized chunks in LDS into `scratch`, then every key finds its final position as its
         // index in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are

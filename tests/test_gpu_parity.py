@@ -488,8 +488,8 @@ def test_full_size_workload_parity_and_properties(device):
 
 def _stacked_scene(P, H, W, seed, spread_px):
     """P small Gaussians whose centres all project into a few neighbouring tiles in the image centre: exercises the
-    tile-sort paths for long lists (eight keys per thread in registers for 1024 < n <= 2048, LDS bitonic up to 8192,
-    rank fallback beyond) and heavy atomics."""
+    tile-sort paths for long lists (eight keys per thread in registers for 1024 < n <= 2048, 1024-thread register network up to 8192,
+    LDS-sorted chunks + rank merge beyond) and heavy atomics."""
     import math
     from hugs_amd import synthetic as syn
     rng = np.random.default_rng(seed)

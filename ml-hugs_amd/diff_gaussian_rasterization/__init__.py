@@ -178,7 +178,9 @@ class GaussianRasterizationSettings(NamedTuple):
 
 def _fill_settings(s, rs, keep):
     dev = keep["device"]
-    bg, vm, pm, cp = (_f32c(x.to(dev)) for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
+    # (the usual case -- fp32, contiguous, already on the device -- costs one attribute check per tensor)
+    bg, vm, pm, cp = (x if (x.device == dev and x.dtype == torch.float32 and x.is_contiguous()) else _f32c(x.to(dev))
+                      for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
     keep["settings_tensors"] = (bg, vm, pm, cp)
     s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
     s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)

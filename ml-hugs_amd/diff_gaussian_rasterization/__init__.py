@@ -288,6 +288,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.num_rendered = int(n)
         ctx.binning_capacity = int(state.binning_capacity)
+        if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
+            _last_num_rendered.clear()
         _last_num_rendered[hint_key] = int(n)
         ctx.bw, ctx.grads, ctx.keep, ctx.dims = bw, grads, keep, (P, M)
         empty = torch.empty(0, device=dev)

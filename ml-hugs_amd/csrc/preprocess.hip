@@ -252,7 +252,8 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8+K9 fused: one thread per Gaussian, only radius > 0 does work.  Outputs are pre-zeroed by the caller.
+// K8+K9 fused: one thread per Gaussian, only radius > 0 does work; every output element is written here (zeros for
+// culled Gaussians and SH coefficients above the active degree), the caller pre-zeroes nothing.
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
                            const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rots,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 3
+#define HGS_ABI_VERSION 4
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
@@ -91,6 +91,11 @@ typedef struct hgs_forward_args {
     /* Optional [P,12] floats: the `grad_accum` the caller is going to hand to hgs_rasterize_backward for this frame.
      * When non-NULL forward zeroes it (inside its first kernel, for free), so the caller need not. */
     float *grad_accum_to_zero;
+    /* !=0: out_color = clamp(colour, 0, 1), and backward passes dL/dout_color only where the unclamped value was inside
+     * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
+     * its autograd backward, without the five elementwise passes over the image they cost. */
+    int32_t clamp_output;
+    int32_t reserved;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */

@@ -107,7 +107,8 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ gate)
+                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ gate,
+                     int clamp_output)
 {
     if (*(const_u32p)gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
@@ -149,19 +150,27 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
         const size_t HW = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
         const float Tf = __builtin_fabsf(T);
         final_T[pix] = Tf;
-        n_contrib[pix] = last;
-        out_color[pix] = __builtin_fmaf(Tf, bg[0], C0);
-        out_color[HW + pix] = __builtin_fmaf(Tf, bg[1], C1);
-        out_color[2 * HW + pix] = __builtin_fmaf(Tf, bg[2], C2);
+        float c0 = __builtin_fmaf(Tf, bg[0], C0), c1 = __builtin_fmaf(Tf, bg[1], C1), c2 = __builtin_fmaf(Tf, bg[2], C2);
+        // bits 29..31 of n_contrib: "dL/dcolour passes" per channel -- all set without clamping, else set where the
+        // unclamped value lies inside [0, 1] (torch.clamp's backward); last < 2^28 (GID_BITS)
+        uint32_t pass = 7u;
+        if (clamp_output) {
+            pass = (c0 >= 0.0f && c0 <= 1.0f ? 1u : 0u) | (c1 >= 0.0f && c1 <= 1.0f ? 2u : 0u) | (c2 >= 0.0f && c2 <= 1.0f ? 4u : 0u);
+            c0 = fminf(fmaxf(c0, 0.0f), 1.0f), c1 = fminf(fmaxf(c1, 0.0f), 1.0f), c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
+        }
+        n_contrib[pix] = last | (pass << 29);
+        out_color[pix] = c0;
+        out_color[HW + pix] = c1;
+        out_color[2 * HW + pix] = c2;
     }
 }
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, hipStream_t st)
+                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output, hipStream_t st)
 {
     hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
-                       act_stride, act_count, splats, bg, out_color, final_T, n_contrib, gate);
+                       act_stride, act_count, splats, bg, out_color, final_T, n_contrib, gate, clamp_output ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,11 +304,12 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
     for (int k = 0; k < NQ; ++k) {
         const float Tf = in_img[k] ? ld_T[k] : 0.0f;
         p[k].T = Tf;
-        p[k].g0 = in_img[k] ? ld_g[k][0] : 0.0f;
-        p[k].g1 = in_img[k] ? ld_g[k][1] : 0.0f;
-        p[k].g2 = in_img[k] ? ld_g[k][2] : 0.0f;
+        // bits 29..31 of n_contrib: which channels' dL/dcolour pass (the forward's clamp mask)
+        p[k].g0 = in_img[k] && (ld_n[k] >> 29 & 1u) ? ld_g[k][0] : 0.0f;
+        p[k].g1 = in_img[k] && (ld_n[k] >> 30 & 1u) ? ld_g[k][1] : 0.0f;
+        p[k].g2 = in_img[k] && (ld_n[k] >> 31 & 1u) ? ld_g[k][2] : 0.0f;
         p[k].S = Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
-        p[k].last_contributor = in_img[k] ? ld_n[k] : 0u;
+        p[k].last_contributor = in_img[k] ? (ld_n[k] & 0x0FFFFFFFu) : 0u;
         wmax = max(wmax, p[k].last_contributor);
     }
     // the wave starts at the deepest entry any of its pixels composited

@@ -297,7 +297,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         STAGE_CHECK(dbg, st, "tile_sort");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
           launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
-                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, st); }
+                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, a.clamp_output != 0, st); }
         STAGE_CHECK(dbg, st, "blend_forward");
         return HGS_OK;
     };

@@ -27,7 +27,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 3
+_ABI_VERSION = 4
 
 
 def library_path():
@@ -48,7 +48,7 @@ class _ForwardArgs(C.Structure):
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
-                ("grad_accum_to_zero", C.c_void_p)]
+                ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _ForwardState(C.Structure):
@@ -239,7 +239,7 @@ def _point_at_grads(a, grads, M):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, clamp_output=False):
         lib = _load()
         _require_gpu(means3D, "means3D")
         dev = means3D.device
@@ -272,6 +272,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         args, state = bw.fwd, bw.state
         _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
+        args.clamp_output = 1 if clamp_output else 0
         M = int(args.M)
         grads = None
         if P > 0 and any(ctx.needs_input_grad):
@@ -316,7 +317,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         bw, grads = ctx.bw, ctx.grads
         if grad_out_color is None:  # colour did not take part in the loss
             ctx.grads = None
-            return (None,) * 9
+            return (None,) * 10
         if grads is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
             grads = _grad_slab(P, M, dev, zero=True)
             _point_at_grads(bw, grads, M)
@@ -340,13 +341,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_scales if scales.numel() else None,
                 g_rot if rotations.numel() else None,
                 g_cov3D if cov3Ds_precomp.numel() else None,
-                None)
+                None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, clamp_output=False):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, clamp_output)
 
 
 class GaussianRasterizer(nn.Module):
@@ -372,7 +373,9 @@ class GaussianRasterizer(nn.Module):
         return present
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, clamp_output=False):
+        """`clamp_output` is the one addition to upstream's signature: True fuses the `torch.clamp(image, 0, 1)` that
+        the reference's render() applies right after this call (gs_renderer.py:153), forward and backward."""
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -391,7 +394,7 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = empty
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings)
+                                   cov3D_precomp, raster_settings, clamp_output)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -426,7 +429,7 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         holder["splats"] = sub(geom, "splats", 48 * P, torch.float32).view(P, 12)
         holder["tiles_touched"] = sub(geom, "tiles_touched", 4 * P, torch.int32)
         holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
-        holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W)
+        holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W) & 0x0FFFFFFF  # top bits: clamp mask
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
         lst = sub(binning, "list", 8 * N, torch.int64)                      # sorted: (pos1 << 32) | mask << 28 | gaussian
         raw = lst & 0xFFFFFFFF

@@ -138,9 +138,10 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
         opacities=opacity,
         scales=scales,
         rotations=rotations,
+        clamp_output=True,   # the reference's torch.clamp(rendered_image, 0.0, 1.0) (:153), fused into the blend kernels
     )
     return {
-        "render": torch.clamp(image, 0.0, 1.0),
+        "render": image,
         "viewspace_points": screenspace_points,
         "visibility_filter": radii > 0,
         "radii": radii,

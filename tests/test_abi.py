@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert {"hgs_rasterize_forward", "hgs_rasterize_backward", "hgs_mark_visible", "hgs_last_error"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in the header but not exported"
-    assert lib.hgs_abi_version() == 3
+    assert lib.hgs_abi_version() == 4
 
 
 def test_ctypes_structs_match_the_c_layout():

@@ -288,6 +288,34 @@ def test_non_finite_inputs_are_culled_like_the_oracle_and_poison_nothing(device)
         assert rel_l2(g[clean], r.reshape(g.shape)[clean]) <= GRAD_REL_TOL, k
 
 
+def test_fused_output_clamp_equals_torch_clamp_forward_and_backward(device):
+    """clamp_output=True == torch.clamp(image, 0, 1) applied after the call (gs_renderer.py:153), including which pixels
+    let the gradient through (inclusive bounds), on a scene whose colours leave [0, 1] on both sides."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(**CASES["basic_d3"])
+    sc["bg"] = np.array([-1.5, 2.5, 0.5], np.float32)   # colours are >= 0: an out-of-range background reaches both bounds
+    sc["opacities"] = (0.3 * sc["opacities"]).astype(np.float32)
+    dL = to_dev(sc["dL_dpix"], device)
+    outs = []
+    for fused in (False, True):
+        t = gpu_tensors(sc, device)
+        rast = GaussianRasterizer(gpu_settings(sc, device))
+        kw = dict(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"],
+                  colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+        if fused:
+            img, radii = rast(**kw, clamp_output=True)
+        else:
+            raw, radii = rast(**kw)
+            assert float(raw.detach().min()) < 0.0 and float(raw.detach().max()) > 1.0, "the scene must exercise both bounds"
+            img = torch.clamp(raw, 0.0, 1.0)
+        img.backward(dL)
+        outs.append((img.detach(), {k: v.grad for k, v in t.items() if v is not None and v.grad is not None}))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert rel_l2(outs[1][1][k].cpu().numpy(), outs[0][1][k].cpu().numpy()) <= 1e-5, k
+
+
 def test_api_errors(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(**CASES["single"])

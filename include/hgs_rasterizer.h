@@ -16,9 +16,10 @@
  * The library allocates nothing that outlives a call: per-call scratch (geometry, binning and
  * image state) is obtained through the caller's allocation callback so that it lives in
  * caller-owned memory (torch uint8 tensors kept by the autograd ctx until backward).
- * All work is enqueued on `stream` (a hipStream_t); forward waits ONCE on the host for a 4-byte copy of N, the number
- * of (tile, Gaussian) pairs that sizes the binning buffer -- before enqueueing the rest of the frame, or, when the
- * caller passes binning_capacity_hint, after it (the wait then overlaps the GPU's work).
+ * All work is enqueued on `stream` (a hipStream_t).  N, the number of (tile, Gaussian) pairs that sizes the binning
+ * buffer, reaches the host through ONE 64-bit system-scope store of the tile-scan kernel into a pinned slot the host
+ * polls (no copy, no event): forward waits for it before enqueueing the rest of the frame, or, when the caller passes
+ * binning_capacity_hint, after it (the wait then overlaps the GPU's work).
  * All floating point is fp32, contiguous.
  */
 #ifndef HGS_RASTERIZER_H
@@ -151,7 +152,7 @@ int32_t hgs_densification_stats(int32_t n, const float *viewspace_grad, const in
 /* SURVEY.md 8f row f-2 -- the K nearest template vertices of every query point: replaces pytorch3d.ops.knn_points for
  * batch size 1 as called at /root/reference/hugs/models/hugs_wo_trimlp.py:60,99 (points [n,3], template_points [m,3],
  * 1 <= K <= 8, K <= m).  dists [n,K] = squared L2 distances in ascending order, idx [n,K] int64; equal distances keep
- * the lower template index first.  template_points must be 16-byte aligned. */
+ * the lower template index first.  Pointers need float alignment only. */
 int32_t hgs_knn_points(int32_t n, const float *points, int32_t m, const float *template_points, int32_t K,
                        float *dists, int64_t *idx, void *stream);
 
@@ -163,8 +164,8 @@ int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, cons
                                  void *stream);
 
 /* SURVEY.md 8f row f-4 -- replaces simple_knn._C.distCUDA2 (/root/reference/hugs/models/scene.py:20,181): mean_dist2[i]
- * = mean of the squared distances from points[i] to its three nearest OTHER points of the same cloud ([n,3], n >= 4,
- * 16-byte aligned).  Exact (brute force), fp32. */
+ * = mean of the squared distances from points[i] to its three nearest OTHER points of the same cloud ([n,3], n >= 4).
+ * Exact (brute force), fp32. */
 int32_t hgs_dist_cuda2(int32_t n, const float *points, float *mean_dist2, void *stream);
 
 /* Message for the last negative return value on the calling thread. */

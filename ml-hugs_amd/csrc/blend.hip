@@ -72,7 +72,6 @@ __device__ __forceinline__ float log2_alpha(const SplatRec& s, float dx, float d
 // XCD gets every 8th tile of every image row: a little less L2 locality than one band of the image per XCD (+3 us in
 // the forward on a uniform scene), but the XCDs stay evenly loaded when the Gaussians are not -- a person-sized blob in
 // the middle of the frame cost the banded order 17 us (forward) / 19-49 us (backward).
-__device__ __forceinline__ int remap_tile(int bid, int) { return bid; }
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4u* const_u4p;
@@ -111,7 +110,7 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
                      int clamp_output)
 {
     if (*(const_u32p)gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
-    const int tile = remap_tile(blockIdx.x, cam.gx * cam.gy);
+    const int tile = blockIdx.x;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -405,7 +404,7 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vbid = NQ == 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + w;
     if (vbid >= num_tiles) return;
-    const int tile = remap_tile(vbid, num_tiles);
+    const int tile = vbid;
     const v2u range = ((const_u2p)ranges)[tile];
     if (range.y <= range.x) return;
     blend_backward_wave<NQ>(cam, lastg, tile, w, range, act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);

@@ -28,9 +28,19 @@ extern "C" int32_t hgs_densification_stats(int32_t n, const float* viewspace_gra
                                            float* xyz_gradient_accum, float* denom, void* stream)
 {
     if (n < 0 || (n > 0 && (!viewspace_grad || !radii || !visibility_filter || !max_radii2D || !xyz_gradient_accum || !denom)))
+    {
+        hgs::set_last_error("densification_stats: n must be >= 0 and all six arrays non-null");
         return HGS_ERR_INVALID_ARGUMENT;
+    }
     if (n == 0) return HGS_OK;
     hipLaunchKernelGGL(densification_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, viewspace_grad,
                        radii, visibility_filter, max_radii2D, xyz_gradient_accum, denom);
-    return hipGetLastError() == hipSuccess ? HGS_OK : HGS_ERR_HIP;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "densification_stats: %s", hipGetErrorString(e));
+        hgs::set_last_error(msg);
+        return HGS_ERR_HIP;
+    }
+    return HGS_OK;
 }

@@ -57,13 +57,22 @@ __device__ __forceinline__ float sqdist(float px, float py, float pz, float tx, 
 
 constexpr int KNN_SPLIT = 4;  // waves per workgroup = template segments
 
-// scans template vertices [j0, j1), j0 a multiple of 4; vertex `skip` (or -1) is never offered (a cloud searched
-// against itself: a point is not its own neighbour)
+// scans template vertices [j0, j1) in ascending order; vertex `skip` (or -1) is never offered (a cloud searched against
+// itself: a point is not its own neighbour).  `templ` needs only float alignment: vertices up to the first one that
+// starts on a 16-byte boundary (vertex j does when j == phase mod 4, phase = float offset of templ inside its 16 bytes)
+// are taken one at a time, as is the tail.
 template <int K>
 __device__ __forceinline__ void scan_template(float px, float py, float pz, const float* __restrict__ templ, int j0, int j1,
                                               int skip, Best<K>& best)
 {
     best.init();
+    const int phase = (int)(((uintptr_t)templ >> 2) & 3u);
+    const int ja = min(j0 + ((phase - j0) & 3), j1);
+    for (int j = j0; j < ja; ++j) {
+        const_f32p q = (const_f32p)(templ + 3 * (size_t)j);
+        if (j != skip) best.offer(sqdist(px, py, pz, q[0], q[1], q[2]), j);
+    }
+    j0 = ja;
     const int j4 = j0 + ((j1 - j0) & ~3);
     // 4 vertices = 12 floats = three aligned 16-byte scalar loads; the next trip's loads are issued before this trip's
     // arithmetic (two register sets), so the scalar-cache latency runs under it
@@ -80,9 +89,10 @@ __device__ __forceinline__ void scan_template(float px, float py, float pz, cons
         float d0 = sqdist(px, py, pz, a.x, a.y, a.z), d1 = sqdist(px, py, pz, a.w, b.x, b.y);
         float d2 = sqdist(px, py, pz, b.z, b.w, c.x), d3 = sqdist(px, py, pz, c.y, c.z, c.w);
         a = an, b = bn, c = cn;
-        if ((skip & ~3) == j) {  // at most one trip per lane
+        const unsigned ds = (unsigned)(skip - j);
+        if (ds < 4u) {  // at most one trip per lane
             const float inf = __builtin_inff();
-            d0 = skip == j ? inf : d0, d1 = skip == j + 1 ? inf : d1, d2 = skip == j + 2 ? inf : d2, d3 = skip == j + 3 ? inf : d3;
+            d0 = ds == 0u ? inf : d0, d1 = ds == 1u ? inf : d1, d2 = ds == 2u ? inf : d2, d3 = ds == 3u ? inf : d3;
         }
         const float dmin = fminf(fminf(d0, d1), fminf(d2, d3));
         if (__builtin_amdgcn_ballot_w64(dmin < best.d[K - 1]) == 0ull) continue;
@@ -238,7 +248,7 @@ extern "C" int32_t hgs_knn_points(int32_t n, const float* points, int32_t m, con
     if (n < 0 || m < K || K < 1) return fail_knn("knn_points: need n >= 0 and 1 <= K <= m");
     if (n == 0) return HGS_OK;
     if (!points || !template_points || !dists || !idx) return fail_knn("knn_points: null pointer");
-    if (((uintptr_t)template_points & 15) != 0) return fail_knn("knn_points: template_points must be 16-byte aligned");
+    if (((uintptr_t)template_points & 3) != 0) return fail_knn("knn_points: template_points must be float-aligned");
     if (int rc = dispatch_k<LaunchKnn>(K, n, points, m, template_points, dists, idx, (hipStream_t)stream)) return rc;
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("knn_points: kernel launch failed");
@@ -254,7 +264,7 @@ extern "C" int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float* points, int3
     if (n < 0 || m < K || K < 1 || J < 1) return fail_knn("smpl_lbsweight_top_k: need n >= 0, J >= 1 and 1 <= K <= m");
     if (n == 0) return HGS_OK;
     if (!points || !template_points || !lbs_weights || !out_dist || !out_weights) return fail_knn("smpl_lbsweight_top_k: null pointer");
-    if (((uintptr_t)template_points & 15) != 0) return fail_knn("smpl_lbsweight_top_k: template_points must be 16-byte aligned");
+    if (((uintptr_t)template_points & 3) != 0) return fail_knn("smpl_lbsweight_top_k: template_points must be float-aligned");
     if (int rc = dispatch_k<LaunchLbs>(K, n, points, m, template_points, lbs_weights, J, out_dist, out_weights, (hipStream_t)stream)) return rc;
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("smpl_lbsweight_top_k: kernel launch failed");
@@ -269,7 +279,7 @@ extern "C" int32_t hgs_dist_cuda2(int32_t n, const float* points, float* mean_di
     if (n == 0) return HGS_OK;
     if (n < 4) return fail_knn("distCUDA2: needs at least 4 points (three neighbours besides the point itself)");
     if (!points || !mean_dist2) return fail_knn("distCUDA2: null pointer");
-    if (((uintptr_t)points & 15) != 0) return fail_knn("distCUDA2: points must be 16-byte aligned");
+    if (((uintptr_t)points & 3) != 0) return fail_knn("distCUDA2: points must be float-aligned");
     hipLaunchKernelGGL(mean_dist3_kernel, dim3((n + 63) / 64), dim3(64 * KNN_SPLIT), 0, (hipStream_t)stream, n, points, mean_dist2);
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("distCUDA2: kernel launch failed");

@@ -71,6 +71,13 @@ def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_colo
         side.wait_stream(main)
         with torch.cuda.stream(side):
             human_pkg = human_only()
+            # main-stream tensors read (and saved for backward) by side-stream kernels: tell the caching allocator, so
+            # that a caller dropping them early cannot have their blocks recycled under those kernels
+            used = [human_gs_out[src] for src, _ in _FIELDS] + [bg_color, human_bg_color] + \
+                   [data[k] for k in ("world_view_transform", "full_proj_transform", "camera_center")]
+            for t in used:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
     pkg = render(means3D=g["means3D"], feats=g["feats"], opacity=g["opacity"], scales=g["scales"],
                  rotations=g["rotations"], data=data, scaling_modifier=scaling_modifier, bg_color=bg_color,
                  active_sh_degree=g["active_sh_degree"])

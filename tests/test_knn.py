@@ -112,6 +112,27 @@ def test_hip_lbsweight_full_size_against_the_oracle(device):
 
 
 @pytest.mark.gpu
+def test_hip_search_takes_batches_and_offset_views(device):
+    """B = 2 with the SMPL template: element 1 starts 6890*12 bytes in (8 mod 16); likewise a sliced cloud handed to
+    distCUDA2.  pytorch3d / simple_knn have no alignment rule, so neither has the library (float alignment only)."""
+    from hugs_amd.knn import distCUDA2, knn_points, smpl_lbsweight_top_k
+    sets = [body(500, 6890, 24, seed=s) for s in (21, 22)]
+    templ = np.stack([s[0] for s in sets]); pts = np.stack([s[2] for s in sets]); w = sets[0][1]
+    res = knn_points(torch.from_numpy(pts).to(device), torch.from_numpy(templ).to(device), K=6)
+    xd, out = smpl_lbsweight_top_k(torch.from_numpy(w).to(device), torch.from_numpy(pts).to(device), torch.from_numpy(templ).to(device))
+    for b in range(2):
+        d, i = ko.knn_points(pts[b], templ[b], 6)
+        assert np.array_equal(res.idx[b].cpu().numpy(), i)
+        assert np.array_equal(res.dists[b].cpu().numpy().view(np.uint32), d.view(np.uint32))
+        rd, rw = ko.smpl_lbsweight_top_k(w, pts[b], templ[b], K=6)
+        np.testing.assert_allclose(out[b].cpu().numpy(), rw, rtol=1e-4, atol=1e-6)
+    cloud = np.random.default_rng(3).standard_normal((1003, 3)).astype(np.float32)
+    for off in (1, 2, 3):   # storage offsets of 12, 24, 36 bytes
+        got = distCUDA2(torch.from_numpy(cloud).to(device)[off:])
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), ko.dist_cuda2(cloud[off:]).view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_hip_knn_errors(device):
     from hugs_amd.knn import knn_points
     p = torch.zeros(1, 4, 3, device=device)

@@ -2,7 +2,10 @@
 """Headline benchmark: rasterizer forward+backward FPS at 1080p, and the HBM roofline of its dominant kernel.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or on its own: with WORLD_SIZE unset the parent
+    process -- before it touches the GPU -- starts N child ranks itself, relays rank 0's JSON line and exits with the
+    worst child's code.
 
 Workload = BASELINE.json configs[1]: 200k scene Gaussians, [P,16,3] SH at degree 3, 1920x1080, white
 background, seeded synthetic inputs already resident in HBM.  One step = one call of the
@@ -39,7 +42,7 @@ def alg_bytes(P, Pv, N, S, T, K, M=16):
     return frame, blend_bwd, blend_fwd
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -53,14 +56,108 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-frames-in-flight figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only rendezvous (gloo) and gather their ids -- no rasterizer work, no GPU needed; "
+                         "checks the self-launcher (tests/test_bench_launcher.py)")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N fresh rank processes (never exec / re-exec: this process has not touched the
+    GPU and does not need to), one per LOCAL_RANK, rendezvous on 127.0.0.1.  Rank 0's stdout is this process's stdout."""
+    import socket
+    import subprocess
+    n = args.gpus
+    backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not args.launcher_selftest:
+        import torch  # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible. One rank per GPU over RCCL needs {n}; "
+                             "set HGS_BENCH_BACKEND=gloo to let ranks share GPUs (plumbing check, not a scaling number).")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    log(f"[launcher] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}, backend {backend}")
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out0.decode().splitlines():   # the contract is ONE JSON line on stdout: library chatter goes to stderr
+        if line.startswith("{"):
+            print(line, flush=True)
+        elif line.strip():
+            log(line)
+    if any(codes):
+        log(f"[launcher] rank exit codes {codes}")
+        raise SystemExit(max(abs(c) for c in codes) or 1)
+
+
+def launcher_selftest(args, rank, world):
+    """Rendezvous + the bench's own gather plumbing on gloo, nothing else."""
+    import torch
+    import torch.distributed as dist
+    from hugs_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo")
+    ids = sharding.gather_frame_metrics([rank], [[float(rank), float(os.getpid())]], world, device=torch.device("cpu"))
+    slowest = sharding.max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int((ids[:, 1] > 0).sum()),
+                          "rank_ids": [int(x) for x in ids[:, 0].tolist()], "max_over_ranks_ok": abs(slowest - 0.001 * world) < 1e-9}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def measured_copy_peak(torch, device, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes / time) of this GPU, now: the practical HBM ceiling next to the
+    datasheet figure."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # HGS_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (several
@@ -73,7 +170,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    log(f"[rank {rank}] world_size {dist.get_world_size() if world > 1 else 1} ({backend if world > 1 else 'single process'}), "
+        f"device {device} = {torch.cuda.get_device_name(device)}")
 
     from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, profile_enable,
                                              profile_read)
@@ -139,7 +237,8 @@ def main():
         from diff_gaussian_rasterization import _debug_forward_state
         N = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
                                  scales=t["scales"].detach(), rotations=t["rotations"].detach())[2]["N"]
-    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv)]], world, device=coll_dev)
+    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv), float(device.index), 1.0]], world, device=coll_dev)
+    copy_peak = measured_copy_peak(torch, device) if rank == 0 else None
 
     # per-stage breakdown in a separate, untimed pass (every stage bracketed by events)
     profile_enable()
@@ -186,6 +285,7 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_seen": int(frames[:, 3].sum()), "rank_devices": [int(x) for x in frames[:, 2].tolist()],
         "config": {"workload": f"configs[1]: {P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
                                f"{'forward only' if args.forward_only else 'forward+backward'} through "
                                "GaussianRasterizer (drop-in API), one camera per GPU",
@@ -193,11 +293,17 @@ def main():
                    "N_per_frame_all_ranks": [int(x) for x in frames[:, 0].tolist()]},
         "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                     "peak_measured": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
+                     "peak_measured_how": "1 GiB device-to-device copy_ on this GPU in this run, (read + write bytes) / time",
                      "traffic": None, "algorithmic_bytes_per_launch": int(dom_B),
                      "avg_launch_ms": round(dom_ms, 4), "launches_timed": prof[dominant][1],
-                     "note": "this kernel is VALU/atomic-bound, not HBM-bound (DESIGN.md); see pixel_splat_evals_per_s"},
+                     "note": "north_star's '>= 60 % of the HBM roofline' is structurally unreachable for the two blend kernels: "
+                             "they do ~256 pixel-splat evaluations per 40-byte list entry and are VALU-issue bound (see "
+                             "valu_issue.busy_frac) with HBM mostly idle; the per-Gaussian kernels (K1, K8) are the ones on the "
+                             "HBM roofline (DESIGN.md section 4)"},
         "whole_frame": {"algorithmic_bytes": int(frame_B), "GB_per_s": round(frame_B * fps / world / 1e9, 2),
-                        "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5)},
+                        "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5),
+                        "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
         "stages_ms": stages,
     }
@@ -205,27 +311,40 @@ def main():
         out["two_frames_in_flight"] = {"value": round(fps_two_streams, 2), "unit": "frames/s",
                                        "note": "same workload, frames alternate between two HIP streams of one process"}
 
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs of this same
-    # command; collected and corrected as MI355X_MICROARCH.md prescribes) -- only for the workload they were taken on
-    try:
-        import glob
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]  # named per round: r1f < r1h < r2a
-        pmc = json.load(open(newest))
-        wl = pmc["workload"]
-        if (wl["gaussians"], wl["height"], wl["width"], wl["sh_degree"]) == (P, H, W, D):
+    # HBM traffic and VALU issue utilisation of the dominant kernel from the committed rocprofv3 PMC passes (separate
+    # runs of this same command; collected and corrected as MI355X_MICROARCH.md prescribes).  Attached only when they
+    # were taken on this workload AND on the kernel sources of the running build (profiles/build_id.py).
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from build_id import csrc_sha16
+    here = csrc_sha16()
+
+    def newest(pattern):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))  # named per round: r1p < r2a < r2b
+        return files[-1] if files else None
+
+    f = newest("*_pmc_traffic.json")
+    if f:
+        pmc = json.load(open(f))
+        wl = pmc.get("workload", {})
+        same_wl = (wl.get("gaussians"), wl.get("height"), wl.get("width"), wl.get("sh_degree")) == (P, H, W, D)
+        if same_wl and pmc.get("csrc_sha16") == here and dominant + "_kernel" in pmc["kernels"]:
             out["roofline"]["traffic"] = pmc["kernels"][dominant + "_kernel"]["hbm_bytes_corrected"]
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(newest)
-    except Exception:
-        pass
-    # ... and its VALU issue utilisation from the SQ counter passes of the same round: the bound that actually holds
-    try:
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_utilization.json")))[-1]
-        vu = json.load(open(newest))["kernels"][dominant + "_kernel"]
-        out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": vu["valu_busy_frac"],
-                             "wave_instructions_per_launch": vu["valu_wave_instructions"],
-                             "source": "profiles/" + os.path.basename(newest) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
-    except Exception:
-        pass
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(f)
+        else:
+            out["roofline"]["traffic_note"] = (f"stale or other workload: profiles/{os.path.basename(f)} was taken on csrc "
+                                               f"{pmc.get('csrc_sha16')}, this build is {here}")
+    f = newest("*_valu_utilization.json")
+    if f:
+        vu_all = json.load(open(f))
+        vu = vu_all.get("kernels", {}).get(dominant + "_kernel")
+        if vu and vu_all.get("csrc_sha16") == here:
+            out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": vu["valu_busy_frac"],
+                                 "wave_instructions_per_launch": vu["valu_wave_instructions"],
+                                 "source": "profiles/" + os.path.basename(f) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
+        else:
+            out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": None,
+                                 "note": f"stale: profiles/{os.path.basename(f)} was taken on csrc {vu_all.get('csrc_sha16')}, this build is {here}"}
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)
@@ -240,6 +359,7 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
     this box's host cores on a bounded sample of the same workload. Baseline only."""
     from oracle import hgs_oracle as ho
     # the port keeps one double-precision gradient accumulator per thread: beyond ~32 threads that costs more than it buys
+    # (`cores` = threads actually used; the box's core count and CPU model are reported beside it)
     cores = min(os.cpu_count() or 1, 32)
     ho.set_threads(cores)
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
@@ -255,7 +375,8 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
         if el + el / n > budget_s or n >= 8:
             break
     log(f"[cpu_baseline] {n} frame(s) in {el:.2f} s on {cores} threads")
-    return {"value": round(n / el, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    model, host_cpus = host_cpu()
+    return {"value": round(n / el, 4), "unit": "frames/s", "cores": cores, "host_cpus": host_cpus, "cpu_model": model, "kind": "port",
             "sample": f"{n} full frame(s) of the same workload ({'fwd+bwd' if with_backward else 'fwd'}), "
                       "C oracle (oracle/hgs_oracle.c, fp32, OpenMP over tiles)"}
 

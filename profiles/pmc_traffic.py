@@ -13,6 +13,8 @@ import sys
 
 import pandas as pd
 
+from build_id import csrc_sha16
+
 
 def per_kernel(path, counter):
     c = pd.read_csv(path)
@@ -26,6 +28,7 @@ def main(fetch_csv, write_csv, tag, P, H, W, D):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of "
                      f"`bench.py --steps 5 --warmup 2 --no-cpu-baseline` on MI355X, build {tag}; mean per dispatch, KiB as reported",
+           "csrc_sha16": csrc_sha16(),
            "workload": {"gaussians": int(P), "height": int(H), "width": int(W), "sh_degree": int(D)},
            "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming "
                          "reads -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; most reads of the blend kernels are narrow or "

@@ -8,6 +8,8 @@ import json
 import re
 import sys
 
+from build_id import csrc_sha16
+
 
 def parse(path):
     out, cur = {}, None
@@ -23,7 +25,7 @@ def parse(path):
 
 def main(set1, set2):
     a, b = parse(set1), parse(set2)
-    res = {"source": [set1, set2], "formula": "SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)", "kernels": {}}
+    res = {"source": [set1, set2], "csrc_sha16": csrc_sha16(), "formula": "SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)", "kernels": {}}
     for k in sorted(set(a) & set(b)):
         if "SQ_ACTIVE_INST_VALU" in a[k] and "GRBM_GUI_ACTIVE" in b[k]:
             cyc = b[k]["GRBM_GUI_ACTIVE"] / 8.0

@@ -21,6 +21,20 @@ import numpy as np
 import torch
 
 
+SH_C0 = 0.28209479177387814
+
+
+def RGB2SH(rgb):
+    """/root/reference/hugs/utils/spherical_harmonics.py:128-129 -- the DC coefficient that renders as `rgb`
+    (used when a scene is created from a coloured point cloud, scene.py:166-194)."""
+    return (rgb - 0.5) / SH_C0
+
+
+def SH2RGB(sh):
+    """spherical_harmonics.py:132-133 -- what a degree-0 coefficient renders as (before the rasterizer's clamp at 0)."""
+    return sh * SH_C0 + 0.5
+
+
 def attribute_names(n_dc=3, n_rest=45, n_scale=3, n_rot=4):
     """scene.py:229-241 (construct_list_of_attributes)."""
     names = ["x", "y", "z", "nx", "ny", "nz"]

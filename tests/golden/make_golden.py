@@ -11,6 +11,9 @@ What is recorded (all fp32, seeded):
   * get_projection_matrix       hugs/utils/graphics.py:76-96
   * get_rotating_camera / get_static_camera dicts   hugs/datasets/utils.py:15-53,64-124
   * psnr                        hugs/utils/image.py:27-29
+  * build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)   hugs/models/scene.py:36-41
+    (the one place the reference states how scale_modifier enters Sigma3D; reached through get_covariance, :144)
+  * RGB2SH / SH2RGB             hugs/utils/spherical_harmonics.py:128-133   (the +0.5 / C0 colour convention)
   * the boundary transcript of render_human_scene (kwargs / settings / returned keys, shapes, dtypes)
     captured with a recording stand-in for diff_gaussian_rasterization   hugs/renderer/gs_renderer.py:20-161
 
@@ -155,6 +158,36 @@ def main():
     L = rgen.build_scaling_rotation(torch.from_numpy(s), torch.from_numpy(q))
     cov = rgen.strip_symmetric(L @ L.transpose(1, 2))
     out["cov_scales"], out["cov_quats_raw"], out["cov_packed"] = s, q, cov.numpy()
+
+    # ---- Sigma3D with a scale modifier: SceneGS.setup_functions' nested build_covariance_from_scaling_rotation ----
+    # scene.py:36-41, compiled from the source file (the module imports simple_knn / plyfile ...) with the reference's
+    # own build_scaling_rotation / strip_symmetric (general.py) in its namespace; executed through the attribute the
+    # reference itself uses (self.covariance_activation, scene.py:45,144)
+    import ast as _ast
+
+    def _method_src(path, cls, name, ns):
+        tree = _ast.parse(open(path).read())
+        node = next(f for c in tree.body if isinstance(c, _ast.ClassDef) and c.name == cls
+                    for f in c.body if isinstance(f, _ast.FunctionDef) and f.name == name)
+        node.decorator_list = []
+        exec(compile(_ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        return ns[name]
+
+    setup_functions = _method_src(os.path.join(REF, "hugs/models/scene.py"), "SceneGS", "setup_functions",
+                                  {"torch": torch, "build_scaling_rotation": rgen.build_scaling_rotation,
+                                   "strip_symmetric": rgen.strip_symmetric, "inverse_sigmoid": rgen.inverse_sigmoid})
+    holder = types.SimpleNamespace()
+    setup_functions(holder)
+    mods = np.array([0.5, 1.0, 1.7], np.float32)
+    out["covmod_modifiers"] = mods
+    out["covmod_packed"] = np.stack([holder.covariance_activation(torch.from_numpy(s), float(m), torch.from_numpy(q)).numpy()
+                                     for m in mods])
+
+    # ---- RGB <-> SH DC convention ----
+    rgb = np.random.default_rng(123).uniform(-0.2, 1.2, (P, 3)).astype(np.float32)   # own generator: older vectors stay as they were
+    out["rgb2sh_in"] = rgb
+    out["rgb2sh_out"] = rsh.RGB2SH(torch.from_numpy(rgb)).numpy()
+    out["sh2rgb_out"] = rsh.SH2RGB(torch.from_numpy(sh[:, 0])).numpy()      # of the DC coefficients recorded above
 
     # ---- projection matrix + camera dicts ----
     from hugs.utils import graphics as rgfx

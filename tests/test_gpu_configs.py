@@ -111,13 +111,17 @@ def test_c3_human_only_512(P, device):
     assert float(human["shs"].grad[:, 1:].abs().max()) == 0.0
 
 
-def test_c4_joint_human_scene_1080p(device):
+@pytest.mark.parametrize("n_human,n_scene", [(30_000, 100_000), (110_210, 200_000)])
+def test_c4_joint_human_scene_1080p(n_human, n_scene, device):
+    """(110 210, 200 000) is the full BASELINE configs[3] size (SMPL subdivided twice, hugs_human.yaml:28 + the 200k scene;
+    what tools/bench_c4.py times): both renders through render_human_scene with the side stream on, the sparse-frame
+    backward on the human-only render, radii exact, images and every gradient against the oracle."""
     from hugs_amd.renderer import render_human_scene
     H, W = 1080, 1920
     cam0 = syn.pinhole_camera(H, W)
-    hm = human_gaussians(30_000, seed=7)
+    hm = human_gaussians(n_human, seed=7)
     hm["xyz"] = (hm["xyz"] + np.array([0.0, 0.0, 4.0], np.float32)).astype(np.float32)  # stand 4 m in front of the camera
-    sm = scene_model(100_000, cam0, seed=8)
+    sm = scene_model(n_scene, cam0, seed=8)
     rng = np.random.default_rng(2)
     bg, hbg = rng.uniform(0, 1, 3).astype(np.float32), rng.uniform(0, 1, 3).astype(np.float32)
     dL1 = (rng.standard_normal((3, H, W)) * 1e-3).astype(np.float32)
@@ -142,7 +146,7 @@ def test_c4_joint_human_scene_1080p(device):
     (pkg["render"] * to_dev(dL1, device)).sum().backward(retain_graph=True)
     (pkg["human_img"] * to_dev(dL2, device)).sum().backward()
     # the human's parameters receive the sum of both renders' gradients; the scene's only the joint render's
-    for k, rk in (("xyz", "means3D"), ("opacity", "opacities"), ("scales", "scales"), ("rotq", "rotations")):
+    for k, rk in (("xyz", "means3D"), ("opacity", "opacities"), ("scales", "scales"), ("rotq", "rotations"), ("shs", "shs")):
         r = g1[rk][:nh] + g2[rk]
         assert rel_l2(human[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
         r = g1[rk][nh:]

@@ -119,3 +119,68 @@ def test_empty_and_all_culled():
     sc["means3D"][:, 2] = 0.1
     f = ho.forward(oracle_inputs(sc))
     assert f["N"] == 0 and np.allclose(f["color"], 1.0)  # background only
+
+
+# ---- a third, derivation-free check: central finite differences of the fp64 oracle FORWARD ---------------------------
+# The analytic backward (oracle/hgs_oracle.c K7-K9, and the HIP K7-K9 typed from the same derivation) and the autograd
+# restatement both encode somebody's reading of Appendix A.5; finite differences of the forward encode nothing.  The
+# scenes avoid the three places where the reference's gradient is DELIBERATELY not the derivative (A.6: straight-through
+# 0.99 cap -> opacities <= 0.9; frustum-clamp masks -> nothing outside 1.3 tanfov; culled Gaussians), so the plain
+# derivative is the expected answer -- including the scale_modifier factor in dL/dscale.
+FD_SCENES = {
+    "sh3_rot_mod": dict(P=24, H=32, W=40, seed=21, D=3, rotated_camera=True, with_culled=False, scale_modifier=0.7, sigma_px=5.0),
+    "rgb_cov_precomp": dict(P=20, H=32, W=32, seed=22, colors_precomp=True, cov3D_precomp=True, with_culled=False, sigma_px=5.0,
+                            bg=(0.3, 0.6, 0.1)),
+    "sh1_unitq": dict(P=32, H=24, W=48, seed=23, D=1, nonunit_quat=False, with_culled=False, sigma_px=4.0),
+}
+
+
+@pytest.mark.parametrize("name", list(FD_SCENES))
+def test_analytic_backward_equals_finite_differences_of_the_forward_fp64(name):
+    sc = make_scene(**FD_SCENES[name])
+    sc["opacities"] = np.minimum(sc["opacities"], 0.9).astype(np.float32)   # alpha = o G never reaches the 0.99 cap
+    ho.set_threads(1, np.float64)
+    dL = sc["dL_dpix"].astype(np.float64)
+    tensors = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "colors_precomp": "colors", "scales": "scales",
+               "rotations": "rotations", "cov3D_precomp": "cov3D"}
+    base = {k: None if sc[k] is None else np.asarray(sc[k], np.float64).copy() for k in tensors}
+
+    def loss(vals):
+        s = dict(sc)
+        s.update(vals)
+        f = ho.forward(oracle_inputs(s, dtype=np.float64))
+        return float((f["color"] * dL).sum()), f
+
+    l0, f0 = loss(base)
+    assert (f0["radii"] > 0).all() and f0["N"] > sc["means3D"].shape[0]
+    g = ho.backward(oracle_inputs(dict(sc, **base), dtype=np.float64), f0, dL)
+    checked = 0
+    for k, gk in tensors.items():
+        if base[k] is None:
+            continue
+        ana = g[gk].reshape(base[k].shape)
+        if k == "shs":   # coefficients above the active degree: no effect on the forward, zero gradient
+            K = (sc["D"] + 1) ** 2
+            assert float(np.abs(ana[:, K:]).max(initial=0.0)) == 0.0
+        flat = base[k].reshape(-1)
+        fd1, fd2 = np.zeros_like(flat), np.zeros_like(flat)
+        idx = np.arange(flat.size) if k != "shs" else np.flatnonzero((np.arange(flat.size) // 3) % sc["M"] < (sc["D"] + 1) ** 2)
+        for i in idx:
+            h = 1e-6 * max(1.0, abs(flat[i]))
+            for fd, step in ((fd1, h), (fd2, 2 * h)):
+                v = flat.copy()
+                v[i] += step
+                lp, _ = loss({**base, k: v.reshape(base[k].shape)})
+                v[i] -= 2 * step
+                lm, _ = loss({**base, k: v.reshape(base[k].shape)})
+                fd[i] = (lp - lm) / (2 * step)
+        scale = np.abs(ana).max()
+        # a step that moves some pixel's alpha across 1/255 (or T across 1e-4, or a radius across an integer) lands on a
+        # jump of the forward: there the two step sizes disagree by ~2x and the element says nothing -- rare by construction
+        smooth = np.abs(fd1 - fd2) <= 1e-5 * scale + 1e-7 * np.abs(fd1)
+        usable = smooth[idx]
+        assert usable.mean() >= 0.98, (name, k, float(usable.mean()))
+        err = np.abs(fd1 - ana.reshape(-1))[idx][usable].max() / scale
+        assert err <= 2e-6, (name, k, float(err))
+        checked += int(usable.sum())
+    assert checked >= 250

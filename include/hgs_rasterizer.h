@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 4
+#define HGS_ABI_VERSION 5
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
@@ -96,7 +96,10 @@ typedef struct hgs_forward_args {
      * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
      * its autograd backward, without the five elementwise passes over the image they cost. */
     int32_t clamp_output;
-    int32_t reserved;
+    /* !=0: the caller expects no tile with more than 2048 entries (its previous frame of this shape had none, see
+     * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
+     * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
+    int32_t expect_no_long_tiles;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -107,7 +110,7 @@ typedef struct hgs_forward_state {
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad its own wave */
-    int32_t reserved;
+    int32_t has_long_tiles;   /* !=0: some tile list is longer than 2048 entries (feeds the next frame's expect_no_long_tiles) */
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */
@@ -174,7 +177,7 @@ const char *hgs_last_error(void);
 int32_t hgs_abi_version(void);
 
 /* Scratch sizes (so a caller may pre-allocate) */
-size_t hgs_geom_bytes(int32_t P);
+size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_image_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 
@@ -183,9 +186,10 @@ size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t ima
  * stage k; 0 disables (default).  hgs_profile_read synchronises the recorded events of that stage,
  * adds them up since the last reset and returns the number of timed launches through *launches. */
 enum {
-    HGS_STAGE_PREPROCESS = 0, HGS_STAGE_SCAN = 1, HGS_STAGE_EMIT_KEYS = 2, HGS_STAGE_SORT = 3,
-    HGS_STAGE_TILE_RANGES = 4, HGS_STAGE_BLEND_FORWARD = 5, HGS_STAGE_BLEND_BACKWARD = 6,
-    HGS_STAGE_PREPROCESS_BACKWARD = 7, HGS_NUM_STAGES = 8
+    HGS_STAGE_PREPROCESS = 0,    /* projection + SH + per-tile pair counts */
+    HGS_STAGE_SCAN = 1,          /* tile scan -> ranges, N */
+    HGS_STAGE_EMIT_KEYS = 2, HGS_STAGE_SORT = 3, HGS_STAGE_BLEND_FORWARD = 4, HGS_STAGE_BLEND_BACKWARD = 5,
+    HGS_STAGE_PREPROCESS_BACKWARD = 6, HGS_NUM_STAGES = 7
 };
 void hgs_profile_enable(uint32_t stage_mask);
 int32_t hgs_profile_read(int32_t stage, double *total_ms, int64_t *launches);

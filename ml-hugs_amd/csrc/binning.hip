@@ -1,10 +1,14 @@
 // Tile binning (scan, key emission, sort, tile ranges), restructured for MI355X:
 //
-//   count       per-tile population: a 1024-Gaussian workgroup counts into an LDS array, flushed with coalesced atomics
+//   (count)     per-tile population: done at the tail of the preprocess kernel (preprocess.hip) -- a 1024-Gaussian
+//               workgroup counts into an LDS array and takes one RETURNING atomic per touched tile, which is also
+//               where its run starts inside the tile's segment (run_start[group][tile]); count_kernel below is the
+//               fallback for frames with more tiles than fit an LDS array
 //   tile_scan   one workgroup: exclusive scan of the tile counts -> ranges[tile] = [start,end), N = total (published
-//               to the host from the kernel), the capacity gate, the list of long tiles
-//   emit        every (Gaussian, tile) pair takes a slot of its tile's segment and stores its 64-bit sort key
-//               (depth bits << 32 | Gaussian << 4 | quad coverage mask) there                     -- a bucket scatter
+//               to the host from the kernel), the capacity gate, the list of long tiles; re-zeroes the counters
+//   emit        every (Gaussian, tile) pair takes a slot of its tile's segment -- segment start + its group's run start +
+//               an LDS counter -- and stores its 64-bit sort key (depth bits << 32 | Gaussian << 4 | quad coverage
+//               mask) there                                                                       -- a bucket scatter
 //   tile_sort   one workgroup per tile: bitonic sort of the segment in registers (LDS for long tiles) by (fp32 depth
 //               bits, Gaussian index) and, while the segment is at hand, the tile's compacted per-quad lists
 //
@@ -16,6 +20,7 @@
 #include <type_traits>
 
 #include "hgs_common.h"
+#include "binning_walk.h"
 
 namespace hgs {
 
@@ -37,11 +42,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // oracle leaves them); cursor[t] = start of the tile's segment; n_total[0] = N; n_total[1] = (N > capacity), the gate
 // that makes the kernels of an optimistically launched frame return at once when the binning buffer was guessed
 // too small (hgs_api.hip).  N is also published to the host, straight from this kernel, as ONE 64-bit system-scope
-// store (sparse bit << 63 | ticket << 32 | N) into a pinned, host-coherent slot the host polls: no copy kernel, no event.
+// store (sparse bit << 63 | long-tiles bit << 62 | ticket << 32 | N) into a pinned, host-coherent slot the host polls:
+// no copy kernel, no event.  A thread scans eight consecutive tiles (two 16-byte loads, 64 bytes of ranges stored), so
+// the 8 160 tiles of a 1080p frame are one pass with two barriers.
 constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
 
+constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
+
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
+tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t* __restrict__ large_tiles,
                  uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
@@ -51,11 +60,32 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (int base = 0; base < num_tiles; base += 1024) {
-        const int t = base + threadIdx.x;
-        const uint32_t c = t < num_tiles ? tile_count[t] : 0u;
-        const uint32_t inc = wave_inclusive_scan(c);
+    for (int base = 0; base < num_tiles; base += 1024 * SCAN_ITEMS) {
+        const int t0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t c[SCAN_ITEMS];
+        if (t0 + SCAN_ITEMS <= num_tiles) {  // (the counter array is 16-byte aligned and t0 a multiple of 8)
+            const uint4 lo = reinterpret_cast<const uint4*>(tile_count + t0)[0], hi = reinterpret_cast<const uint4*>(tile_count + t0)[1];
+            c[0] = lo.x, c[1] = lo.y, c[2] = lo.z, c[3] = lo.w, c[4] = hi.x, c[5] = hi.y, c[6] = hi.z, c[7] = hi.w;
+            // the counters are self-cleaning: zero again for the next frame on this stream
+            reinterpret_cast<uint4*>(tile_count + t0)[0] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(tile_count + t0)[1] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) {
+                c[k] = t0 + k < num_tiles ? tile_count[t0 + k] : 0u;
+                if (t0 + k < num_tiles) tile_count[t0 + k] = 0u;
+            }
+        }
+        uint32_t mine = 0, nonempty = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) mine += c[k], nonempty += c[k] ? 1u : 0u;
+        const uint32_t inc = wave_inclusive_scan(mine);
         if (lane == 63) wsum[w] = inc;
+        // non-empty tiles of the wave (for the sparse-frame decision)
+        uint32_t ne = nonempty;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ne += (uint32_t)__shfl_xor((int)ne, d, 64);
+        if (lane == 0 && ne) atomicAdd(&n_nonempty, ne);
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
@@ -65,14 +95,30 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
             total += v;
         }
         __syncthreads();
-        if (t < num_tiles) {
-            const uint32_t start = carry + before + inc - c;
-            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
-            cursor[t] = start;
-            if (c > (uint32_t)SORT_CAP_SMALL) large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)t;  // rare
+        uint32_t start = carry + before + inc - mine;
+        uint32_t st[SCAN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            st[k] = start;
+            start += c[k];
+            if (c[k] > (uint32_t)SORT_CAP_SMALL && t0 + k < num_tiles) large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)(t0 + k);  // rare
         }
-        const unsigned long long ne = __builtin_amdgcn_ballot_w64(c != 0u);
-        if (lane == 0 && ne) atomicAdd(&n_nonempty, (uint32_t)__popcll(ne));
+        if (t0 + SCAN_ITEMS <= num_tiles) {
+            uint4* r4 = reinterpret_cast<uint4*>(ranges + t0);
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k += 2)
+                r4[k / 2] = make_uint4(c[k] ? st[k] : 0u, c[k] ? st[k] + c[k] : 0u, c[k + 1] ? st[k + 1] : 0u,
+                                       c[k + 1] ? st[k + 1] + c[k + 1] : 0u);
+            reinterpret_cast<uint4*>(cursor + t0)[0] = make_uint4(st[0], st[1], st[2], st[3]);
+            reinterpret_cast<uint4*>(cursor + t0)[1] = make_uint4(st[4], st[5], st[6], st[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k)
+                if (t0 + k < num_tiles) {
+                    ranges[t0 + k] = c[k] ? make_uint2(st[k], st[k] + c[k]) : make_uint2(0u, 0u);
+                    cursor[t0 + k] = st[k];
+                }
+        }
         carry += total;
     }
     __syncthreads();
@@ -82,12 +128,13 @@ tile_scan_kernel(const uint32_t* __restrict__ tile_count, int num_tiles, uint2* 
         // the backward blend then splits long tiles over four waves
         const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
         n_total[3] = sparse;
-        __hip_atomic_store(host_slot, ((unsigned long long)((sparse << 31) | ticket) << 32) | carry, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        // (sparse << 63 | has-long-tiles << 62 | 30-bit ticket << 32 | N)
+        const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)(n_large ? 1u : 0u) << 30);
+        __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
                       hipStream_t st)
 {
@@ -121,93 +168,6 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
         best = fmaxf(best, C * dyh * dyh + (B * dyh + A * dx) * dx);
     }
     return best;
-}
-
-// Both binning kernels below walk the (Gaussian, tile) pairs the same way.  A workgroup owns BIN_GROUP Gaussians, one
-// per thread, and a thread walks its own rectangle, record in registers (a typical splat touches 9-16 tiles, so the
-// lanes of a wave finish together) -- no staging, no cross-lane search.  A splat with more than BIN_SOLO_MAX tiles is
-// not walked by its lane: afterwards the wave takes such splats one at a time (record broadcast with v_readlane), 64
-// tiles per step, so one huge splat cannot serialise a lane.  Atomics are aggregated per workgroup in an LDS array
-// indexed by tile and touch global memory once per (workgroup, tile) with coalesced vector atomics: scattered global
-// atomics cost ~15 G cache-line transactions/s on this chip, more than everything else in the binning phase together.
-constexpr int BIN_GROUP = 1024;           // Gaussians per workgroup
-constexpr int BIN_THREADS = 1024;         // one Gaussian per thread
-constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to emit's 48 KB of staging
-constexpr uint32_t BIN_SOLO_MAX = 48;     // tiles a lane walks on its own
-
-struct SplatRect {  // what the walk needs of one Gaussian
-    float x, y, A, B, C, thr;  // centre, log2-domain half-conic, threshold on the exponent (emit only)
-    uint32_t depth_bits;
-    int minx, miny, width;
-    uint32_t cnt;  // tiles touched (0: culled)
-};
-
-__device__ __forceinline__ SplatRect load_rect(int P, const Camera& cam, const Splat* __restrict__ splats, int g, bool with_mask_inputs)
-{
-    SplatRect r;
-    r.x = r.y = 0.f, r.A = r.C = -1.f, r.B = 0.f, r.thr = 3.0e38f, r.depth_bits = 0, r.minx = r.miny = 0, r.width = 1, r.cnt = 0;
-    if (g < P) {
-        const float4 tail = reinterpret_cast<const float4*>(splats + g)[2];
-        const int radius = __float_as_int(tail.z);
-        if (radius > 0) {
-            const float4 head = reinterpret_cast<const float4*>(splats + g)[0];
-            const float px = head.x, py = head.y, radf = (float)radius;
-            // identical expressions to the preprocess kernel => identical rectangle
-            const int minx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px - radf) / 16.0f));
-            const int maxx = (int)fminf((float)cam.gx, fmaxf(0.0f, (px + radf + 15.0f) / 16.0f));
-            const int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
-            const int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
-            r.cnt = (uint32_t)((maxx - minx) * (maxy - miny));
-            r.x = px, r.y = py, r.A = head.z, r.B = head.w;
-            r.minx = minx, r.miny = miny, r.width = maxx - minx;
-            r.depth_bits = __float_as_uint(tail.y);
-            if (with_mask_inputs) {
-                const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
-                r.C = mid.x;
-                // log2 domain (hgs_common.h): contributes iff exp2(power + L) >= 1/255  <=>  power >= -(log2 255 + L);
-                // 0.07 of slack covers the blend kernels' rounding (and makes the mask a strict superset)
-                r.thr = -(7.9943534f + mid.y) - 0.07f;
-            }
-        }
-    }
-    return r;
-}
-
-// f(owner_lane, tx, ty, rect of the owner) for every tile of every rectangle held by the wave's lanes
-template <class F>
-__device__ __forceinline__ void for_each_pair(const SplatRect& mine, F&& f)
-{
-    const int lane = threadIdx.x & 63;
-    const bool big = mine.cnt > BIN_SOLO_MAX;
-    if (!big && mine.cnt) {
-        int tx = mine.minx, ty = mine.miny;
-        const int endx = mine.minx + mine.width;
-        for (uint32_t k = 0; k < mine.cnt; ++k) {
-            f(lane, tx, ty, mine);
-            if (++tx == endx) tx = mine.minx, ++ty;
-        }
-    }
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
-    while (todo) {  // wave-uniform
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        SplatRect r;
-        r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), src));
-        r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), src));
-        r.A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.A), src));
-        r.B = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.B), src));
-        r.C = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.C), src));
-        r.thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.thr), src));
-        r.depth_bits = (uint32_t)__builtin_amdgcn_readlane((int)mine.depth_bits, src);
-        r.minx = __builtin_amdgcn_readlane(mine.minx, src);
-        r.miny = __builtin_amdgcn_readlane(mine.miny, src);
-        r.width = __builtin_amdgcn_readlane(mine.width, src);
-        r.cnt = (uint32_t)__builtin_amdgcn_readlane((int)mine.cnt, src);
-        for (uint32_t k = (uint32_t)lane; k < r.cnt; k += 64u) {
-            const uint32_t ry = k / (uint32_t)r.width, rx = k - ry * (uint32_t)r.width;
-            f(src, r.minx + (int)rx, r.miny + (int)ry, r);
-        }
-    }
 }
 
 // The same walk, evenly dealt: the wave's rectangles are staged in LDS, their tile counts prefix-summed, and the pairs
@@ -251,37 +211,25 @@ __device__ __forceinline__ void for_each_pair_dealt(const PairStage& st, F&& f)
     }
 }
 
-// count: tile_count[t] += number of Gaussians of this workgroup touching tile t
-template <bool USE_LDS>
+// count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise the preprocess kernel counts):
+// tile_count[t] += number of Gaussians touching tile t, global atomics
 __global__ void __launch_bounds__(BIN_THREADS)
 count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ tile_count)
 {
-    extern __shared__ uint32_t hist[];
-    const int num_tiles = cam.gx * cam.gy;
-    uint32_t* bins = USE_LDS ? hist : tile_count;
-    if (USE_LDS) {
-        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
-        __syncthreads();
-    }
     const SplatRect mine = load_rect(P, cam, splats, blockIdx.x * BIN_GROUP + threadIdx.x, false);
-    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&bins[ty * cam.gx + tx], 1u); });
-    if (USE_LDS) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) {
-            const uint32_t c = hist[t];
-            if (c) atomicAdd(&tile_count[t], c);
-        }
-    }
+    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&tile_count[ty * cam.gx + tx], 1u); });
 }
 
 // emit: every pair takes a slot of its tile's segment and stores its 64-bit sort key there.
 // The value's low 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on some
 // pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never missing):
 // the blend kernels skip a (quad, splat) pair whose bit is clear without touching a VGPR.
+// USE_LDS: slot = segment start + this group's run start (both already known: tile_scan and the preprocess kernel's
+// returning atomics) + a workgroup-private LDS counter -- one pass, no global atomic.  Otherwise: a global atomic per pair.
 template <bool USE_LDS>
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
-            uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
+            const uint32_t* __restrict__ run_start, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
 {
     if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     extern __shared__ uint32_t hist[];
@@ -290,26 +238,10 @@ emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __res
     const int g0 = blockIdx.x * BIN_GROUP + (threadIdx.x & ~63);
     const SplatRect mine = load_rect(P, cam, splats, g0 + (threadIdx.x & 63), true);
     if (USE_LDS) {
-        // pass A: this workgroup's population of every tile; then ONE returning atomic per touched tile reserves
-        // a contiguous run of the tile's segment, and bins[] becomes the workgroup-private cursor into it
-        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = 0;
-        __syncthreads();
-        for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
-        __syncthreads();
-        // eight tiles per thread and round: the returning atomics of a round are all in flight together
-        for (int t0 = threadIdx.x; t0 < num_tiles; t0 += 8 * BIN_THREADS) {
-            uint32_t c[8], base[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * BIN_THREADS;
-                c[u] = t < num_tiles ? hist[t] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&cursor[t0 + u * BIN_THREADS], c[u]) : 0u;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c[u]) hist[t0 + u * BIN_THREADS] = base[u];
-        }
+        // this group's cursor into every tile segment (entries of tiles the group does not touch are never used, and
+        // run_start holds nothing meaningful for them)
+        const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
+        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = cursor[t] + my_runs[t];
         __syncthreads();
     }
     __shared__ float4 stage[BIN_THREADS / 64][64][3];
@@ -335,21 +267,17 @@ emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __res
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
 {
-    const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
-    if (num_tiles <= BIN_LDS_TILES)
-        hipLaunchKernelGGL(count_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, tile_count);
-    else
-        hipLaunchKernelGGL(count_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
+    hipLaunchKernelGGL(count_kernel, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
 }
 
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
-                 hipStream_t st)
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start,
+                 uint64_t* keys, const uint32_t* gate, hipStream_t st)
 {
     const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
-    if (num_tiles <= BIN_LDS_TILES)
-        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, keys, gate);
+    if (run_start)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, run_start, keys, gate);
     else
-        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, keys, gate);
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, run_start, keys, gate);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -560,7 +488,11 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
         if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
         return;
     }
-    if (n > (uint32_t)SORT_CAP_SMALL) return;
+    if (n > (uint32_t)SORT_CAP_SMALL) {
+        // the long-tile kernel's job; until it has run the tile's lists read as empty (its launch may be deferred)
+        if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
+        return;
+    }
     if (n <= 256u) tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
     else if (n <= 512u) tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
     else if (n <= 1024u) tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
@@ -666,12 +598,16 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, hipStream_t st)
+                      const uint32_t* n_total, bool small_tiles, bool long_tiles, hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                       n_total + 1);
-    hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(SORT_LARGE_THREADS), 0, st, ranges,
-                       keys, list, scratch, act, stride, act_count, large_tiles, n_total);
+    if (small_tiles)
+        hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
+                           n_total + 1);
+    // the long-tile kernel walks a device-built list that is empty on most frames: the caller skips its launch when the
+    // previous frame of this shape had no long tile, and runs it (and the forward blend again) when that guess was wrong
+    if (long_tiles)
+        hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(SORT_LARGE_THREADS), 0, st, ranges,
+                           keys, list, scratch, act, stride, act_count, large_tiles, n_total);
 }
 
 }  // namespace hgs

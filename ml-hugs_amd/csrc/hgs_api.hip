@@ -96,7 +96,8 @@ struct ProfScope {
 };
 
 // The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes -- (sparse-frame bit << 63 |
-// 31-bit ticket << 32 | N) -- and the host polls: a ring of slots so that calls from several threads / streams do not collide.
+// long-tiles bit << 62 | 30-bit ticket << 32 | N) -- and the host polls: a ring of slots so that calls from several
+// threads / streams do not collide.
 struct HostSlot { volatile unsigned long long* word; uint32_t ticket; };
 HostSlot host_slot()
 {
@@ -112,27 +113,27 @@ HostSlot host_slot()
         }
         memset(base, 0, RING * 64);
     }
-    next = (next + 1) & 0x7FFFFFFFu;
+    next = (next + 1) & 0x3FFFFFFFu;
     if (next == 0) ++next;  // ticket 0 is the initial content of a slot
     return {base + 8 * (next % RING), next};
 }
 
 // Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
 // (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
-int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out)
+int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out, bool* long_out)
 {
     for (unsigned spins = 1;; ++spins) {
         const unsigned long long v = *hs.word;
-        if (((uint32_t)(v >> 32) & 0x7FFFFFFFu) == hs.ticket) {
-            *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0;
+        if (((uint32_t)(v >> 32) & 0x3FFFFFFFu) == hs.ticket) {
+            *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0, *long_out = ((v >> 62) & 1u) != 0;
             return HGS_OK;
         }
         if ((spins & 0x3FFF) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess) {
                 const unsigned long long v2 = *hs.word;
-                if (((uint32_t)(v2 >> 32) & 0x7FFFFFFFu) == hs.ticket) {
-                    *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0;
+                if (((uint32_t)(v2 >> 32) & 0x3FFFFFFFu) == hs.ticket) {
+                    *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0, *long_out = ((v2 >> 62) & 1u) != 0;
                     return HGS_OK;
                 }
                 return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
@@ -141,6 +142,47 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
         }
         __builtin_ia32_pause();
     }
+}
+
+// Per-tile pair counters: one small device array per (device, stream), ZERO between frames -- the preprocess kernel adds
+// into it and tile_scan_kernel, its only reader, zeroes what it read.  (A frame cannot zero them itself: the adds of the
+// preprocess kernel's workgroups must not race with a fill by another workgroup of the same kernel; a memset node in
+// front of every frame is a launch this design does without.)  An entry is re-zeroed before use if the previous call on
+// its stream ended between the preprocess kernel and the scan (an error return).
+struct TileCounters {
+    int dev; hipStream_t st; uint32_t* buf; size_t tiles; bool dirty;
+};
+std::mutex g_tc_mu;
+std::vector<TileCounters> g_tc;
+
+int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, size_t* index)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_tc_mu);
+    size_t k = 0;
+    for (; k < g_tc.size(); ++k)
+        if (g_tc[k].dev == dev && g_tc[k].st == st) break;
+    if (k == g_tc.size()) g_tc.push_back({dev, st, nullptr, 0, true});
+    TileCounters& e = g_tc[k];
+    const size_t want = (tiles + 7) / 8 * 8;  // the scan reads whole groups of eight
+    if (e.tiles < want) {
+        // (the old, smaller array is left to the stream's earlier frames; it is a few KB)
+        if (hipMalloc((void**)&e.buf, want * sizeof(uint32_t)) != hipSuccess) return fail(HGS_ERR_ALLOC, "tile counter allocation failed");
+        e.tiles = want, e.dirty = true;
+    }
+    if (e.dirty) {
+        const hipError_t er = hipMemsetAsync(e.buf, 0, e.tiles * sizeof(uint32_t), st);
+        if (er != hipSuccess) return fail(HGS_ERR_HIP, "hipMemsetAsync(tile counters): %s", hipGetErrorString(er));
+    }
+    e.dirty = true;  // until this call has enqueued the scan
+    *out = e.buf, *index = k;
+    return HGS_OK;
+}
+void tile_counters_clean(size_t index)
+{
+    std::lock_guard<std::mutex> lk(g_tc_mu);
+    g_tc[index].dirty = false;
 }
 
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
@@ -213,18 +255,18 @@ int32_t hgs_profile_read(int32_t stage, double* total_ms, int64_t* launches)
 }
 const char* hgs_stage_name(int32_t stage)
 {
-    static const char* names[HGS_NUM_STAGES] = {"preprocess", "scan", "emit_keys", "sort", "tile_ranges",
+    static const char* names[HGS_NUM_STAGES] = {"preprocess", "scan", "emit_keys", "sort",
                                                 "blend_forward", "blend_backward", "preprocess_backward"};
     return stage >= 0 && stage < HGS_NUM_STAGES ? names[stage] : "?";
 }
 
-size_t hgs_geom_bytes(int32_t P) { return GeomLayout(P < 1 ? 1 : P).total; }
+size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return GeomLayout(P < 1 ? 1 : P, num_tiles_of(H, W)).total; }
 size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
 
 size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int32_t W)
 {
-    GeomLayout g(P < 1 ? 1 : P);
+    GeomLayout g(P < 1 ? 1 : P, num_tiles_of(H, W));
     ImageLayout im(H, W);
     BinningLayout b(N);
     if (!strcmp(name, "splats")) return g.splats;
@@ -249,7 +291,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (!a.out_color || !a.radii) return fail(HGS_ERR_INVALID_ARGUMENT, "out_color and radii are required");
     const bool dbg = a.s.debug != 0;
 
-    GeomLayout gl(a.P);
+    const int num_tiles = cam.gx * cam.gy;
+    GeomLayout gl(a.P, num_tiles);
     ImageLayout il(cam.H, cam.W);
     char* geom = (char*)alloc(alloc_ctx, HGS_BUF_GEOM, gl.total);
     char* image = (char*)alloc(alloc_ctx, HGS_BUF_IMAGE, il.total);
@@ -259,15 +302,18 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     Splat* splats = (Splat*)(geom + gl.splats);
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
+    // the preprocess kernel counts pairs per tile itself when the tile array fits LDS (any frame up to ~7 Mpixel)
+    uint32_t* run_start = num_tiles <= BIN_LDS_TILES ? (uint32_t*)(geom + gl.run_start) : nullptr;
     uint2* ranges = (uint2*)(image + il.ranges);
-    uint32_t* tile_count = (uint32_t*)(image + il.tile_count);
     uint32_t* cursor = (uint32_t*)(image + il.cursor);
     uint32_t* n_total = (uint32_t*)(image + il.n_total);
     uint32_t* large_tiles = (uint32_t*)(image + il.large_tiles);
-    const int num_tiles = cam.gx * cam.gy;
+    uint32_t* tile_count = nullptr;
+    size_t tc_index = 0;
+    if (int rc = acquire_tile_counters(st, (size_t)num_tiles, &tile_count, &tc_index)) return rc;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
-      launch_preprocess(a, cam, splats, tiles_touched, tile_count, st); }
+      launch_preprocess(a, cam, splats, tiles_touched, tile_count, run_start, st); }
     STAGE_CHECK(dbg, st, "preprocess");
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
@@ -275,14 +321,17 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
-      launch_count(a.P, cam, splats, tile_count, st);
+      if (!run_start) launch_count(a.P, cam, splats, tile_count, st);
       launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, large_tiles, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
+    tile_counters_clean(tc_index);  // the scan, which re-zeroes them, is enqueued
 
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
     const uint32_t* gate = n_total + 1;
+    // the long-tile sort is launched unless the caller expects no long tile (its previous frame of this shape had none)
+    const bool guess_no_long = a.expect_no_long_tiles != 0;
     // enqueue emit -> sort -> blend for a binning buffer laid out for `capacity` entries
-    auto enqueue_frame = [&](int64_t capacity) -> int {
+    auto enqueue_frame = [&](int64_t capacity, bool with_long_sort) -> int {
         BinningLayout bl(capacity);
         char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
         if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
@@ -290,10 +339,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, keys, gate, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
-          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total, st); }
+          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total, true, with_long_sort, st); }
         STAGE_CHECK(dbg, st, "tile_sort");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
           launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
@@ -302,19 +351,36 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         return HGS_OK;
     };
 
-    if (hint > 0)
-        if (int rc = enqueue_frame(hint)) return rc;  // optimistic: the GPU runs on while the host waits for N below
+    bool long_sort_done = false, enqueued = false;
+    if (hint > 0) {
+        if (int rc = enqueue_frame(hint, !guess_no_long)) return rc;  // optimistic: the GPU runs on while the host waits for N below
+        long_sort_done = !guess_no_long, enqueued = true;
+    }
     uint32_t n32 = 0;
-    bool sparse = false;
-    if (int rc = wait_for_slot(slot, st, &n32, &sparse)) return rc;
+    bool sparse = false, has_long = false;
+    if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long)) return rc;
     const int64_t N = (int64_t)n32;
     state->num_rendered = N;
     state->sparse_frame = sparse ? 1 : 0;
-    if (hint <= 0 || N > hint) {
-        // exact size known now; after a too-small guess the gated kernels above did nothing, and the emit cursors are
-        // untouched, so the frame is simply enqueued again
-        HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
-        if (int rc = enqueue_frame(N)) return rc;
+    state->has_long_tiles = has_long ? 1 : 0;
+    if (!enqueued || N > hint) {
+        // exact size known now (and whether there are long tiles); after a too-small guess the gated kernels above did
+        // nothing, so the frame is simply enqueued again
+        if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
+        if (int rc = enqueue_frame(N, has_long)) return rc;
+    } else if (has_long && !long_sort_done) {
+        // guessed "no long tiles" wrongly: their lists read as empty so far -- sort them now and blend again
+        BinningLayout bl(state->binning_capacity);
+        char* bin = (char*)state->binning;
+        uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
+        { ProfScope ps(HGS_STAGE_SORT, st);
+          launch_tile_sort(ranges, num_tiles, (uint64_t*)(bin + bl.keys), (uint64_t*)(bin + bl.list), (uint64_t*)(bin + bl.scratch), act,
+                           bl.act_stride, act_count, large_tiles, n_total, false, true, st); }
+        STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
+        { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
+          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
+                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, a.clamp_output != 0, st); }
+        STAGE_CHECK(dbg, st, "blend_forward (after long tiles)");
     }
     return N;
 }
@@ -334,7 +400,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
         !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
         return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");
     const bool dbg = f.s.debug != 0;
-    GeomLayout gl(f.P);
+    GeomLayout gl(f.P, cam.gx * cam.gy);
     ImageLayout il(cam.H, cam.W);
     BinningLayout bl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered);
     if (a.state.geom_bytes < gl.total || a.state.image_bytes < il.total || a.state.binning_bytes < bl.total)

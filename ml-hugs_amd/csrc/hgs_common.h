@@ -44,19 +44,30 @@ struct Camera {  // small by-value kernel argument
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
+#ifndef HGS_BIN_GROUP
+#define HGS_BIN_GROUP 1024
+#endif
+constexpr int BIN_GROUP = HGS_BIN_GROUP;           // Gaussians per binning workgroup (preprocess + emit share the partition)
+constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to emit's 48 KB of staging
+inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
 struct GeomLayout {
-    size_t splats, tiles_touched, total;
-    explicit GeomLayout(int P) {
+    size_t splats, tiles_touched, run_start, total;
+    GeomLayout(int P, int num_tiles) {
         size_t o = 0;
         splats = o;         o = align_up(o + sizeof(Splat) * (size_t)P);
         tiles_touched = o;  o = align_up(o + 4 * (size_t)P);
+        // run_start[group][tile]: where, inside the tile's segment, the run of binning group `group` (BIN_GROUP
+        // consecutive Gaussians) begins -- handed out by the preprocess kernel's returning atomics, consumed by emit.
+        // Only (group, tile) pairs with at least one entry are ever written or read.
+        run_start = o;
+        if (num_tiles <= BIN_LDS_TILES) o = align_up(o + 4 * (size_t)((P + BIN_GROUP - 1) / BIN_GROUP) * (size_t)num_tiles);
         total = o;
     }
 };
 constexpr int ACT_PAD = 16;
 constexpr int NUM_LISTS = 5;  // four per-quad lists + one "any quad" list per tile
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, act_count, tile_count, cursor, large_tiles, n_total, total;
+    size_t final_T, n_contrib, ranges, act_count, cursor, large_tiles, n_total, total;
     ImageLayout(int H, int W) {
         size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
         size_t o = 0;
@@ -64,8 +75,7 @@ struct ImageLayout {
         n_contrib = o;  o = align_up(o + 4 * S);
         ranges = o;     o = align_up(o + 8 * T);
         act_count = o;  o = align_up(o + 4 * T * NUM_LISTS);   // entries in each tile's compacted lists
-        tile_count = o; o = align_up(o + 4 * T);   // Gaussians touching each tile (zeroed by K1, count kernel adds)
-        cursor = o;     o = align_up(o + 4 * T);   // next free slot of each tile's segment (atomics in emit)
+        cursor = o;     o = align_up(o + 4 * T);   // start of each tile's segment (the fallback emit path advances it with atomics)
         large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
         n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles, [3] sparse-frame flag
         total = o;
@@ -92,21 +102,25 @@ struct BinningLayout {
 // kernels / launchers (defined in the .hip files)
 void set_last_error(const char* msg);  // hgs_api.hip
 
+// tile_count: ZERO on entry (hgs_api.hip keeps a self-cleaning counter array per stream).  run_start != nullptr: the
+// kernel also counts the (Gaussian, tile) pairs per tile (LDS histogram per BIN_GROUP Gaussians, one returning atomic per
+// touched tile) and records every group's run offsets; nullptr: count_kernel does the counting (very large tile counts).
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, hipStream_t st);
+                       uint32_t* tile_count, uint32_t* run_start, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
-void launch_tile_scan(const uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+// (re-zeroes tile_count behind itself)
+void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
                       hipStream_t st);
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, uint64_t* keys, const uint32_t* gate,
-                 hipStream_t st);
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start,
+                 uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, hipStream_t st);
+                      const uint32_t* n_total, bool small_tiles, bool long_tiles, hipStream_t st);
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,

@@ -27,7 +27,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 4
+_ABI_VERSION = 5
 
 
 def library_path():
@@ -48,14 +48,14 @@ class _ForwardArgs(C.Structure):
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
-                ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("reserved", C.c_int32)]
+                ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32)]
 
 
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
                 ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("has_long_tiles", C.c_int32)]
 
 
 class _BackwardArgs(C.Structure):
@@ -92,7 +92,7 @@ def _load():
     lib.hgs_last_error.restype = C.c_char_p
     for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_scratch_offset):
         fn.restype = C.c_size_t
-    lib.hgs_geom_bytes.argtypes = [C.c_int32]
+    lib.hgs_geom_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
@@ -107,8 +107,7 @@ def _load():
     return lib
 
 
-STAGES = ("preprocess", "scan", "emit_keys", "sort", "tile_ranges", "blend_forward", "blend_backward",
-          "preprocess_backward")
+STAGES = ("preprocess", "scan", "emit_keys", "sort", "blend_forward", "blend_backward", "preprocess_backward")
 
 
 def profile_enable(stages=STAGES):
@@ -208,8 +207,12 @@ _USE_HINT = os.environ.get("HGS_BINNING_HINT", "1") != "0"
 
 
 def _capacity_hint(key):
-    n = _last_num_rendered.get(key) if _USE_HINT else None
-    return 0 if n is None else n + n // 8 + 4096
+    """(binning_capacity_hint, expect_no_long_tiles) from the previous frame of this shape"""
+    prev = _last_num_rendered.get(key) if _USE_HINT else None
+    if prev is None:
+        return 0, 0
+    n, had_long = prev
+    return n + n // 8 + 4096, 0 if had_long else 1
 
 
 def _grad_slab(P, M, dev, zero):
@@ -280,7 +283,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _point_at_grads(bw, grads, M)
             args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
-        args.binning_capacity_hint = _capacity_hint(hint_key)
+        args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), stream)
@@ -291,7 +294,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.binning_capacity = int(state.binning_capacity)
         if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
             _last_num_rendered.clear()
-        _last_num_rendered[hint_key] = int(n)
+        _last_num_rendered[hint_key] = (int(n), bool(state.has_long_tiles))
         ctx.bw, ctx.grads, ctx.keep, ctx.dims = bw, grads, keep, (P, M)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D,

@@ -197,12 +197,12 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     dgr._last_num_rendered.pop(key, None)
     t0, c0, r0 = run_gpu(sc, device)                       # no guess: waits for N, exact capacity
     n = c0.grad_fn.num_rendered
-    assert c0.grad_fn.binning_capacity == n and dgr._last_num_rendered[key] == n
+    assert c0.grad_fn.binning_capacity == n and dgr._last_num_rendered[key] == (n, False)
     c0.backward(to_dev(sc["dL_dpix"], device))
     if guess == "none":
         dgr._last_num_rendered.pop(key)
     elif guess == "too_small":
-        monkeypatch.setattr(dgr, "_capacity_hint", lambda k: 100)
+        monkeypatch.setattr(dgr, "_capacity_hint", lambda k: (100, 1))
         assert n > 1000
     t1, c1, r1 = run_gpu(sc, device)
     cap = c1.grad_fn.binning_capacity
@@ -562,6 +562,48 @@ def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, longest_
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         r = refg[k]
         assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+
+
+@pytest.mark.parametrize("wrong_guess", ["no_long_tiles", "capacity_and_no_long_tiles"])
+def test_wrong_guess_about_long_tiles_never_changes_results(wrong_guess, device, monkeypatch):
+    """With a hint the frame is enqueued before the host knows whether any tile list exceeds 2048 entries; the caller's
+    guess `expect_no_long_tiles` (previous frame of this shape had none) skips the long-tile sort launch.  A wrong guess
+    must be repaired -- long tiles sorted, forward blend repeated -- with identical results (include/hgs_rasterizer.h)."""
+    import diff_gaussian_rasterization as dgr
+    sc = _stacked_scene(6000, 64, 64, seed=47, spread_px=6.0)     # longest tile list in 2049..8192
+    key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])
+    dgr._last_num_rendered.pop(key, None)
+    t0, c0, r0 = run_gpu(sc, device)                               # no hint: everything known before binning
+    n = c0.grad_fn.num_rendered
+    assert dgr._last_num_rendered[key] == (n, True)
+    c0.backward(to_dev(sc["dL_dpix"], device))
+    cap = n + 999 if wrong_guess == "no_long_tiles" else 100
+    monkeypatch.setattr(dgr, "_capacity_hint", lambda k: (cap, 1))
+    t1, c1, r1 = run_gpu(sc, device)
+    assert c1.grad_fn.num_rendered == n and dgr._last_num_rendered[key] == (n, True)
+    c1.backward(to_dev(sc["dL_dpix"], device))
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= 1e-5, k
+
+
+def test_tile_counters_are_clean_after_every_frame(device):
+    """The per-stream tile counters are zeroed by the scan that reads them: frames of different sizes, alternating on one
+    stream and on a second stream, keep producing the oracle's N and ranges."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    scs = [make_scene(**CASES[n]) for n in ("basic_d3", "deg1_ragged", "big_splats")]
+    refs = [ho.forward(oracle_inputs(sc), stop_after="binning") for sc in scs]
+    side = torch.cuda.Stream(device)
+    for rep in range(3):
+        for sc, ref in zip(scs, refs):
+            for stream in (torch.cuda.current_stream(device), side):
+                with torch.cuda.stream(stream):
+                    t = gpu_tensors(sc, device, grad=False)
+                    _, _, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                                    scales=t["scales"], rotations=t["rotations"])
+                    assert st["N"] == ref["N"]
+                    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
 
 
 def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):

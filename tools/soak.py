@@ -30,7 +30,7 @@ while time.time() - t0 < 40:
     H, W = random.choice(shapes); P = random.choice([1, 50, 3000, 40000, 200000 if H >= 270 else 5000])
     t, st, m2d, dL = scene(P, H, W)
     r = random.random()
-    dgr._capacity_hint = (lambda k: 64) if r < 0.1 else ((lambda k: 0) if r < 0.2 else orig_hint)
+    dgr._capacity_hint = (lambda k: (64, 1)) if r < 0.1 else ((lambda k: (0, 0)) if r < 0.2 else orig_hint)
     s = random.choice(streams)
     s.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(s):

@@ -43,7 +43,9 @@ enum {
     HGS_ERR_INVALID_ARGUMENT = -1,
     HGS_ERR_ALLOC = -2,
     HGS_ERR_HIP = -3,
-    HGS_ERR_NO_DEVICE = -4
+    HGS_ERR_NO_DEVICE = -4,
+    HGS_PENDING = -5,        /* hgs_forward_poll: the frame's tile scan has not run yet */
+    HGS_ERR_OVERFLOW = -6    /* hgs_forward_poll: a deferred frame needed more binning entries than it was given */
 };
 
 /* Returns a device pointer to at least `bytes` bytes, 256-byte aligned, or NULL. */
@@ -100,6 +102,19 @@ typedef struct hgs_forward_args {
      * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
      * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
     int32_t expect_no_long_tiles;
+    /* !=0 (needs binning_capacity_hint > 0): DEFERRED frame -- everything is enqueued for a binning buffer of
+     * binning_capacity_hint entries and the call returns 0 at once, without waiting for N (the GPU never waits for the
+     * host anyway; this takes the host's one wait per frame away too: forward-only frame loops pipeline freely).  The
+     * caller MUST later call hgs_forward_poll(state): it yields N, or HGS_ERR_OVERFLOW when the frame needed more than
+     * the hint -- its kernels then did nothing and out_color / radii are NOT valid until the frame is run again.  Use a
+     * generous hint (the scratch is the caller's: e.g. a persistent arena per stream). */
+    int32_t defer_n;
+    int32_t reserved;
+    /* Optional caller-provided scratch (e.g. persistent arenas for frames that need no backward): buffer k
+     * (HGS_BUF_GEOM / HGS_BUF_BINNING / HGS_BUF_IMAGE) is used when scratch[k] != NULL and scratch_bytes[k] suffices,
+     * otherwise the allocation callback is asked as usual.  256-byte aligned device pointers. */
+    void *scratch[3];
+    size_t scratch_bytes[3];
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -111,6 +126,7 @@ typedef struct hgs_forward_state {
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad its own wave */
     int32_t has_long_tiles;   /* !=0: some tile list is longer than 2048 entries (feeds the next frame's expect_no_long_tiles) */
+    uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */
@@ -138,6 +154,10 @@ typedef struct hgs_backward_args {
 } hgs_backward_args;
 
 int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);
+
+/* For a frame enqueued with defer_n: N (and state->num_rendered / sparse_frame / has_long_tiles filled in), HGS_PENDING
+ * when block == 0 and the frame's tile scan has not run yet, HGS_ERR_OVERFLOW (see defer_n), or another error code. */
+int64_t hgs_forward_poll(hgs_forward_state *state, int32_t block, void *stream);
 
 /* Replaces _C.mark_visible: present[i] = (z_view(means3D[i]) > 0.2). */
 int32_t hgs_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present,

@@ -98,24 +98,24 @@ struct ProfScope {
 // The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes -- (sparse-frame bit << 63 |
 // long-tiles bit << 62 | 30-bit ticket << 32 | N) -- and the host polls: a ring of slots so that calls from several
 // threads / streams do not collide.
-struct HostSlot { volatile unsigned long long* word; uint32_t ticket; };
+struct HostSlot { volatile unsigned long long* word; uint32_t ticket; uint32_t index; };
+constexpr unsigned SLOT_RING = 1024;  // deferred frames are polled later: far more slots than frames anyone keeps in flight
+unsigned long long* g_slot_base = nullptr;
 HostSlot host_slot()
 {
-    constexpr unsigned RING = 64;
     static std::mutex mu;
-    static unsigned long long* base = nullptr;
     static uint32_t next = 0;
     std::lock_guard<std::mutex> lk(mu);
-    if (!base) {
-        if (hipHostMalloc((void**)&base, RING * 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-            base = nullptr;
-            return {nullptr, 0};
+    if (!g_slot_base) {
+        if (hipHostMalloc((void**)&g_slot_base, SLOT_RING * 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            g_slot_base = nullptr;
+            return {nullptr, 0, 0};
         }
-        memset(base, 0, RING * 64);
+        memset(g_slot_base, 0, SLOT_RING * 64);
     }
     next = (next + 1) & 0x3FFFFFFFu;
     if (next == 0) ++next;  // ticket 0 is the initial content of a slot
-    return {base + 8 * (next % RING), next};
+    return {g_slot_base + 8 * (next % SLOT_RING), next, next % SLOT_RING};
 }
 
 // Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
@@ -183,6 +183,14 @@ void tile_counters_clean(size_t index)
 {
     std::lock_guard<std::mutex> lk(g_tc_mu);
     g_tc[index].dirty = false;
+}
+
+bool slot_ready(const HostSlot& hs, uint32_t* n_out, bool* sparse_out, bool* long_out)
+{
+    const unsigned long long v = *hs.word;
+    if (((uint32_t)(v >> 32) & 0x3FFFFFFFu) != hs.ticket) return false;
+    *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0, *long_out = ((v >> 62) & 1u) != 0;
+    return true;
 }
 
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
@@ -294,8 +302,14 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const int num_tiles = cam.gx * cam.gy;
     GeomLayout gl(a.P, num_tiles);
     ImageLayout il(cam.H, cam.W);
-    char* geom = (char*)alloc(alloc_ctx, HGS_BUF_GEOM, gl.total);
-    char* image = (char*)alloc(alloc_ctx, HGS_BUF_IMAGE, il.total);
+    // caller-provided scratch when it suffices, else the allocation callback
+    auto obtain = [&](int which, size_t bytes) -> char* {
+        if (a.scratch[which] && a.scratch_bytes[which] >= bytes) return (char*)a.scratch[which];
+        return (char*)alloc(alloc_ctx, which, bytes);
+    };
+    if (a.defer_n && a.binning_capacity_hint <= 0) return fail(HGS_ERR_INVALID_ARGUMENT, "defer_n needs a binning_capacity_hint");
+    char* geom = obtain(HGS_BUF_GEOM, gl.total);
+    char* image = obtain(HGS_BUF_IMAGE, il.total);
     if (!geom || !image) return fail(HGS_ERR_ALLOC, "scratch allocation failed (geom %zu B, image %zu B)", gl.total, il.total);
     state->geom = geom, state->geom_bytes = gl.total;
     state->image = image, state->image_bytes = il.total;
@@ -333,7 +347,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // enqueue emit -> sort -> blend for a binning buffer laid out for `capacity` entries
     auto enqueue_frame = [&](int64_t capacity, bool with_long_sort) -> int {
         BinningLayout bl(capacity);
-        char* bin = (char*)alloc(alloc_ctx, HGS_BUF_BINNING, bl.total);
+        char* bin = obtain(HGS_BUF_BINNING, bl.total);
         if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
         state->binning = bin, state->binning_bytes = bl.total, state->binning_capacity = capacity;
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
@@ -352,6 +366,13 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     };
 
     bool long_sort_done = false, enqueued = false;
+    state->n_token = ((uint64_t)slot.index << 32) | slot.ticket;
+    if (a.defer_n) {
+        // deferred frame: never waits; nothing can be repaired later, so the long-tile sort is always part of it
+        if (int rc = enqueue_frame(hint, true)) return rc;
+        state->num_rendered = -1;
+        return 0;
+    }
     if (hint > 0) {
         if (int rc = enqueue_frame(hint, !guess_no_long)) return rc;  // optimistic: the GPU runs on while the host waits for N below
         long_sort_done = !guess_no_long, enqueued = true;
@@ -383,6 +404,27 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         STAGE_CHECK(dbg, st, "blend_forward (after long tiles)");
     }
     return N;
+}
+
+int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
+{
+    if (!state) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
+    if (state->num_rendered >= 0) return state->num_rendered;
+    const uint32_t index = (uint32_t)(state->n_token >> 32), ticket = (uint32_t)state->n_token;
+    if (!g_slot_base || index >= SLOT_RING || ticket == 0) return fail(HGS_ERR_INVALID_ARGUMENT, "state does not belong to a deferred frame");
+    const HostSlot hs{g_slot_base + 8 * index, ticket, index};
+    uint32_t n32 = 0;
+    bool sparse = false, has_long = false;
+    if (!slot_ready(hs, &n32, &sparse, &has_long)) {
+        if (!block) return HGS_PENDING;
+        if (int rc = wait_for_slot(hs, (hipStream_t)stream, &n32, &sparse, &has_long)) return rc;
+    }
+    state->sparse_frame = sparse ? 1 : 0, state->has_long_tiles = has_long ? 1 : 0;
+    if ((int64_t)n32 > state->binning_capacity)
+        return fail(HGS_ERR_OVERFLOW, "deferred frame needed %u binning entries but was given %lld: its output is invalid, run it again",
+                    n32, (long long)state->binning_capacity);
+    state->num_rendered = (int64_t)n32;
+    return state->num_rendered;
 }
 
 int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)

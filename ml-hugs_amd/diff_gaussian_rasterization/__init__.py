@@ -22,7 +22,8 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "library_path"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_deferred", "DeferredFrame",
+           "library_path"]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
@@ -48,14 +49,15 @@ class _ForwardArgs(C.Structure):
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
-                ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32)]
+                ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
+                ("defer_n", C.c_int32), ("reserved", C.c_int32), ("scratch", C.c_void_p * 3), ("scratch_bytes", C.c_size_t * 3)]
 
 
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
                 ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
-                ("has_long_tiles", C.c_int32)]
+                ("has_long_tiles", C.c_int32), ("n_token", C.c_uint64)]
 
 
 class _BackwardArgs(C.Structure):
@@ -87,6 +89,8 @@ def _load():
                                           C.POINTER(_ForwardState), C.c_void_p]
     lib.hgs_rasterize_backward.restype = C.c_int32
     lib.hgs_rasterize_backward.argtypes = [C.POINTER(_BackwardArgs), C.c_void_p]
+    lib.hgs_forward_poll.restype = C.c_int64
+    lib.hgs_forward_poll.argtypes = [C.POINTER(_ForwardState), C.c_int32, C.c_void_p]
     lib.hgs_mark_visible.restype = C.c_int32
     lib.hgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hgs_last_error.restype = C.c_char_p
@@ -206,6 +210,18 @@ _last_num_rendered = {}
 _USE_HINT = os.environ.get("HGS_BINNING_HINT", "1") != "0"
 
 
+_max_num_rendered = {}   # largest N seen per shape key: sizes the binning arena of deferred frames
+_DEFERRED_MIN_CAPACITY = 1 << 22
+
+
+def _remember(key, n, has_long):
+    if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
+        _last_num_rendered.clear()
+        _max_num_rendered.clear()
+    _last_num_rendered[key] = (n, has_long)
+    _max_num_rendered[key] = max(n, _max_num_rendered.get(key, 0))
+
+
 def _capacity_hint(key):
     """(binning_capacity_hint, expect_no_long_tiles) from the previous frame of this shape"""
     prev = _last_num_rendered.get(key) if _USE_HINT else None
@@ -215,28 +231,74 @@ def _capacity_hint(key):
     return n + n // 8 + 4096, 0 if had_long else 1
 
 
-def _grad_slab(P, M, dev, zero):
-    """One allocation carved into the [P,12] atomic accumulator (the only part that must be zero -- the library
-    overwrites every other element; `zero=False` when forward is asked to zero it) and the eight gradient tensors."""
-    sizes = [12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P]
+_GRAD_NAMES = ("grad_accum", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+               "dL_drotations")
+
+
+def _grad_layout(P, M):
+    """Element offsets of the [P,12] atomic accumulator and the eight gradient tensors inside one fp32 slab."""
+    sizes = (12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P)
     offs, total = [], 0
     for n in sizes:
         offs.append(total)
         total += (n + 63) // 64 * 64
-    slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+    return sizes, offs, max(total, 1)
+
+
+def _grad_slab(P, M, dev, zero, bw):
+    """One allocation for the accumulator (the only part that must be zero -- the library overwrites every other element;
+    `zero=False` when forward is asked to zero it) and the gradient tensors; the backward argument block is pointed at
+    it by address arithmetic, the tensor views are only made for what backward() returns."""
+    sizes, offs, total = _grad_layout(P, M)
+    slab = torch.empty(total, dtype=torch.float32, device=dev)
     if zero:
         slab[:max(offs[1], 1)].zero_()
-    view = lambda k, *shape: slab[offs[k]:offs[k] + sizes[k]].view(*shape)
-    return (view(0, P, 12), view(1, P, 3), view(2, P, 1), view(3, P, 3), view(4, P, 3), view(5, P, 6),
-            view(6, P, M, 3), view(7, P, 3), view(8, P, 4))
+    base = slab.data_ptr()
+    for k, name in enumerate(_GRAD_NAMES):
+        setattr(bw, name, base + 4 * offs[k] if (sizes[k] or k != 6) else None)
+    return slab
 
 
-def _point_at_grads(a, grads, M):
-    g_accum, g_means2D, g_opacity, g_colors, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
-    a.grad_accum, a.dL_dmeans2D, a.dL_dopacity = g_accum.data_ptr(), g_means2D.data_ptr(), g_opacity.data_ptr()
-    a.dL_dcolors, a.dL_dmeans3D, a.dL_dcov3D = g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr()
-    a.dL_dsh = g_sh.data_ptr() if M else None
-    a.dL_dscales, a.dL_drotations = g_scales.data_ptr(), g_rot.data_ptr()
+def _grad_view(slab, P, M, k, *shape):
+    sizes, offs, _ = _grad_layout(P, M)
+    return slab[offs[k]:offs[k] + sizes[k]].view(*shape)
+
+
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+# Scratch for frames that need no backward (validation / animation / canonical render loops run under torch.no_grad(),
+# gs_trainer.py:448-684): one persistent arena per (device, stream) instead of three allocations per frame.  Work on a
+# stream is ordered, so the next frame on that stream may overwrite it.
+_arenas = {}
+
+
+def _arena(dev, stream_id, nbytes):
+    key = (dev.index, stream_id)
+    t = _arenas.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        _arenas[key] = t
+    return t
+
+
+def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=None):
+    """Pre-sized scratch handed to the library through args.scratch (no allocation callbacks): one buffer holding geom |
+    image | binning(capacity).  Returns (buffer, (offsets))."""
+    g, im = _align(lib.hgs_geom_bytes(P, H, W)), _align(lib.hgs_image_bytes(H, W))
+    b = _align(lib.hgs_binning_bytes(capacity, H, W)) if capacity > 0 else 0
+    total = g + im + b
+    buf = _arena(dev, persistent_for_stream, total) if persistent_for_stream is not None else \
+        torch.empty(total, dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    base_al = _align(base)
+    o = base_al - base            # (torch's caching allocator hands out 512-byte aligned blocks: o == 0)
+    args.scratch[0], args.scratch_bytes[0] = base_al, g
+    args.scratch[2], args.scratch_bytes[2] = base_al + g, im
+    if b:
+        args.scratch[1], args.scratch_bytes[1] = base_al + g + im, b
+    return buf, (o, g, o + g, im, o + g + im, b)   # geom off/len, image off/len, binning off/len
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -277,25 +339,35 @@ class _RasterizeGaussians(torch.autograd.Function):
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
         args.clamp_output = 1 if clamp_output else 0
         M = int(args.M)
-        grads = None
-        if P > 0 and any(ctx.needs_input_grad):
-            grads = _grad_slab(P, M, dev, zero=False)
-            _point_at_grads(bw, grads, M)
+        needs_grad = P > 0 and any(ctx.needs_input_grad)
+        slab = None
+        if needs_grad:
+            slab = _grad_slab(P, M, dev, False, bw)
             args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
-        with torch.cuda.device(dev):
-            stream = _stream_ptr(dev)
-            n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), stream)
+        prev_dev = torch.cuda.current_device()
+        if prev_dev != dev.index:
+            torch.cuda.set_device(dev)
+        try:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            scratch = None
+            if P > 0:
+                # pre-sized scratch, no allocation callbacks: per frame when backward will need it, else the stream's arena
+                scratch = _provide_scratch(args, lib, dev, P, H, W, int(args.binning_capacity_hint),
+                                           None if needs_grad else stream)
+            n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), C.c_void_p(stream))
+        finally:
+            if prev_dev != dev.index:
+                torch.cuda.set_device(prev_dev)
         if n < 0:
             _raise_last(lib, "rasterize_gaussians")
 
         ctx.num_rendered = int(n)
         ctx.binning_capacity = int(state.binning_capacity)
-        if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
-            _last_num_rendered.clear()
-        _last_num_rendered[hint_key] = (int(n), bool(state.has_long_tiles))
-        ctx.bw, ctx.grads, ctx.keep, ctx.dims = bw, grads, keep, (P, M)
+        _remember(hint_key, int(n), bool(state.has_long_tiles))
+        ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P, M)
+        ctx.scratch, ctx.bufs = scratch, bufs   # kept alive for backward (and read by _debug_forward_state)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D,
                               sh if sh is not None else empty,
@@ -304,7 +376,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               scales if scales is not None else empty,
                               rotations if rotations is not None else empty,
                               cov3Ds_precomp if cov3Ds_precomp is not None else empty,
-                              radii, bufs.get(0, empty), bufs.get(1, empty), bufs.get(2, empty))
+                              radii)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zero-filled int32 "gradient" for radii
         return color, radii
@@ -313,37 +385,41 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         lib = _load()
         # the saved tensors are what `ctx.bw` points into: unpacking them also runs autograd's in-place-modification check
-        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, _radii, _geom, _binning,
-         _image) = ctx.saved_tensors
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, _radii = ctx.saved_tensors
         dev = means3D.device
         P, M = ctx.dims
-        bw, grads = ctx.bw, ctx.grads
+        bw, slab = ctx.bw, ctx.slab
         if grad_out_color is None:  # colour did not take part in the loss
-            ctx.grads = None
+            ctx.slab = None
             return (None,) * 10
-        if grads is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
-            grads = _grad_slab(P, M, dev, zero=True)
-            _point_at_grads(bw, grads, M)
-        ctx.grads = None
-        g_accum, g_means2D, g_opacity, g_colors, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
+        if slab is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
+            slab = _grad_slab(P, M, dev, True, bw)
+        ctx.slab = None
 
         if P > 0:
             grad_out_color = _f32c(grad_out_color)
             bw.dL_dout_color = grad_out_color.data_ptr()
-            with torch.cuda.device(dev):
-                rc = lib.hgs_rasterize_backward(C.byref(bw), _stream_ptr(dev))
+            prev_dev = torch.cuda.current_device()
+            if prev_dev != dev.index:
+                torch.cuda.set_device(dev)
+            try:
+                rc = lib.hgs_rasterize_backward(C.byref(bw), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            finally:
+                if prev_dev != dev.index:
+                    torch.cuda.set_device(prev_dev)
             if rc < 0:
                 _raise_last(lib, "rasterize_gaussians_backward")
 
+        v = lambda k, *shape: _grad_view(slab, P, M, k, *shape)
         # order of forward's inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
         # cov3Ds_precomp, raster_settings
-        return (g_means3D, g_means2D,
-                g_sh if sh.numel() else None,
-                g_colors if colors_precomp.numel() else None,
-                g_opacity,
-                g_scales if scales.numel() else None,
-                g_rot if rotations.numel() else None,
-                g_cov3D if cov3Ds_precomp.numel() else None,
+        return (v(4, P, 3), v(1, P, 3),
+                v(6, P, M, 3) if sh.numel() else None,
+                v(3, P, 3) if colors_precomp.numel() else None,
+                v(2, P, 1),
+                v(7, P, 3) if scales.numel() else None,
+                v(8, P, 4) if rotations.numel() else None,
+                v(5, P, 6) if cov3Ds_precomp.numel() else None,
                 None, None)
 
 
@@ -351,6 +427,92 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                         raster_settings, clamp_output=False):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, clamp_output)
+
+
+class DeferredFrame:
+    """A forward-only frame that was enqueued without the host waiting for its N (hgs_forward_args.defer_n).  `color`
+    and `radii` are valid once resolve() has returned (it checks that the frame fitted its binning buffer and, if it
+    did not, runs it again with the exact size -- same output tensors, same stream)."""
+    __slots__ = ("color", "radii", "args", "state", "keep", "stream", "key", "num_rendered")
+
+    def resolve(self):
+        if self.num_rendered is not None:
+            return self.num_rendered
+        lib = _load()
+        dev = self.color.device
+        with torch.cuda.device(dev):
+            n = lib.hgs_forward_poll(C.byref(self.state), 1, C.c_void_p(self.stream.cuda_stream))
+            if n == -6:   # HGS_ERR_OVERFLOW: the gated kernels did nothing -- run the frame again, waiting for N this time
+                self.args.defer_n, self.args.binning_capacity_hint = 0, 0
+                bufs = []
+
+                def _alloc(_ctx, which, nbytes):
+                    bufs.append(torch.empty(int(nbytes), dtype=torch.uint8, device=dev))
+                    return bufs[-1].data_ptr()
+
+                with torch.cuda.stream(self.stream):
+                    n = lib.hgs_rasterize_forward(C.byref(self.args), _ALLOC_FN(_alloc), None, C.byref(self.state),
+                                                  C.c_void_p(self.stream.cuda_stream))
+                    for b in bufs:
+                        b.record_stream(self.stream)
+            if n < 0:
+                _raise_last(lib, "rasterize_gaussians (deferred frame)")
+        self.num_rendered = int(n)
+        _remember(self.key, int(n), bool(self.state.has_long_tiles))
+        return self.num_rendered
+
+
+def rasterize_deferred(means3D, opacities, raster_settings, shs=None, colors_precomp=None, scales=None, rotations=None,
+                       cov3D_precomp=None, clamp_output=False):
+    """Forward-only rasterization on torch's CURRENT stream without any host wait: returns a DeferredFrame whose
+    .color / .radii the GPU fills asynchronously; call .resolve() before handing them to anyone (hugs_amd.renderer.
+    render_batch does).  Scratch comes from the stream's persistent arena, sized for 4x the largest N this shape has
+    shown (at least 4 Mi entries).  The first frame of a shape has no history and is an ordinary (waiting) frame."""
+    lib = _load()
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    rs = raster_settings
+    with torch.no_grad():
+        means3D = _f32c(means3D) if means3D.numel() else means3D.float().reshape(0, 3)
+        shs, colors_precomp, opacities = _f32c(shs), _f32c(colors_precomp), _f32c(opacities)
+        scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
+        P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+        f = DeferredFrame()
+        f.color = torch.zeros(3, H, W, dtype=torch.float32, device=dev) if P == 0 else \
+            torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        f.radii = torch.empty(P, dtype=torch.int32, device=dev)
+        f.keep = {"device": dev, "inputs": (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)}
+        f.args, f.state = _ForwardArgs(), _ForwardState()
+        f.stream, f.key, f.num_rendered = torch.cuda.current_stream(dev), (dev.index, P, H, W), None
+        _fill_forward(f.args, rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, f.keep)
+        f.args.out_color, f.args.radii = f.color.data_ptr(), _ptr(f.radii)
+        f.args.clamp_output = 1 if clamp_output else 0
+        if P == 0:
+            f.num_rendered = 0
+            return f
+        seen = _max_num_rendered.get(f.key)
+        bufs = []
+
+        def _alloc(_ctx, which, nbytes):
+            bufs.append(torch.empty(int(nbytes), dtype=torch.uint8, device=dev))
+            return bufs[-1].data_ptr()
+
+        with torch.cuda.device(dev):
+            if seen is None:    # nothing known about this shape yet: an ordinary frame that waits for N
+                f.keep["scratch"] = _provide_scratch(f.args, lib, dev, P, H, W, 0, f.stream.cuda_stream)
+            else:
+                cap = max(4 * seen + 4096, _DEFERRED_MIN_CAPACITY)
+                f.args.binning_capacity_hint, f.args.defer_n = cap, 1
+                f.keep["scratch"] = _provide_scratch(f.args, lib, dev, P, H, W, cap, f.stream.cuda_stream)
+            n = lib.hgs_rasterize_forward(C.byref(f.args), _ALLOC_FN(_alloc), None, C.byref(f.state),
+                                          C.c_void_p(f.stream.cuda_stream))
+        f.keep["bufs"] = bufs
+        if n < 0:
+            _raise_last(lib, "rasterize_gaussians (deferred)")
+        if seen is None:
+            f.num_rendered = int(n)
+            _remember(f.key, int(n), bool(f.state.has_long_tiles))
+    return f
 
 
 class GaussianRasterizer(nn.Module):
@@ -416,9 +578,13 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
                                              scales if scales is not None else e,
                                              rotations if rotations is not None else e,
                                              cov3D_precomp if cov3D_precomp is not None else e, rs)
-    saved = color.grad_fn.saved_tensors
-    geom, binning, image = saved[8], saved[9], saved[10]
+    fn = color.grad_fn
     P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+    geom = binning = image = None
+    if P > 0:
+        buf, (go, gl, io, il, bo, bl) = fn.scratch
+        geom, image = buf[go:go + gl], buf[io:io + il]
+        binning = buf[bo:bo + bl] if bl and 1 not in fn.bufs else fn.bufs[1]   # a too-small guess falls back to the callback
     N = color.grad_fn.num_rendered
     cap = color.grad_fn.binning_capacity if P > 0 else 0   # the binning buffer is laid out for `cap` >= N entries
     off = lambda name: lib.hgs_scratch_offset(name.encode(), P, cap, H, W)

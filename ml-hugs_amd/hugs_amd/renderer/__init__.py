@@ -1,1 +1,1 @@
-from .gs_renderer import render, render_human_scene  # noqa: F401
+from .gs_renderer import render, render_batch, render_human_scene, render_human_scene_batch  # noqa: F401

@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_deferred
 
 _FIELDS = (("shs", "feats"), ("xyz", "means3D"), ("opacity", "opacity"), ("scales", "scales"), ("rotq", "rotations"))
 
@@ -153,3 +153,114 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
         "visibility_filter": radii > 0,
         "radii": radii,
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# Pipelined forward-only rendering for the reference's frame loops.
+#
+# validate / animate / render_canonical (gs_trainer.py:448-537, 539-586, 588-684) run under torch.no_grad() and call
+# render_human_scene once per frame, one frame after the other on one stream; every call waits once on the host for the
+# frame's pair count.  Frames are independent, so here they are (a) enqueued without any host wait (deferred frames: the
+# binning buffer comes from a persistent, generously sized arena per stream and the count is checked afterwards), and
+# (b) dealt round-robin to a few side HIP streams, so that one frame's latency-bound binning runs under another's
+# VALU-bound blending.  Results are bit-identical to calling render() / render_human_scene() frame by frame: the same
+# kernels run on the same inputs (tests/test_gpu_parity.py::test_render_batch_equals_serial_rendering).
+_batch_streams = {}
+
+
+def _streams_for(device, n):
+    pool = _batch_streams.setdefault(device, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
+def _render_deferred(means3D, feats, opacity, scales, rotations, data, scaling_modifier, bg_color, active_sh_degree):
+    device = means3D.device
+    if bg_color is None:
+        bg_color = torch.zeros(3, dtype=torch.float32, device=device)
+    settings = GaussianRasterizationSettings(
+        image_height=int(data["image_height"]), image_width=int(data["image_width"]),
+        tanfovx=math.tan(data["fovx"] * 0.5), tanfovy=math.tan(data["fovy"] * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=data["world_view_transform"], projmatrix=data["full_proj_transform"],
+        sh_degree=active_sh_degree, campos=data["camera_center"], prefiltered=False, debug=False)
+    is_rgb = feats.dim() == 2
+    return rasterize_deferred(means3D, opacity, settings, shs=None if is_rgb else feats, colors_precomp=feats if is_rgb else None,
+                              scales=scales, rotations=rotations, clamp_output=True)
+
+
+def render_batch(frames, num_streams=2):
+    """Forward-only (no autograd graph) rendering of independent frames, pipelined.
+
+    `frames`: an iterable of dicts holding render()'s keyword arguments (means3D, feats, opacity, scales, rotations, data
+    [, scaling_modifier, bg_color, active_sh_degree]); it may be a generator that produces each frame's Gaussians on the
+    caller's stream as it goes (the posed human of the animation loop).  Returns, in order, what render() returns for
+    every frame -- {"render", "viewspace_points", "visibility_filter", "radii"} -- valid on the caller's stream."""
+    out, pending = [], []
+    main = side = None
+    with torch.no_grad():
+        for i, fr in enumerate(frames):
+            device = fr["means3D"].device
+            if main is None:
+                main = torch.cuda.current_stream(device)
+                side = _streams_for(device, max(1, int(num_streams)))
+            st = side[i % len(side)]
+            st.wait_stream(main)          # this frame's inputs were produced on the caller's stream
+            with torch.cuda.stream(st):
+                f = _render_deferred(fr["means3D"], fr["feats"], fr["opacity"], fr["scales"], fr["rotations"], fr["data"],
+                                     fr.get("scaling_modifier", 1.0), fr.get("bg_color"), fr.get("active_sh_degree", 0))
+            for t in f.keep["inputs"]:    # read by side-stream kernels: keep the caching allocator from recycling them early
+                if t is not None and t.is_cuda:
+                    t.record_stream(st)
+            pending.append((f, fr["means3D"]))
+        for f, _ in pending:              # every frame fitted its binning buffer (or is run again, exactly sized)
+            f.resolve()
+        if main is not None:
+            for st in side:
+                main.wait_stream(st)
+        for f, means3D in pending:
+            f.color.record_stream(main)
+            f.radii.record_stream(main)
+            out.append({"render": f.color, "viewspace_points": torch.zeros_like(means3D), "visibility_filter": f.radii > 0,
+                        "radii": f.radii})
+    return out
+
+
+def render_human_scene_batch(items, num_streams=2):
+    """render_human_scene for a sequence of frames, forward only, pipelined (see render_batch).  `items`: an iterable of
+    dicts with render_human_scene's arguments (data, human_gs_out, scene_gs_out, bg_color [, human_bg_color,
+    scaling_modifier, render_mode, render_human_separate]).  Returns the same dicts render_human_scene returns."""
+    items = list(items) if not isinstance(items, (list, tuple)) else items
+    frames, layout = [], []
+    for it in items:
+        mode = it.get("render_mode", "human_scene")
+        g = _gather(it.get("human_gs_out"), it.get("scene_gs_out"), mode)
+        common = {"data": it["data"], "scaling_modifier": it.get("scaling_modifier", 1.0)}
+        frames.append({**common, "means3D": g["means3D"], "feats": g["feats"], "opacity": g["opacity"], "scales": g["scales"],
+                       "rotations": g["rotations"], "bg_color": it.get("bg_color"), "active_sh_degree": g["active_sh_degree"]})
+        separate = bool(it.get("render_human_separate")) and mode == "human_scene"
+        if separate:
+            h = _gather(it["human_gs_out"], None, "human")
+            hbg = it.get("human_bg_color")
+            frames.append({**common, "means3D": h["means3D"], "feats": h["feats"], "opacity": h["opacity"], "scales": h["scales"],
+                           "rotations": h["rotations"], "bg_color": hbg if hbg is not None else it.get("bg_color"),
+                           "active_sh_degree": h["active_sh_degree"]})
+        layout.append((mode, separate))
+    rendered = iter(render_batch(frames, num_streams))
+    out = []
+    for it, (mode, separate) in zip(items, layout):
+        pkg = next(rendered)
+        if separate:
+            hp = next(rendered)
+            pkg["human_img"], pkg["human_visibility_filter"], pkg["human_radii"] = hp["render"], hp["visibility_filter"], hp["radii"]
+        if mode == "human":
+            pkg["human_visibility_filter"], pkg["human_radii"] = pkg["visibility_filter"], pkg["radii"]
+        elif mode == "human_scene":
+            n_h, n_s = it["human_gs_out"]["xyz"].shape[0], it["scene_gs_out"]["xyz"].shape[0]
+            pkg["scene_visibility_filter"], pkg["scene_radii"] = pkg["visibility_filter"][n_h:], pkg["radii"][n_h:]
+            if "human_visibility_filter" not in pkg:
+                pkg["human_visibility_filter"], pkg["human_radii"] = pkg["visibility_filter"][:-n_s], pkg["radii"][:-n_s]
+        else:
+            pkg["scene_visibility_filter"], pkg["scene_radii"] = pkg["visibility_filter"], pkg["radii"]
+        out.append(pkg)
+    return out

@@ -606,6 +606,93 @@ def test_tile_counters_are_clean_after_every_frame(device):
                     assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
 
 
+def _orbit_frames(sc, device, n):
+    """n cameras on a small orbit around the scene's camera, as render() keyword dicts (the Gaussians are shared)"""
+    import math
+    from hugs_amd import synthetic as syn
+    t = gpu_tensors(sc, device, grad=False)
+    frames = []
+    for i in range(n):
+        yaw = math.radians(2.0) * (i - n // 2)
+        w2c = np.eye(4)
+        w2c[0, 0], w2c[0, 2], w2c[2, 0], w2c[2, 2] = math.cos(yaw), math.sin(yaw), -math.sin(yaw), math.cos(yaw)
+        cam = syn.camera_from_w2c(w2c @ np.linalg.inv(np.eye(4)), sc["cam"]["fovx"], sc["cam"]["fovy"], sc["H"], sc["W"])
+        data = {k: (to_dev(v, device) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+        frames.append(dict(means3D=t["means3D"], feats=t["shs"], opacity=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                           data=data, bg_color=to_dev(sc["bg"], device), active_sh_degree=sc["D"]))
+    return frames
+
+
+@pytest.mark.parametrize("num_streams", [1, 3])
+def test_render_batch_equals_serial_rendering(num_streams, device):
+    """hugs_amd.renderer.render_batch: deferred frames (no host wait), round-robin over side streams -- bit-identical to
+    render() frame by frame, for the frame loops of gs_trainer.py:463,551,616."""
+    from hugs_amd.renderer import render, render_batch
+    sc = make_scene(P=3000, H=128, W=192, seed=61, D=3, sigma_px=5.0)
+    frames = _orbit_frames(sc, device, 7)
+    with torch.no_grad():
+        serial = [render(**fr) for fr in frames]
+    for rep in range(2):        # second pass: every frame is a deferred one (the shape has a history now)
+        batch = render_batch(frames, num_streams=num_streams)
+        torch.cuda.synchronize()
+        assert len(batch) == len(serial)
+        for a, b in zip(batch, serial):
+            assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+            assert torch.equal(a["visibility_filter"], b["visibility_filter"]) and a["viewspace_points"].shape == b["viewspace_points"].shape
+    # a generator that makes each frame's Gaussians on the fly (the animation loop's posed human) works too
+    gen = ({**fr, "means3D": fr["means3D"] + 0.0} for fr in frames)
+    again = render_batch(gen, num_streams=num_streams)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a["render"], b["render"]) for a, b in zip(again, serial))
+
+
+def test_deferred_frame_that_overflows_is_run_again(device, monkeypatch):
+    """A deferred frame is given a binning buffer sized from the shape's history; if the frame needs more, its kernels do
+    nothing, hgs_forward_poll reports HGS_ERR_OVERFLOW and resolve() runs the frame again exactly sized."""
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd.renderer import render, render_batch
+    sc = make_scene(P=3000, H=128, W=192, seed=62, D=3, sigma_px=5.0)
+    frames = _orbit_frames(sc, device, 4)
+    with torch.no_grad():
+        serial = [render(**fr) for fr in frames]
+    key = (torch.device(device).index or 0, 3000, 128, 192)
+    n = dgr._last_num_rendered[key][0]
+    assert n > 6000
+    monkeypatch.setattr(dgr, "_DEFERRED_MIN_CAPACITY", 16)
+    monkeypatch.setitem(dgr._max_num_rendered, key, 100)      # "history" says the shape needs ~100 entries: 4 496 are given
+    seen = []
+    orig = dgr.DeferredFrame.resolve
+    monkeypatch.setattr(dgr.DeferredFrame, "resolve", lambda self: seen.append(self.state.binning_capacity) or orig(self))
+    batch = render_batch(frames, num_streams=2)
+    torch.cuda.synchronize()
+    assert seen and seen[0] == 4 * 100 + 4096 < n              # the first frame really was deferred with too little room
+    for a, b in zip(batch, serial):
+        assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+
+
+def test_render_human_scene_batch_matches_render_human_scene(device):
+    from hugs_amd.renderer import render_human_scene, render_human_scene_batch
+    sc_h = make_scene(P=700, H=96, W=128, seed=63, D=0, sigma_px=6.0, with_culled=False)
+    sc_s = make_scene(P=1500, H=96, W=128, seed=64, D=3, sigma_px=5.0)
+    model = lambda sc, deg: {"xyz": to_dev(sc["means3D"], device), "shs": to_dev(sc["shs"], device), "opacity": to_dev(sc["opacities"], device),
+                             "scales": to_dev(sc["scales"], device), "rotq": to_dev(sc["rotations"], device), "active_sh_degree": deg}
+    human, scene = model(sc_h, 0), model(sc_s, 3)
+    items = []
+    for fr in _orbit_frames(sc_s, device, 3):
+        items.append(dict(data=fr["data"], human_gs_out=human, scene_gs_out=scene, bg_color=fr["bg_color"],
+                          human_bg_color=torch.zeros(3, device=device), render_mode="human_scene", render_human_separate=True))
+    items.append(dict(data=items[0]["data"], human_gs_out=human, scene_gs_out=None, bg_color=items[0]["bg_color"], render_mode="human"))
+    with torch.no_grad():
+        serial = [render_human_scene(**it) for it in items]
+    batch = render_human_scene_batch(items)
+    torch.cuda.synchronize()
+    for a, b in zip(batch, serial):
+        assert set(a) == set(b)
+        for k in b:
+            if k != "viewspace_points":
+                assert torch.equal(a[k], b[k]), k
+
+
 def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):
     """A 4096 x 2304 image has 36 864 tiles: the binning kernels cannot keep a per-tile array in LDS and fall back
     to direct global atomics; results must not change."""

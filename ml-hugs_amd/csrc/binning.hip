@@ -148,67 +148,25 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32
 // The value's top 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on
 // some pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never
 // missing): the blend kernels skip a (quad, splat) pair whose bit is clear without touching a VGPR.
-// max over the pixel-centre rectangle [x0,x0+7] x [y0,y0+7] of  A dx^2 + B dx dy + C dy^2  (concave)
-__device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, float B, float C, float x0, float y0)
+// max over the pixel-centre rectangle [x0,x0+7] x [y0,y0+7] of  f(d) = A dx^2 + B dx dy + C dy^2  (concave, d = centre - pixel).
+// With the centre outside the rectangle the maximum sits on an edge FACING the centre: if the centre's x lies inside
+// [x0, x0+7] the gradient condition rules the two vertical edges out (and likewise for y), so at most one vertical and one
+// horizontal edge are candidates -- the nearer ones -- and each is a 1-D concave problem (vertex clamped to the segment).
+// hA = -1/(2A), hC = -1/(2C): v_rcp_f32 (1 ulp) instead of an IEEE divide -- an error eps in the vertex position lowers the
+// value found by ~A eps^2, far inside the threshold's slack.
+__device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, float B, float C, float hA, float hC, float x0, float y0)
 {
-    const float dxl = sx - (x0 + 7.0f), dxh = sx - x0, dyl = sy - (y0 + 7.0f), dyh = sy - y0;
-    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return 0.0f;  // centre inside the quad
-    // vertex of the 1-D restriction: d* = -B d_other / (2 A|C).  v_rcp_f32 (1 ulp) instead of an IEEE divide: an error
-    // eps in the vertex position lowers the value found by ~A eps^2, far inside the threshold's slack
-    const float hA = -0.5f * __builtin_amdgcn_rcpf(A), hC = -0.5f * __builtin_amdgcn_rcpf(C);
-    float best = -3.0e38f;
-    {
-        float dy = fminf(dyh, fmaxf(dyl, B * dxl * hC));
-        best = fmaxf(best, A * dxl * dxl + (B * dxl + C * dy) * dy);
-        dy = fminf(dyh, fmaxf(dyl, B * dxh * hC));
-        best = fmaxf(best, A * dxh * dxh + (B * dxh + C * dy) * dy);
-        float dx = fminf(dxh, fmaxf(dxl, B * dyl * hA));
-        best = fmaxf(best, C * dyl * dyl + (B * dyl + A * dx) * dx);
-        dx = fminf(dxh, fmaxf(dxl, B * dyh * hA));
-        best = fmaxf(best, C * dyh * dyh + (B * dyh + A * dx) * dx);
-    }
-    return best;
-}
-
-// The same walk, evenly dealt: the wave's rectangles are staged in LDS, their tile counts prefix-summed, and the pairs
-// handed to lanes 64 at a time (each pair finds its owner by a 6-step search over the wave's prefix sums).  Worth its
-// staging and shuffles only when the body is heavy -- emit's coverage-mask computation -- where idle lanes would cost more.
-struct PairStage {  // one wave's 64 staged Gaussians
-    float4 (*rec)[3];
-    uint32_t incl, total;
-};
-__device__ __forceinline__ void stage_rects(const SplatRect& m, PairStage& st)
-{
-    const int lane = threadIdx.x & 63;
-    st.incl = wave_inclusive_scan(m.cnt);
-    st.rec[lane][0] = make_float4(m.x, m.y, m.A, m.B);
-    st.rec[lane][1] = make_float4(m.C, m.thr, __uint_as_float(m.depth_bits), __uint_as_float(st.incl - m.cnt));
-    st.rec[lane][2] = make_float4(__int_as_float(m.minx), __int_as_float(m.miny), __int_as_float(m.width), 0.f);
-    __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: the reads below see the writes above
-    st.total = (uint32_t)__shfl((int)st.incl, 63, 64);
-}
-// calls f(owner_lane, tx, ty, rec0, rec1) for every pair of the staged wave, 64 pairs per trip
-template <class F>
-__device__ __forceinline__ void for_each_pair_dealt(const PairStage& st, F&& f)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t s0 = 0; s0 < st.total; s0 += 64) {
-        const uint32_t s = s0 + lane;
-        // owner = smallest lane whose inclusive count exceeds s (all lanes take part in the shuffles)
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const uint32_t v = (uint32_t)__shfl((int)st.incl, lo + step - 1, 64);
-            if (v <= s) lo += step;
-        }
-        if (s < st.total) {
-            const float4 a = st.rec[lo][0], b = st.rec[lo][1], c = st.rec[lo][2];
-            const uint32_t k = s - __float_as_uint(b.w);
-            const uint32_t wdt = (uint32_t)__float_as_int(c.z);
-            const uint32_t ry = k / wdt, rx = k - ry * wdt;
-            f(lo, __float_as_int(c.x) + (int)rx, __float_as_int(c.y) + (int)ry, a, b);
-        }
-    }
+    const float dxl = sx - (x0 + 7.0f), dxh = sx - x0, dyl = sy - (y0 + 7.0f), dyh = sy - y0;  // d ranges over [dxl,dxh] x [dyl,dyh]
+    const bool x_in = dxl <= 0.0f && dxh >= 0.0f, y_in = dyl <= 0.0f && dyh >= 0.0f;
+    // nearer vertical edge: d.x = dxl when the centre is right of the quad (dxl > 0), else dxh (only used when !x_in)
+    const float ex = dxl > 0.0f ? dxl : dxh;
+    const float dy = fminf(dyh, fmaxf(dyl, B * ex * hC));
+    const float fx = A * ex * ex + (B * ex + C * dy) * dy;
+    const float ey = dyl > 0.0f ? dyl : dyh;
+    const float dx = fminf(dxh, fmaxf(dxl, B * ey * hA));
+    const float fy = C * ey * ey + (B * ey + A * dx) * dx;
+    const float best = fmaxf(x_in ? -3.0e38f : fx, y_in ? -3.0e38f : fy);
+    return (x_in && y_in) ? 0.0f : best;
 }
 
 // count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise the preprocess kernel counts):
@@ -224,45 +182,119 @@ count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __re
 // The value's low 4 bits carry a coverage mask: bit q is set when the splat can reach alpha >= 1/255 on some
 // pixel of the tile's 8x8 quad q (q = qx + 2 qy).  It is CONSERVATIVE (may be set needlessly, never missing):
 // the blend kernels skip a (quad, splat) pair whose bit is clear without touching a VGPR.
-// USE_LDS: slot = segment start + this group's run start (both already known: tile_scan and the preprocess kernel's
-// returning atomics) + a workgroup-private LDS counter -- one pass, no global atomic.  Otherwise: a global atomic per pair.
+//
+// A workgroup of 1024 threads owns one binning group (G <= 1024 Gaussians, the preprocess kernel's partition) and
+// deals the group's pairs evenly to ALL its threads: the Gaussians' pair counts are prefix-summed, every Gaussian writes
+// its index at the first of its pair slots in an LDS array, a forward max-fill turns that into "owner of slot s", and
+// thread t then takes slots t, t + 1024, ... -- no per-pair search, no wave waiting for the one with the big splats, and
+// for small inputs (the 6 890 Gaussians of the SMPL template are 108 groups of 64) sixteen waves per group instead of one.
+// slot = segment start + this group's run start (both already known: tile_scan and the preprocess kernel's returning
+// atomics) + a workgroup-private LDS counter -- one pass, no global atomic.  !USE_LDS: fallback, a global atomic per pair.
+constexpr int EMIT_THREADS = 1024;
+constexpr int EMIT_SLOTS = 8192;  // pair slots dealt per round (LDS: 2 bytes each)
+
 template <bool USE_LDS>
-__global__ void __launch_bounds__(BIN_THREADS)
-emit_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(EMIT_THREADS)
+emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
             const uint32_t* __restrict__ run_start, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
 {
     if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
+    constexpr int NT = EMIT_THREADS, PER = EMIT_SLOTS / NT;
     extern __shared__ uint32_t hist[];
+    __shared__ float4 rec[BIN_GROUP][3];
+    __shared__ uint32_t excl[BIN_GROUP];
+    __shared__ __attribute__((aligned(16))) uint16_t own[EMIT_SLOTS];
+    __shared__ uint32_t wtot[NT / 64];
     const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : cursor;
-    const int g0 = blockIdx.x * BIN_GROUP + (threadIdx.x & ~63);
-    const SplatRect mine = load_rect(P, cam, splats, g0 + (threadIdx.x & 63), true);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g0 = blockIdx.x * G;
+    SplatRect mine;
+    mine.cnt = 0;
+    if (tid < G) mine = load_rect(P, cam, splats, g0 + tid, true);  // (g0 + tid >= P: an empty rectangle)
     if (USE_LDS) {
         // this group's cursor into every tile segment (entries of tiles the group does not touch are never used, and
         // run_start holds nothing meaningful for them)
         const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
-        for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) hist[t] = cursor[t] + my_runs[t];
-        __syncthreads();
+        for (int t = tid; t < num_tiles; t += NT) hist[t] = cursor[t] + my_runs[t];
     }
-    __shared__ float4 stage[BIN_THREADS / 64][64][3];
-    PairStage st;
-    st.rec = stage[threadIdx.x >> 6];
-    stage_rects(mine, st);
-    for_each_pair_dealt(st, [&](int owner, int tx, int ty, const float4& a, const float4& b) {
-        const float A = a.z, B = a.w, C = b.x, thr = b.y;
-        uint32_t mask = 0xFu;
-        if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
-            mask = 0;
-            const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    // exclusive prefix sum of the pair counts over the group
+    const uint32_t incl = wave_inclusive_scan(mine.cnt);
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (max_power_in_quad(a.x, a.y, A, B, C, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
-                    mask |= 1u << q;
+    for (int k = 0; k < NT / 64; ++k) {
+        const uint32_t v = wtot[k];
+        if (k < w) before += v;
+        total += v;
+    }
+    const uint32_t first = before + incl - mine.cnt;  // this Gaussian's pairs are slots [first, first + cnt)
+    if (tid < G) {
+        excl[tid] = first;
+        rec[tid][0] = make_float4(mine.x, mine.y, mine.A, mine.B);
+        rec[tid][1] = make_float4(mine.C, mine.thr, __uint_as_float(mine.depth_bits), 1.0f / (float)mine.width);
+        rec[tid][2] = make_float4(__int_as_float(mine.minx), __int_as_float(mine.miny), __int_as_float(mine.width), 0.f);
+    }
+    for (uint32_t base = 0; base < total; base += EMIT_SLOTS) {
+        // owner of every slot of this round: scatter (index + 1) at each Gaussian's first slot, then fill forward (the
+        // owners ascend with the slot, so "fill forward" is a running maximum)
+        __syncthreads();  // previous round done with own[]
+        reinterpret_cast<uint4*>(own)[tid] = make_uint4(0u, 0u, 0u, 0u);  // PER = 8 u16 per thread
+        __syncthreads();
+        if (mine.cnt && first < base + EMIT_SLOTS && first + mine.cnt > base) own[max(first, base) - base] = (uint16_t)(tid + 1);
+        __syncthreads();
+        {
+            uint4 v = reinterpret_cast<uint4*>(own)[tid];
+            uint32_t e[PER] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+#pragma unroll
+            for (int k = 1; k < PER; ++k) e[k] = max(e[k], e[k - 1]);
+            uint32_t run = e[PER - 1];  // inclusive max over the wave's threads
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t n = (uint32_t)__shfl_up((int)run, d, 64);
+                if (lane >= d) run = max(run, n);
+            }
+            __syncthreads();  // wtot is free again
+            if (lane == 63) wtot[w] = run;
+            __syncthreads();
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k)
+                if (k < w) carry = max(carry, wtot[k]);
+            const uint32_t up = (uint32_t)__shfl_up((int)run, 1, 64);
+            carry = max(carry, lane ? up : 0u);  // everything before this thread's eight slots
+#pragma unroll
+            for (int k = 0; k < PER; ++k) e[k] = max(e[k], carry);
+            reinterpret_cast<uint4*>(own)[tid] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
         }
-        const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
-        // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
-        keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + owner) << 4) | mask);
-    });
+        __syncthreads();
+        const uint32_t n_round = min((uint32_t)EMIT_SLOTS, total - base);
+        for (uint32_t s = tid; s < n_round; s += NT) {
+            const uint32_t o = (uint32_t)own[s] - 1u;
+            const float4 a = rec[o][0], b = rec[o][1], c = rec[o][2];
+            const uint32_t k = base + s - excl[o];
+            // row of the pair inside the rectangle: k / width, exactly (k < 2^22) without an integer divide
+            const uint32_t wdt = (uint32_t)__float_as_int(c.z);
+            uint32_t ry = (uint32_t)(((float)k + 0.5f) * b.w);
+            const uint32_t rx = k - ry * wdt;
+            const int tx = __float_as_int(c.x) + (int)rx, ty = __float_as_int(c.y) + (int)ry;
+            const float A = a.z, B = a.w, C = b.x, thr = b.y;
+            uint32_t mask = 0xFu;
+            if (A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f) {
+                mask = 0;
+                const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+                const float hA = -0.5f * __builtin_amdgcn_rcpf(A), hC = -0.5f * __builtin_amdgcn_rcpf(C);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (max_power_in_quad(a.x, a.y, A, B, C, hA, hC, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
+                        mask |= 1u << q;
+            }
+            const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
+            // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
+            keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + (int)o) << 4) | mask);
+        }
+    }
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
@@ -270,14 +302,15 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
     hipLaunchKernelGGL(count_kernel, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
 }
 
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start,
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, int group,
                  uint64_t* keys, const uint32_t* gate, hipStream_t st)
 {
-    const int num_tiles = cam.gx * cam.gy, blocks = (P + BIN_GROUP - 1) / BIN_GROUP;
-    if (run_start)
-        hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * num_tiles, st, P, cam, splats, cursor, run_start, keys, gate);
+    if (group)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3((P + group - 1) / group), dim3(EMIT_THREADS), sizeof(uint32_t) * cam.gx * cam.gy, st,
+                           P, group, cam, splats, cursor, run_start, keys, gate);
     else
-        hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(BIN_THREADS), 0, st, P, cam, splats, cursor, run_start, keys, gate);
+        hipLaunchKernelGGL(emit_kernel<false>, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(EMIT_THREADS), 0, st, P, BIN_GROUP, cam, splats,
+                           cursor, nullptr, keys, gate);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ namespace hgs {
 // tiles per step, so one huge splat cannot serialise a lane.  Atomics are aggregated per workgroup in an LDS array
 // indexed by tile and touch global memory once per (workgroup, tile) with coalesced vector atomics: scattered global
 // atomics cost ~15 G cache-line transactions/s on this chip, more than everything else in the binning phase together.
-constexpr int BIN_THREADS = BIN_GROUP;    // one Gaussian per thread (BIN_GROUP, BIN_LDS_TILES: hgs_common.h)
+constexpr int BIN_THREADS = BIN_GROUP;    // threads of the fallback kernels (BIN_GROUP, BIN_LDS_TILES, bin_group_for: hgs_common.h)
 constexpr uint32_t BIN_SOLO_MAX = 48;     // tiles a lane walks on its own
 
 struct SplatRect {  // what the walk needs of one Gaussian

@@ -317,7 +317,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     Splat* splats = (Splat*)(geom + gl.splats);
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
     // the preprocess kernel counts pairs per tile itself when the tile array fits LDS (any frame up to ~7 Mpixel)
-    uint32_t* run_start = num_tiles <= BIN_LDS_TILES ? (uint32_t*)(geom + gl.run_start) : nullptr;
+    const int group = bin_group_for(a.P, num_tiles);
+    uint32_t* run_start = group ? (uint32_t*)(geom + gl.run_start) : nullptr;
     uint2* ranges = (uint2*)(image + il.ranges);
     uint32_t* cursor = (uint32_t*)(image + il.cursor);
     uint32_t* n_total = (uint32_t*)(image + il.n_total);
@@ -327,7 +328,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (int rc = acquire_tile_counters(st, (size_t)num_tiles, &tile_count, &tc_index)) return rc;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
-      launch_preprocess(a, cam, splats, tiles_touched, tile_count, run_start, st); }
+      launch_preprocess(a, cam, splats, tiles_touched, tile_count, run_start, group, st); }
     STAGE_CHECK(dbg, st, "preprocess");
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
@@ -335,7 +336,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
-      if (!run_start) launch_count(a.P, cam, splats, tile_count, st);
+      if (!group) launch_count(a.P, cam, splats, tile_count, st);
       launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, large_tiles, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
     tile_counters_clean(tc_index);  // the scan, which re-zeroes them, is enqueued
@@ -353,7 +354,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, keys, gate, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, group, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total, true, with_long_sort, st); }

@@ -44,12 +44,25 @@ struct Camera {  // small by-value kernel argument
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
-#ifndef HGS_BIN_GROUP
-#define HGS_BIN_GROUP 1024
-#endif
-constexpr int BIN_GROUP = HGS_BIN_GROUP;           // Gaussians per binning workgroup (preprocess + emit share the partition)
+constexpr int BIN_GROUP = 1024;           // most Gaussians per binning workgroup (one per thread)
 constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to emit's 48 KB of staging
 inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
+// Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
+// (a group = a workgroup).  A group is the unit of parallelism of both kernels, and either runs one workgroup per CU, so
+// the groups should just fill the 256 CUs in one round: ~250 groups when P allows it (200 000 Gaussians: 241 groups of
+// 832, not 196 of 1024 on three quarters of the chip; the 6 890 Gaussians of the SMPL template: 108 groups of 64, not 7
+// of 1024).  Every group also pays for passes over all tiles (LDS histogram, flush, cursor load), which bounds how small
+// a group may be on a frame with many tiles (~4 M tile visits in total).  0: more tiles than fit LDS -- the
+// global-atomics fallback kernels.
+inline int bin_group_for(int P, int num_tiles)
+{
+    if (num_tiles > BIN_LDS_TILES) return 0;
+    const long long want = ((long long)P + 249) / 250;                                   // ~250 groups
+    const long long floor_by_tiles = ((long long)P * num_tiles + (4ll << 20) - 1) / (4ll << 20);  // <= 4 Mi tile visits
+    long long g = want > floor_by_tiles ? want : floor_by_tiles;
+    g = (g + 63) / 64 * 64;
+    return (int)(g < 64 ? 64 : (g > BIN_GROUP ? BIN_GROUP : g));
+}
 struct GeomLayout {
     size_t splats, tiles_touched, run_start, total;
     GeomLayout(int P, int num_tiles) {
@@ -60,7 +73,7 @@ struct GeomLayout {
         // consecutive Gaussians) begins -- handed out by the preprocess kernel's returning atomics, consumed by emit.
         // Only (group, tile) pairs with at least one entry are ever written or read.
         run_start = o;
-        if (num_tiles <= BIN_LDS_TILES) o = align_up(o + 4 * (size_t)((P + BIN_GROUP - 1) / BIN_GROUP) * (size_t)num_tiles);
+        if (const int g = bin_group_for(P, num_tiles)) o = align_up(o + 4 * (size_t)((P + g - 1) / g) * (size_t)num_tiles);
         total = o;
     }
 };
@@ -102,11 +115,11 @@ struct BinningLayout {
 // kernels / launchers (defined in the .hip files)
 void set_last_error(const char* msg);  // hgs_api.hip
 
-// tile_count: ZERO on entry (hgs_api.hip keeps a self-cleaning counter array per stream).  run_start != nullptr: the
+// tile_count: ZERO on entry (hgs_api.hip keeps a self-cleaning counter array per stream).  group = bin_group_for() != 0: the
 // kernel also counts the (Gaussian, tile) pairs per tile (LDS histogram per BIN_GROUP Gaussians, one returning atomic per
-// touched tile) and records every group's run offsets; nullptr: count_kernel does the counting (very large tile counts).
+// touched tile) and records every group's run offsets in run_start; 0: count_kernel does the counting (very large tile counts).
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, uint32_t* run_start, hipStream_t st);
+                       uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
@@ -115,7 +128,7 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
                       hipStream_t st);
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start,
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, int group,
                  uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,

@@ -124,13 +124,13 @@ __device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one thread per Gaussian.  FUSED_COUNT: the workgroup (BIN_GROUP = 1024 Gaussians) also counts its (Gaussian, tile)
+// K1: one thread per Gaussian.  FUSED_COUNT: the workgroup (a binning group, bin_group_for()) also counts its (Gaussian, tile)
 // pairs per tile in an LDS histogram while the rectangles are still in registers, takes ONE returning atomic per touched
 // tile on the global per-tile counters -- the value returned is where this group's run starts inside the tile's segment
 // -- and leaves it in run_start[group][tile] for the emit kernel.  (The separate count kernel, its launch gap and emit's
 // own counting + reservation pass are gone: 11 + 1 + ~12 us on the 200k / 1080p frame.)
-template <bool FUSED_COUNT>
-__global__ void __launch_bounds__(FUSED_COUNT ? BIN_THREADS : 256)
+template <bool FUSED_COUNT>  // true: blockDim.x = the binning group (bin_group_for(), <= 1024); false: 256 threads, no counting
+__global__ void __launch_bounds__(FUSED_COUNT ? BIN_GROUP : 256)
 preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rots,
@@ -139,7 +139,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                   uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
                   uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start, float4* __restrict__ zero_accum)
 {
-    constexpr int NT = FUSED_COUNT ? BIN_THREADS : 256;
+    const int NT = FUSED_COUNT ? (int)blockDim.x : 256;
     extern __shared__ uint32_t hist[];
     const int num_tiles = cam.gx * cam.gy;
     const int i = blockIdx.x * NT + threadIdx.x;
@@ -281,18 +281,17 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
 }
 
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, uint32_t* run_start, hipStream_t st)
+                       uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st)
 {
-    const int num_tiles = cam.gx * cam.gy;
-    if (run_start)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + BIN_GROUP - 1) / BIN_GROUP), dim3(BIN_THREADS),
-                           sizeof(uint32_t) * num_tiles, st, a.P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales,
-                           a.rotations, a.cov3D_precomp, a.s.viewmatrix, a.s.projmatrix, a.s.campos, splats, tiles_touched,
-                           a.radii, tile_count, run_start, (float4*)a.grad_accum_to_zero);
+    if (group)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + group - 1) / group), dim3(group), sizeof(uint32_t) * cam.gx * cam.gy,
+                           st, a.P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp,
+                           a.s.viewmatrix, a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, run_start,
+                           (float4*)a.grad_accum_to_zero);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
                            a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
-                           a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, run_start,
+                           a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, nullptr,
                            (float4*)a.grad_accum_to_zero);
 }
 

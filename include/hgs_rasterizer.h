@@ -186,6 +186,24 @@ int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, cons
                                  const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
                                  void *stream);
 
+/* SURVEY.md 8f row f-2, second half -- the skinning step of the human model's learned LBS, fused: replaces the matmul /
+ * cat / batched-matmul / slice statements of lbs_extra (/root/reference/hugs/models/modules/lbs.py:60-73, called every
+ * training step at hugs/models/hugs_trimlp.py:477-489) and the rotation product of hugs_trimlp.py:517, for one batch element:
+ *   T[i] = sum_j weights[i,j] A[j]   ([n,16], row-major 4x4)     verts[i] = (T[i] [v[i], 1])[:3]
+ *   rot_out[i] = T[i][:3,:3] rotmat[i]                            (rotmat / rot_out may both be NULL)
+ * A [J,16], 1 <= J <= 32; weights [n,J]; v [n,3] (= v_posed); rotmat [n,9].  T must be 16-byte aligned. */
+int32_t hgs_lbs_skin_forward(int32_t n, int32_t J, const float *A, const float *weights, const float *v,
+                             const float *rotmat, float *T, float *verts, float *rot_out, void *stream);
+/* Its backward: gradients w.r.t. A [J,16], weights [n,J], v [n,3] and rotmat [n,9] given dL/dverts, dL/dT, dL/drot_out
+ * (each may be NULL = zero).  T is forward's output.  `workspace`: hgs_lbs_skin_backward_workspace(n, J) bytes, 16-byte
+ * aligned.  dL/dA is a contraction over all n Gaussians: it runs on the matrix cores and is reduced in a fixed order (no
+ * float atomics, bit-reproducible). */
+size_t hgs_lbs_skin_backward_workspace(int32_t n, int32_t J);
+int32_t hgs_lbs_skin_backward(int32_t n, int32_t J, const float *A, const float *weights, const float *v,
+                              const float *rotmat, const float *T, const float *dL_dverts, const float *dL_dT,
+                              const float *dL_drot, float *dL_dA, float *dL_dweights, float *dL_dv, float *dL_drotmat,
+                              void *workspace, void *stream);
+
 /* SURVEY.md 8f row f-4 -- replaces simple_knn._C.distCUDA2 (/root/reference/hugs/models/scene.py:20,181): mean_dist2[i]
  * = mean of the squared distances from points[i] to its three nearest OTHER points of the same cloud ([n,3], n >= 4).
  * Exact (brute force), fp32. */

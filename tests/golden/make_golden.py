@@ -319,6 +319,40 @@ def main():
                knn_lbsweight_dist=d1[0].numpy(), knn_lbsweight_weights=w1[0].numpy(),
                knn_lbsmap_dist=d2[0].numpy(), knn_lbsmap_transform=T2[0].numpy(), knn_lbsmap_info=i2[0].numpy())
 
+    # ---- learned LBS skinning (second half): lbs_extra, hugs/models/modules/lbs.py:19-73, compiled
+    # from its source file and executed (forward AND autograd backward), plus the rotation product of hugs_trimlp.py:517.
+    # smplx (pip dependency) is absent: lbs_extra's only use of it on the release path (disable_posedirs: true) is a
+    # batch_rodrigues call whose result is discarded; it is given oracle/lbs_oracle.py's restatement of the published
+    # formula, which therefore only shapes the posedirs-enabled vectors below.
+    from oracle import lbs_oracle
+    lns = {"torch": torch, "Tensor": torch.Tensor,
+           "batch_rodrigues": lambda r: torch.from_numpy(lbs_oracle.batch_rodrigues(r.detach().numpy().astype(np.float64), np.float64)).to(r.dtype)}
+    ref_lbs_extra = _function_from_source(os.path.join(REF, "hugs/models/modules/lbs.py"), "lbs_extra", lns)
+    lr = np.random.default_rng(17)
+    nJ, nV = 24, 96
+    A_np = np.tile(np.eye(4, dtype=np.float32), (nJ, 1, 1))
+    A_np[:, :3, :] += 0.3 * lr.standard_normal((nJ, 3, 4)).astype(np.float32)                 # rigid-ish joint transforms
+    logit = 4.0 * lr.standard_normal((nV, nJ))
+    Wl = (np.exp(logit) / np.exp(logit).sum(1, keepdims=True)).astype(np.float32)             # softmax(x / 0.1)-like: peaky rows
+    v_np = (lr.standard_normal((nV, 3)) * np.array([0.25, 0.6, 0.15])).astype(np.float32)
+    R_np = lbs_oracle.batch_rodrigues(lr.standard_normal((nV, 3)).astype(np.float32))          # per-Gaussian rotation matrices
+    pose_np = (0.4 * lr.standard_normal((1, nJ * 3))).astype(np.float32)
+    posedirs_np = (0.01 * lr.standard_normal(((nJ - 1) * 9, nV * 3))).astype(np.float32)
+    g_verts, g_T = lr.standard_normal((nV, 3)).astype(np.float32), lr.standard_normal((nV, 4, 4)).astype(np.float32)
+    g_rot = lr.standard_normal((nV, 3, 3)).astype(np.float32)
+    out.update(lbs_A=A_np, lbs_weights=Wl, lbs_v=v_np, lbs_rotmat=R_np, lbs_pose=pose_np, lbs_posedirs=posedirs_np,
+               lbs_g_verts=g_verts, lbs_g_T=g_T, lbs_g_rot=g_rot)
+    for tag, disable in (("", True), ("_posedirs", False)):
+        tA, tW, tv = (torch.from_numpy(x.copy()).requires_grad_(True) for x in (A_np, Wl, v_np))
+        tR = torch.from_numpy(R_np.copy()).requires_grad_(True)
+        verts, _, T_, v_posed, _ = ref_lbs_extra(tA[None], tv[None], torch.from_numpy(posedirs_np), tW, torch.from_numpy(pose_np),
+                                                 disable_posedirs=disable, pose2rot=True)
+        rot = T_[0][:, :3, :3] @ tR                                                             # hugs_trimlp.py:517
+        ((verts[0] * torch.from_numpy(g_verts)).sum() + (T_[0] * torch.from_numpy(g_T)).sum() + (rot * torch.from_numpy(g_rot)).sum()).backward()
+        out.update({f"lbs{tag}_verts": verts[0].detach().numpy(), f"lbs{tag}_T": T_[0].detach().numpy(), f"lbs{tag}_rot": rot.detach().numpy(),
+                    f"lbs{tag}_v_posed": v_posed[0].detach().numpy(), f"lbs{tag}_dA": tA.grad.numpy(), f"lbs{tag}_dW": tW.grad.numpy(),
+                    f"lbs{tag}_dv": tv.grad.numpy(), f"lbs{tag}_dR": tR.grad.numpy()})
+
     # ---- PLY attribute order: SceneGS.construct_list_of_attributes, scene.py:229-241, executed ----
     # (save_ply / load_ply themselves need the `plyfile` package, which is not installed: only the attribute list,
     # which fixes the on-disk column order, can be produced by the reference here)

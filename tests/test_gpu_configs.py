@@ -111,6 +111,63 @@ def test_c3_human_only_512(P, device):
     assert float(human["shs"].grad[:, 1:].abs().max()) == 0.0
 
 
+def _matrix_to_quaternion(m):
+    """[n,3,3] -> (w,x,y,z), the branch-free half of the standard conversion (trace > -1 for every matrix used here);
+    plain torch so that the same function runs on the GPU tensors and on the CPU reference chain"""
+    w = 0.5 * torch.sqrt(torch.clamp(1.0 + m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2], min=1e-8))
+    return torch.stack([w, (m[:, 2, 1] - m[:, 1, 2]) / (4 * w), (m[:, 0, 2] - m[:, 2, 0]) / (4 * w), (m[:, 1, 0] - m[:, 0, 1]) / (4 * w)], 1)
+
+
+@pytest.mark.parametrize("P", [6890, 110_210])
+def test_c3_lbs_posed_human_through_the_rasterizer(P, device):
+    """BASELINE configs[2] is the "LBS -> rasterizer path": canonical Gaussians are posed by the learned-LBS skinning
+    (hugs_trimlp.py:477-489, 517 -- hugs_amd.lbs.lbs_skin, fused HIP) and rendered by the rasterizer, and the loss
+    gradient flows back through both to the canonical means, the LBS weights and the joint transforms.  Checked against
+    the CPU chain: oracle rasterizer backward, then the LBS oracle's backward."""
+    from hugs_amd.lbs import lbs_skin
+    from hugs_amd.renderer import render_human_scene
+    from oracle import lbs_oracle as lo
+    cam = syn.rotating_camera(2, 10, dist=5.0, fov=0.4, img_size=512)
+    m = human_gaussians(P, seed=9)
+    rng = np.random.default_rng(4)
+    J = 24
+    A = np.tile(np.eye(4, dtype=np.float32), (J, 1, 1))
+    for j in range(J):      # small rigid motions per joint (a pose), joints spread over the body
+        A[j, :3, :3] = lo.batch_rodrigues(0.25 * rng.standard_normal((1, 3)).astype(np.float32))[0]
+        A[j, :3, 3] = 0.05 * rng.standard_normal(3)
+    centres = (rng.standard_normal((J, 3)) * np.array([0.22, 0.55, 0.14])).astype(np.float32)
+    logit = -np.linalg.norm(m["xyz"][:, None] - centres[None], axis=-1) / 0.08
+    W = np.exp(logit - logit.max(1, keepdims=True))
+    W = (W / W.sum(1, keepdims=True)).astype(np.float32)
+    R0 = lo.batch_rodrigues(rng.standard_normal((P, 3)).astype(np.float32))
+    dL = (rng.standard_normal((3, 512, 512)) * 1e-3).astype(np.float32)
+
+    tA, tW, tx, tR = (to_dev(a, device, True) for a in (A, W, m["xyz"], R0))
+    xyz, T, rot = lbs_skin(tA, tW, tx, tR)
+    rotq = _matrix_to_quaternion(rot)
+    human = {"xyz": xyz, "rotq": rotq, "scales": to_dev(m["scales"], device, True), "shs": to_dev(m["shs"], device, True),
+             "opacity": to_dev(m["opacity"], device, True), "active_sh_degree": 0}
+    pkg = render_human_scene(cam_data(cam, device), human, None, bg_color=torch.ones(3, device=device), render_mode="human")
+    pkg["render"].backward(to_dev(dL, device))
+
+    # ---- CPU chain on the posed inputs the GPU produced
+    posed = dict(m, xyz=xyz.detach().cpu().numpy(), rotq=rotq.detach().cpu().numpy())
+    ref_f, _ = oracle_run(posed, cam, (1.0, 1.0, 1.0), 0, dL)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), ref_f["radii"]) and (ref_f["radii"] > 0).mean() > 0.9
+    check_image(pkg["render"].detach().cpu().numpy(), np.clip(ref_f["color"], 0, 1), f"C3 LBS P={P}")
+    inside = ((ref_f["color"] >= 0) & (ref_f["color"] <= 1)).astype(np.float32)
+    _, ref_g = oracle_run(posed, cam, (1.0, 1.0, 1.0), 0, dL * inside)
+    # posed skinning output of the HIP kernel against the LBS oracle
+    o_xyz, o_T, o_rot = lo.skin(A, W, m["xyz"], R0)
+    np.testing.assert_allclose(posed["xyz"], o_xyz, rtol=2e-5, atol=2e-6)
+    # rasterizer gradients w.r.t. (posed xyz, rotq) -> through the quaternion conversion (torch, CPU) -> LBS oracle backward
+    c_rot = torch.from_numpy(o_rot.astype(np.float64)).requires_grad_(True)
+    _matrix_to_quaternion(c_rot).backward(torch.from_numpy(ref_g["rotations"].astype(np.float64)))
+    ref = lo.skin_backward(A, W, m["xyz"], R0, ref_g["means3D"], None, c_rot.grad.numpy())
+    for t, k in ((tA, "A"), (tW, "weights"), (tx, "v"), (tR, "rotmat")):
+        assert rel_l2(t.grad.cpu().numpy().reshape(ref[k].shape), ref[k]) <= 2 * GRAD_REL_TOL, k
+
+
 @pytest.mark.parametrize("n_human,n_scene", [(30_000, 100_000), (110_210, 200_000)])
 def test_c4_joint_human_scene_1080p(n_human, n_scene, device):
     """(110 210, 200 000) is the full BASELINE configs[3] size (SMPL subdivided twice, hugs_human.yaml:28 + the 200k scene;

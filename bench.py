@@ -34,6 +34,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+KERNEL_OF = {"blend_backward": "blend_backward_kernel", "sort": "tile_sort_small_kernel"}   # stage -> kernel name in the profiles
+
+
 def alg_bytes(P, Pv, N, S, T, K, M=16):
     """Algorithmic bytes: whole fwd+bwd frame, and the blend-backward kernel alone."""
     frame = P * (108 + 12 * K + 12 * M) + Pv * (226 + 12 * K) + 124 * N + 40 * S + 24 * T
@@ -217,7 +220,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dominant = "blend_forward" if args.forward_only else "blend_backward"
+    # (forward-only: the forward blend runs fused with the tile sort, stage "sort" = tile_sort_small_kernel)
+    dominant = "sort" if args.forward_only else "blend_backward"
     profile_enable((dominant,))
     fence()
     t0 = time.perf_counter()
@@ -277,7 +281,7 @@ def main():
     S, T = H * W, ((H + 15) // 16) * ((W + 15) // 16)
     frame_B, bwd_B, fwd_B = alg_bytes(P, Pv, N, S, T, K)
     dom_ms = prof[dominant][0] / prof[dominant][1]
-    dom_B = fwd_B if args.forward_only else bwd_B
+    dom_B = fwd_B + 28 * N if args.forward_only else bwd_B   # fused tile sort + forward blend: + keys in, list and compacted lists out
     achieved = dom_B / (dom_ms * 1e-3) / 1e9
     fps = world * args.steps / elapsed
     out = {
@@ -291,7 +295,7 @@ def main():
                                "GaussianRasterizer (drop-in API), one camera per GPU",
                    "gaussians": P, "visible": Pv, "num_rendered_N": int(N), "tiles": T,
                    "N_per_frame_all_ranks": [int(x) for x in frames[:, 0].tolist()]},
-        "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": round(achieved, 2),
+        "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dominant], "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                      "peak_measured": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
                      "peak_measured_how": "1 GiB device-to-device copy_ on this GPU in this run, (read + write bytes) / time",
@@ -328,8 +332,8 @@ def main():
         pmc = json.load(open(f))
         wl = pmc.get("workload", {})
         same_wl = (wl.get("gaussians"), wl.get("height"), wl.get("width"), wl.get("sh_degree")) == (P, H, W, D)
-        if same_wl and pmc.get("csrc_sha16") == here and dominant + "_kernel" in pmc["kernels"]:
-            out["roofline"]["traffic"] = pmc["kernels"][dominant + "_kernel"]["hbm_bytes_corrected"]
+        if same_wl and pmc.get("csrc_sha16") == here and KERNEL_OF[dominant] in pmc["kernels"]:
+            out["roofline"]["traffic"] = pmc["kernels"][KERNEL_OF[dominant]]["hbm_bytes_corrected"]
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(f)
         else:
             out["roofline"]["traffic_note"] = (f"stale or other workload: profiles/{os.path.basename(f)} was taken on csrc "
@@ -337,13 +341,13 @@ def main():
     f = newest("*_valu_utilization.json")
     if f:
         vu_all = json.load(open(f))
-        vu = vu_all.get("kernels", {}).get(dominant + "_kernel")
+        vu = vu_all.get("kernels", {}).get(KERNEL_OF[dominant])
         if vu and vu_all.get("csrc_sha16") == here:
-            out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": vu["valu_busy_frac"],
+            out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": vu["valu_busy_frac"],
                                  "wave_instructions_per_launch": vu["valu_wave_instructions"],
                                  "source": "profiles/" + os.path.basename(f) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
         else:
-            out["valu_issue"] = {"kernel": dominant + "_kernel", "busy_frac": None,
+            out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": None,
                                  "note": f"stale: profiles/{os.path.basename(f)} was taken on csrc {vu_all.get('csrc_sha16')}, this build is {here}"}
 
     if world == 1 and not args.no_cpu_baseline:

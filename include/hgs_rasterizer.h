@@ -235,7 +235,7 @@ void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);
 
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
- * Names: geom: "splats" (48-byte records), "tiles_touched"; binning: "list" (the sorted list, one u64 per entry:
+ * Names: geom: "splats" (64-byte records), "tiles_touched"; binning: "list" (the sorted list, one u64 per entry:
  * (1-based position inside the tile << 32) | quad coverage mask << 28 | Gaussian index), "bitmaps";
  * image: "final_T", "n_contrib" (low 28 bits: position of the last contributing entry; bits 29..31: which colour channels
  * pass dL/dout_color, all set unless clamp_output clipped them), "ranges". Returns (size_t)-1 for an unknown name. */

@@ -21,6 +21,7 @@
 
 #include "hgs_common.h"
 #include "binning_walk.h"
+#include "blend_fwd.h"
 
 namespace hgs {
 
@@ -483,10 +484,11 @@ __device__ __forceinline__ void compact_chunk(uint64_t entry, bool valid, uint32
     __syncthreads();
 }
 
+// (returns the length of compacted list `want_list` -- the fused kernel's waves ask for their quad's)
 template <int E>
-__device__ __forceinline__ void tile_sort_small(uint32_t tile, uint32_t s, uint32_t n, const uint64_t* __restrict__ keys,
-                                                uint64_t* __restrict__ list, uint64_t* __restrict__ act, size_t stride,
-                                                uint32_t* __restrict__ act_count, uint64_t* sh)
+__device__ __forceinline__ uint32_t tile_sort_small(uint32_t tile, uint32_t s, uint32_t n, const uint64_t* __restrict__ keys,
+                                                    uint64_t* __restrict__ list, uint64_t* __restrict__ act, size_t stride,
+                                                    uint32_t* __restrict__ act_count, uint64_t* sh, int want_list)
 {
     uint64_t key[E];
 #pragma unroll
@@ -503,33 +505,71 @@ __device__ __forceinline__ void tile_sort_small(uint32_t tile, uint32_t s, uint3
         if (i < n) list[s + i] = entry;
         compact_chunk(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
     }
+    uint32_t mine = 0;
 #pragma unroll
-    for (int q = 0; q < NUM_LISTS; ++q)
+    for (int q = 0; q < NUM_LISTS; ++q) {
         if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
+        if (q == want_list) mine = carry[q];
+    }
+    return mine;
 }
 
+// Tile sort FUSED with the forward blend: one workgroup per tile sorts the tile's segment, writes the sorted list and the
+// five compacted lists, and its four waves then blend the tile's four quads from the lists they just wrote.  Besides
+// saving a launch, this mixes the two phases on every CU -- the sort is latency-bound (loads, LDS exchanges, barriers:
+// 64 % VALU-busy on its own), the blend VALU-bound (77 % on its own, waiting for scalar loads the rest): each fills the
+// other's idle issue slots.  The lists are read through the scalar cache, which is not coherent with vector stores:
+// the stores are released to L2 (agent-scope fence), the workgroup meets at a barrier, and the scalar cache is
+// invalidated before the first list read (a neighbouring tile's prefetch may have pulled a stale line of this segment in).
+// Long tiles (n > 2048) are left to tile_sort_large_kernel + the stand-alone forward blend over the long-tile list.
+// FUSED = false: sort only (the stand-alone forward blend follows).
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
                        uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count,
-                       const uint32_t* __restrict__ gate)
+                       const uint32_t* __restrict__ gate, Camera cam, uint32_t lastg, const Splat* __restrict__ splats,
+                       const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
+                       uint32_t* __restrict__ n_contrib, int clamp_output, int long_sorted)
 {
     __shared__ uint64_t sh[SORT_CAP_SMALL];
     if (*gate) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t s = rg.x, n = rg.y - rg.x;
+    uint32_t mine = 0;
     if (n == 0) {
         if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
-        return;
+        if (!FUSED) return;
+    } else if (n > (uint32_t)SORT_CAP_SMALL) {
+        // a long tile: sorted by tile_sort_large_kernel, which ran BEFORE this kernel (long_sorted) -- then only the blend is
+        // left to do here -- or whose launch was skipped on the caller's guess that the frame has none: the tile's lists
+        // read as empty and its pixels stay unwritten until the caller has repaired the guess (hgs_api.hip)
+        if (!long_sorted) {
+            if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
+            return;
+        }
+        if (!FUSED) return;
+        mine = ((const_u32p)act_count)[blockIdx.x * NUM_LISTS + w];
+    } else {
+        if (n <= 256u) mine = tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
+        else if (n <= 512u) mine = tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
+        else if (n <= 1024u) mine = tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
+        else mine = tile_sort_small<8>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
+        if (FUSED) {
+            // workgroup scope: wait for the list stores to be acknowledged by L2 (the vector L1 is write-through); an
+            // AGENT-scope release would also write the XCD's whole L2 back -- 0.7 ms per frame when every tile does it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+#ifndef EXP_NO_DCACHE_INV
+            __builtin_amdgcn_s_dcache_inv();
+#endif
+        }
     }
-    if (n > (uint32_t)SORT_CAP_SMALL) {
-        // the long-tile kernel's job; until it has run the tile's lists read as empty (its launch may be deferred)
-        if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
-        return;
+    if (FUSED) {
+        mine = __builtin_amdgcn_readfirstlane(mine);
+        blend_forward_wave(cam, lastg, (int)(blockIdx.x % (uint32_t)cam.gx), (int)(blockIdx.x / (uint32_t)cam.gx), w, mine,
+                           act + (size_t)w * stride + s, splats, bg, out_color, final_T, n_contrib, clamp_output);
     }
-    if (n <= 256u) tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
-    else if (n <= 512u) tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
-    else if (n <= 1024u) tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
-    else tile_sort_small<8>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh);
 }
 
 // Tiles with more than CAP_SMALL entries: bitonic in LDS up to CAP entries, brute-force ranking through global
@@ -631,16 +671,23 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, bool small_tiles, bool long_tiles, hipStream_t st)
+                      const uint32_t* n_total, bool small_tiles, bool long_tiles, const FusedBlend* fb, hipStream_t st)
 {
-    if (small_tiles)
-        hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                           n_total + 1);
-    // the long-tile kernel walks a device-built list that is empty on most frames: the caller skips its launch when the
-    // previous frame of this shape had no long tile, and runs it (and the forward blend again) when that guess was wrong
+    // The long-tile kernel goes FIRST: the small-tile kernel then blends (fused) the long tiles too, from the lists this
+    // one wrote.  It walks a device-built list that is empty on most frames: the caller skips its launch when the previous
+    // frame of this shape had no long tile, and runs it (and the long tiles' forward blend) later when that guess was wrong.
     if (long_tiles)
         hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(SORT_LARGE_THREADS), 0, st, ranges,
                            keys, list, scratch, act, stride, act_count, large_tiles, n_total);
+    if (small_tiles) {
+        if (fb)
+            hipLaunchKernelGGL(tile_sort_small_kernel<true>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
+                               n_total + 1, fb->cam, fb->lastg, fb->splats, fb->bg, fb->out_color, fb->final_T, fb->n_contrib, fb->clamp_output,
+                               long_tiles ? 1 : 0);
+        else
+            hipLaunchKernelGGL(tile_sort_small_kernel<false>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
+                               n_total + 1, Camera{}, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0, long_tiles ? 1 : 0);
+    }
 }
 
 }  // namespace hgs

@@ -1,5 +1,6 @@
 // C ABI entry points (include/hgs_rasterizer.h): argument validation, scratch layout, stage sequencing.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -345,8 +346,27 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const uint32_t* gate = n_total + 1;
     // the long-tile sort is launched unless the caller expects no long tile (its previous frame of this shape had none)
     const bool guess_no_long = a.expect_no_long_tiles != 0;
+    // HGS_FUSED_SORT_BLEND=0: separate tile-sort and forward-blend kernels (A/B measurements); default: fused
+    static const bool fused = [] { const char* e = getenv("HGS_FUSED_SORT_BLEND"); return !(e && e[0] == '0'); }();
+    float* final_T = (float*)(image + il.final_T);
+    uint32_t* n_contrib = (uint32_t*)(image + il.n_contrib);
+    const FusedBlend fb{cam, (uint32_t)(a.P - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0};
+    // repair of a wrong "no long tiles" guess: the long tiles' own sort kernel, then the forward blend over the device-built
+    // list of them (normally the long-tile sort runs in front of the small-tile kernel, which then blends every tile)
+    auto enqueue_long_tiles = [&](const BinningLayout& bl, char* bin) -> int {
+        uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
+        { ProfScope ps(HGS_STAGE_SORT, st);
+          launch_tile_sort(ranges, num_tiles, (uint64_t*)(bin + bl.keys), (uint64_t*)(bin + bl.list), (uint64_t*)(bin + bl.scratch), act,
+                           bl.act_stride, act_count, large_tiles, n_total, false, true, nullptr, st); }
+        STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
+        { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
+          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
+                               a.clamp_output != 0, large_tiles, n_total + 2, st); }
+        STAGE_CHECK(dbg, st, "blend_forward (long tiles)");
+        return HGS_OK;
+    };
     // enqueue emit -> sort -> blend for a binning buffer laid out for `capacity` entries
-    auto enqueue_frame = [&](int64_t capacity, bool with_long_sort) -> int {
+    auto enqueue_frame = [&](int64_t capacity, bool with_long_tiles) -> int {
         BinningLayout bl(capacity);
         char* bin = obtain(HGS_BUF_BINNING, bl.total);
         if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
@@ -357,12 +377,16 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, group, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
-          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total, true, with_long_sort, st); }
-        STAGE_CHECK(dbg, st, "tile_sort");
-        { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
-                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, a.clamp_output != 0, st); }
-        STAGE_CHECK(dbg, st, "blend_forward");
+          launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total,
+                           true, with_long_tiles, fused ? &fb : nullptr, st); }
+        STAGE_CHECK(dbg, st, fused ? "tile_sort + blend_forward" : "tile_sort");
+        if (!fused) {
+            // (when the long-tile sort was skipped, long tiles read as empty here: they are blended by the repair)
+            { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
+              launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
+                                   a.clamp_output != 0, nullptr, nullptr, st); }
+            STAGE_CHECK(dbg, st, "blend_forward");
+        }
         return HGS_OK;
     };
 
@@ -391,18 +415,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
         if (int rc = enqueue_frame(N, has_long)) return rc;
     } else if (has_long && !long_sort_done) {
-        // guessed "no long tiles" wrongly: their lists read as empty so far -- sort them now and blend again
-        BinningLayout bl(state->binning_capacity);
-        char* bin = (char*)state->binning;
-        uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_SORT, st);
-          launch_tile_sort(ranges, num_tiles, (uint64_t*)(bin + bl.keys), (uint64_t*)(bin + bl.list), (uint64_t*)(bin + bl.scratch), act,
-                           bl.act_stride, act_count, large_tiles, n_total, false, true, st); }
-        STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
-        { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color,
-                               (float*)(image + il.final_T), (uint32_t*)(image + il.n_contrib), gate, a.clamp_output != 0, st); }
-        STAGE_CHECK(dbg, st, "blend_forward (after long tiles)");
+        // guessed "no long tiles" wrongly: their lists read as empty so far -- sort and blend them now
+        if (int rc = enqueue_long_tiles(BinningLayout(state->binning_capacity), (char*)state->binning)) return rc;
     }
     return N;
 }

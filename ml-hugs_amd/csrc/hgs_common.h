@@ -20,9 +20,11 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr uint32_t GID_BITS = 28;
 constexpr uint32_t GID_MASK = (1u << GID_BITS) - 1u;
 
-// Per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
-// 48 bytes, 16-byte aligned: three dwordx4 (scalar or vector) loads.
-struct alignas(16) Splat {
+// Per-Gaussian record written by the preprocess kernel and gathered by the blend kernels through the scalar cache.
+// 64 bytes, 64-byte aligned: a record is exactly ONE cache line.  (It was 48 bytes packed; the blend kernels' record
+// fetches then touched 1.5 lines on average -- every second record straddles a line boundary -- and the forward blend,
+// which waits on the scalar cache a quarter of its time, runs ~10 % faster with one line per record.)
+struct alignas(64) Splat {
     float x, y;        // pixel-space mean
     // The blend kernels work in the log2 domain: alpha = exp2(A dx^2 + B dx dy + C dy^2 + L), one v_exp_f32 with no
     // multiply before or after.  (A,B,C) = fl(LOG2E * (-conic.xx/2, -conic.xy, -conic.yy/2)); L = log2(opacity).
@@ -32,8 +34,9 @@ struct alignas(16) Splat {
     float depth;       // view-space z; its raw bits are the low half of the sort key
     int32_t radius;    // 0 => culled
     uint32_t clamped;  // bit c set => colour channel c was clamped at 0
+    uint32_t pad[4];
 };
-static_assert(sizeof(Splat) == 48, "Splat layout");
+static_assert(sizeof(Splat) == 64, "Splat layout");
 
 struct Camera {  // small by-value kernel argument
     int W, H, gx, gy;
@@ -131,13 +134,18 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, int group,
                  uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
+// fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
+struct FusedBlend {
+    Camera cam; uint32_t lastg; const Splat* splats; const float* bg; float* out_color; float* final_T; uint32_t* n_contrib; int clamp_output;
+};
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, bool small_tiles, bool long_tiles, hipStream_t st);
+                      const uint32_t* n_total, bool small_tiles, bool long_tiles, const FusedBlend* fb, hipStream_t st);
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output, hipStream_t st);
+                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output,
+                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,

@@ -56,7 +56,7 @@ int main(void) {
 def test_scratch_size_queries_and_offsets():
     import diff_gaussian_rasterization as dgr
     lib = dgr._load()
-    assert lib.hgs_geom_bytes(1000, 1080, 1920) >= 1000 * (48 + 4) + 4 * 8160
+    assert lib.hgs_geom_bytes(1000, 1080, 1920) >= 1000 * (64 + 4) + 4 * 8160
     assert lib.hgs_image_bytes(1080, 1920) >= 1080 * 1920 * 8 + 8160 * 8
     n = 123456
     assert lib.hgs_binning_bytes(n, 1080, 1920) >= n * 24

@@ -235,7 +235,8 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, coll_dev)
 
     # exact integers of this frame (shared with the oracle): N and the visible count
-    N = color.grad_fn.num_rendered if color.grad_fn is not None else None
+    import diff_gaussian_rasterization as dgr
+    N = dgr.last_frame_info()[0]
     Pv = int((radii > 0).sum())
     if N is None:
         from diff_gaussian_rasterization import _debug_forward_state

@@ -556,13 +556,15 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
         else if (n <= 1024u) mine = tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
         else mine = tile_sort_small<8>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
         if (FUSED) {
-            // workgroup scope: wait for the list stores to be acknowledged by L2 (the vector L1 is write-through); an
-            // AGENT-scope release would also write the XCD's whole L2 back -- 0.7 ms per frame when every tile does it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // The list stores must have been acknowledged by L2 (the vector L1 is write-through) before any wave reads
+            // them through the scalar cache.  A workgroup-scope release fence does NOT wait for that on this target
+            // (a workgroup shares its vector L1, so the compiler emits no vmcnt wait -- observed: one frame in a few
+            // showed stale lists), and an AGENT-scope release also writes the XCD's whole L2 back (0.7 ms per frame when
+            // every tile does it): spell the wait out.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-#ifndef EXP_NO_DCACHE_INV
             __builtin_amdgcn_s_dcache_inv();
-#endif
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the invalidate has completed before the first list read
         }
     }
     if (FUSED) {

@@ -363,8 +363,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if n < 0:
             _raise_last(lib, "rasterize_gaussians")
 
+        global _last_frame_info
         ctx.num_rendered = int(n)
         ctx.binning_capacity = int(state.binning_capacity)
+        _last_frame_info = (ctx.num_rendered, ctx.binning_capacity)
         _remember(hint_key, int(n), bool(state.has_long_tiles))
         ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P, M)
         ctx.scratch, ctx.bufs = scratch, bufs   # kept alive for backward (and read by _debug_forward_state)
@@ -423,8 +425,53 @@ class _RasterizeGaussians(torch.autograd.Function):
                 None, None)
 
 
+# The same binding as a C++ autograd node (ml-hugs_amd/csrc_torch/hgs_torch.cpp -> lib/_hgs_torch.so): identical library
+# calls and policy without the interpreter in the per-frame path.  Used when it has been built (__graft_entry__.build()
+# does); HGS_BINDING=ctypes forces the Python path above.  Both are the HIP path -- neither is a fallback for the kernels.
+_cpp = None
+_CPP_WANTED = os.environ.get("HGS_BINDING", "cpp") != "ctypes"
+
+
+def _load_cpp():
+    global _cpp, _CPP_WANTED
+    if _cpp is not None or not _CPP_WANTED:
+        return _cpp
+    path = os.path.join(os.path.dirname(_LIB_PATH), "_hgs_torch.so")
+    if not os.path.exists(path) or os.environ.get("HGS_RASTERIZER_LIB"):   # (an A/B library build has no matching binding)
+        _CPP_WANTED = False
+        return None
+    _load()   # libhgs_rasterizer.so first (ABI check); the extension links against it
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_hgs_torch", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.abi_version() != _ABI_VERSION:
+        raise RuntimeError("_hgs_torch.so was built against another ABI version; rebuild it")
+    mod.use_hints(_USE_HINT)
+    _cpp = mod
+    return mod
+
+
+_last_frame_info = (None, None)
+
+
+def last_frame_info():
+    """(N, binning capacity) of the last forward, whichever binding ran it."""
+    return _last_frame_info
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, clamp_output=False):
+    global _last_frame_info
+    cpp = _load_cpp()
+    if cpp is not None:
+        rs = raster_settings
+        color, radii = cpp.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
+                                     rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
+                                     float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
+                                     bool(rs.prefiltered), bool(rs.debug), bool(clamp_output))
+        _last_frame_info = cpp.last_frame_info()
+        return color, radii
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, clamp_output)
 

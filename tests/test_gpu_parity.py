@@ -60,6 +60,13 @@ def run_gpu(sc, device, debug=False):
     return t, color, radii
 
 
+def _force_ctypes_binding(monkeypatch):
+    """run the calls of this test through the Python (ctypes) binding instead of the C++ autograd node"""
+    import diff_gaussian_rasterization as dgr
+    monkeypatch.setattr(dgr, "_cpp", None)
+    monkeypatch.setattr(dgr, "_CPP_WANTED", False)
+
+
 def check_image(gpu, ref, what):
     d = np.abs(gpu.astype(np.float64) - ref.astype(np.float64))
     assert d.max() <= COLOR_OUTLIER_TOL, f"{what}: max |d| = {d.max():.3e}"
@@ -192,6 +199,7 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     """forward enqueues the frame before N is known when it has a guess of N (include/hgs_rasterizer.h,
     binning_capacity_hint); a guess that is too small must be detected on the device and the frame redone."""
     import diff_gaussian_rasterization as dgr
+    _force_ctypes_binding(monkeypatch)      # the hint is injected through the Python binding's hooks
     sc = make_scene(**CASES["basic_d3"])
     key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])
     dgr._last_num_rendered.pop(key, None)
@@ -214,6 +222,39 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         if t0[k] is not None and t0[k].grad is not None:   # float atomics: summation order differs run to run
             assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["basic_d3", "precomp_rgb", "precomp_cov", "deg0_M16"])
+def test_cpp_binding_equals_ctypes_binding(name, device, monkeypatch):
+    """The C++ autograd node (csrc_torch/hgs_torch.cpp) and the Python binding make the same library calls: same image,
+    same radii, same gradients; a wrong capacity / long-tile hint injected into the C++ node is repaired the same way."""
+    import diff_gaussian_rasterization as dgr
+    monkeypatch.setattr(dgr, "_CPP_WANTED", True)          # (also when the suite runs with HGS_BINDING=ctypes)
+    cpp = dgr._load_cpp()
+    assert cpp is not None, "lib/_hgs_torch.so is missing: __graft_entry__.build() makes it"
+    sc = make_scene(**CASES[name])
+    g = to_dev(sc["dL_dpix"], device)
+    cpp.clear_hints()
+    runs = []
+    for hint in (None, (100, False), (10 ** 6, False)):      # no history / too small / ample
+        if hint is not None:
+            cpp.set_hint(torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"], hint[0], hint[1])
+        t, c, r = run_gpu(sc, device)
+        assert c.grad_fn is not None and c.grad_fn.name().endswith("Rasterize>") and dgr.last_frame_info()[0] > 0     # the C++ node
+        c.backward(g)
+        runs.append((t, c, r))
+    _force_ctypes_binding(monkeypatch)
+    t0, c0, r0 = run_gpu(sc, device)
+    assert "_RasterizeGaussians" in c0.grad_fn.name()                                                          # the Python node
+    c0.backward(g)
+    torch.cuda.synchronize()
+    for t, c, r in runs:
+        assert torch.equal(c, c0) and torch.equal(r, r0)
+        for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+            if t0[k] is not None and t0[k].grad is not None:
+                assert rel_l2(t[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= 1e-5, k
+            else:
+                assert t[k] is None or t[k].grad is None or float(t[k].grad.abs().max()) == 0.0
 
 
 def test_second_backward_through_a_retained_graph(device):
@@ -570,6 +611,7 @@ def test_wrong_guess_about_long_tiles_never_changes_results(wrong_guess, device,
     guess `expect_no_long_tiles` (previous frame of this shape had none) skips the long-tile sort launch.  A wrong guess
     must be repaired -- long tiles sorted, forward blend repeated -- with identical results (include/hgs_rasterizer.h)."""
     import diff_gaussian_rasterization as dgr
+    _force_ctypes_binding(monkeypatch)
     sc = _stacked_scene(6000, 64, 64, seed=47, spread_px=6.0)     # longest tile list in 2049..8192
     key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])
     dgr._last_num_rendered.pop(key, None)
@@ -651,6 +693,7 @@ def test_deferred_frame_that_overflows_is_run_again(device, monkeypatch):
     nothing, hgs_forward_poll reports HGS_ERR_OVERFLOW and resolve() runs the frame again exactly sized."""
     import diff_gaussian_rasterization as dgr
     from hugs_amd.renderer import render, render_batch
+    _force_ctypes_binding(monkeypatch)
     sc = make_scene(P=3000, H=128, W=192, seed=62, D=3, sigma_px=5.0)
     frames = _orbit_frames(sc, device, 4)
     with torch.no_grad():
@@ -691,6 +734,27 @@ def test_render_human_scene_batch_matches_render_human_scene(device):
         for k in b:
             if k != "viewspace_points":
                 assert torch.equal(a[k], b[k]), k
+
+
+def test_fused_sort_blend_reads_its_own_lists_coherently(device):
+    """The tile-sort kernel blends its tile from the lists it has just written, reading them through the scalar cache
+    (csrc/binning.hip).  Many tiny tiles (lists sharing cache lines) is where a missing wait for the list stores showed:
+    repeated frames must stay bit-identical and equal to the oracle's image."""
+    sc = make_scene(P=3000, H=2304, W=4096, seed=50, D=2, sigma_px=20.0, with_culled=True)
+    ref = ho.forward(oracle_inputs(sc))
+    t = gpu_tensors(sc, device, grad=False)
+    from diff_gaussian_rasterization import GaussianRasterizer
+    rast = GaussianRasterizer(gpu_settings(sc, device))
+    first = None
+    with torch.no_grad():
+        for rep in range(12):
+            color, _ = rast(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                            rotations=t["rotations"])
+            if first is None:
+                first = color.clone()
+                check_image(first.cpu().numpy(), ref["color"], "36k tiles, fused")
+            else:
+                assert torch.equal(color, first), f"frame {rep} differs from frame 0"
 
 
 def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):

@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
 """Stability soak on one MI355X: random scene sizes / image shapes / SH degrees, frames alternating between three HIP
-streams, forced capacity-guess misses (too-small and absent hints), forward-only and forward+backward, for 40 s.
-Prints "soak ok: <frames> ..." or raises.   python tools/soak.py"""
-import sys, math, time, random, numpy as np, torch
+streams and between the two bindings (C++ autograd node, Python ctypes), forced hint misses (too-small capacity, wrong
+"no long tiles", absent hints), forward-only (incl. deferred render_batch frames) and forward+backward, for SOAK_SECONDS
+(default 40).  Every image is compared bit-for-bit with the first render of its scene (the forward is deterministic), every
+gradient within 1e-4 relative of its first value.  Prints "soak ok: <frames> ..." or raises.   python tools/soak.py"""
+import math
 import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-hugs_amd"))
-import diff_gaussian_rasterization as dgr
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from hugs_amd import synthetic as syn
+import diff_gaussian_rasterization as dgr                                                     # noqa: E402
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer     # noqa: E402
+from hugs_amd import synthetic as syn                                                         # noqa: E402
+from hugs_amd.renderer import render, render_batch                                            # noqa: E402
+
 dev = torch.device("cuda:0")
-random.seed(0)
-shapes = [(64, 96), (128, 128), (270, 480), (1080, 1920), (100, 37)]
-scenes = {}
+random.seed(int(os.environ.get("SOAK_SEED", "0")))
+shapes = [(64, 96), (128, 128), (270, 480), (1080, 1920), (100, 37), (2304, 4096)]
+scenes, first = {}, {}
+
+
 def scene(P, H, W):
     k = (P, H, W)
     if k not in scenes:
@@ -19,29 +32,72 @@ def scene(P, H, W):
         g = syn.scene_gaussians(P, cam, seed=P % 97, sigma_px=random.choice([2.0, 5.0, 12.0]), ref_P=max(P, 1000), cluster=random.choice([0.0, 0.6]))
         d = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
         t = {kk: d(g[kk], True) for kk in ("means3D", "opacities", "shs", "scales", "rotations")}
-        st = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"]/2), math.tan(cam["fovy"]/2), torch.ones(3, device=dev), 1.0,
-             d(cam["world_view_transform"]), d(cam["full_proj_transform"]), random.choice([0, 1, 3]), d(cam["camera_center"]), False, False)
-        scenes[k] = (t, st, torch.zeros(P, 3, device=dev, requires_grad=True), torch.randn(3, H, W, device=dev) * 1e-3)
+        data = {kk: (d(v) if isinstance(v, np.ndarray) else v) for kk, v in cam.items()}
+        st = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"] / 2), math.tan(cam["fovy"] / 2), torch.ones(3, device=dev), 1.0,
+                                           data["world_view_transform"], data["full_proj_transform"], random.choice([0, 1, 3]),
+                                           data["camera_center"], False, False)
+        scenes[k] = (t, st, torch.zeros(P, 3, device=dev, requires_grad=True), torch.randn(3, H, W, device=dev) * 1e-3, data)
     return scenes[k]
+
+
+cpp = dgr._load_cpp()
 streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-t0 = time.time(); n = 0
+budget = float(os.environ.get("SOAK_SECONDS", "40"))
+t0 = time.time()
+n = n_batch = 0
 orig_hint = dgr._capacity_hint
-while time.time() - t0 < 40:
-    H, W = random.choice(shapes); P = random.choice([1, 50, 3000, 40000, 200000 if H >= 270 else 5000])
-    t, st, m2d, dL = scene(P, H, W)
+pending = []
+while time.time() - t0 < budget:
+    H, W = random.choice(shapes)
+    P = random.choice([1, 50, 3000, 40000, 200000 if 270 <= H <= 1080 else 5000])
+    key = (P, H, W)
+    t, st, m2d, dL, data = scene(P, H, W)
     r = random.random()
-    dgr._capacity_hint = (lambda k: (64, 1)) if r < 0.1 else ((lambda k: (0, 0)) if r < 0.2 else orig_hint)
+    use_cpp = cpp is not None and random.random() < 0.5
+    dgr._cpp, dgr._CPP_WANTED = (cpp, True) if use_cpp else (None, False)
+    if use_cpp:
+        if r < 0.1:
+            cpp.set_hint(0, P, H, W, 64, False)         # too small, and "no long tiles"
+        elif r < 0.2:
+            cpp.clear_hints()
+    else:
+        dgr._capacity_hint = (lambda k: (64, 1)) if r < 0.1 else ((lambda k: (0, 0)) if r < 0.2 else orig_hint)
     s = random.choice(streams)
     s.wait_stream(torch.cuda.current_stream(dev))
+    mode = random.random()
     with torch.cuda.stream(s):
-        color, radii = GaussianRasterizer(st)(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-        if random.random() < 0.8:
-            color.backward(dL)
-            for x in list(t.values()) + [m2d]:
-                x.grad = None
+        if mode < 0.15 and key in first:                # a few deferred frames of this scene through render_batch
+            fr = dict(means3D=t["means3D"].detach(), feats=t["shs"].detach(), opacity=t["opacities"].detach(), scales=t["scales"].detach(),
+                      rotations=t["rotations"].detach(), data=data, bg_color=st.bg, active_sh_degree=st.sh_degree)
+            with torch.no_grad():
+                want = render(**fr)["render"]
+            for out in render_batch([fr] * 3, num_streams=random.choice([1, 2, 3])):
+                assert torch.equal(out["render"], want), f"render_batch differs from render() on {key}"
+            n_batch += 3
+        else:
+            color, radii = GaussianRasterizer(st)(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"],
+                                                  scales=t["scales"], rotations=t["rotations"])
+            grads = None
+            if mode < 0.8:
+                color.backward(dL)
+                grads = [t[k].grad for k in ("means3D", "opacities", "scales")]
+                for x in list(t.values()) + [m2d]:
+                    x.grad = None
+            pending.append((key, color.detach(), grads))
     n += 1
-    if n % 200 == 0:
+    if n % 50 == 0:
         torch.cuda.synchronize()
-        assert torch.isfinite(color).all()
+        for key, color, grads in pending:
+            if key not in first:
+                assert torch.isfinite(color).all()
+                first[key] = [color, None]
+            assert torch.equal(color, first[key][0]), f"image of {key} changed between frames"
+            if grads is not None:
+                if first[key][1] is None:
+                    first[key][1] = grads
+                for a, b in zip(grads, first[key][1]):
+                    rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                    assert rel <= 1e-4, f"gradient of {key} drifted: {rel:.2e}"
+        pending.clear()
 torch.cuda.synchronize()
-print(f"soak ok: {n} frames in {time.time() - t0:.1f} s over {len(scenes)} scenes")
+print(f"soak ok: {n} frames (+{n_batch} deferred) in {time.time() - t0:.1f} s over {len(scenes)} scenes, C++ binding {'used' if cpp else 'absent'}")

@@ -126,7 +126,8 @@ public:
             std::lock_guard<std::mutex> lk(g_mu);
             auto it = g_hints.find(key);
             if (g_use_hint && it != g_hints.end()) {
-                a.binning_capacity_hint = it->second.n + it->second.n / 8 + 4096;
+                // + 12.5 % + 4096, rounded up to 256 Ki entries: frame after frame asks the caching allocator for the same size
+                a.binning_capacity_hint = (it->second.n + it->second.n / 8 + 4096 + 0x3FFFF) & ~(int64_t)0x3FFFF;
                 a.expect_no_long_tiles = it->second.has_long ? 0 : 1;
             }
         }

@@ -228,7 +228,8 @@ def _capacity_hint(key):
     if prev is None:
         return 0, 0
     n, had_long = prev
-    return n + n // 8 + 4096, 0 if had_long else 1
+    # + 12.5 % + 4096, rounded up to 256 Ki entries: frame after frame asks the caching allocator for the same size
+    return (n + n // 8 + 4096 + 0x3FFFF) & ~0x3FFFF, 0 if had_long else 1
 
 
 _GRAD_NAMES = ("grad_accum", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",

@@ -215,7 +215,7 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     t1, c1, r1 = run_gpu(sc, device)
     cap = c1.grad_fn.binning_capacity
     assert c1.grad_fn.num_rendered == n
-    assert cap == (n if guess != "ample" else n + n // 8 + 4096)
+    assert cap == (n if guess != "ample" else (n + n // 8 + 4096 + 0x3FFFF) & ~0x3FFFF)
     c1.backward(to_dev(sc["dL_dpix"], device))
     torch.cuda.synchronize()
     assert torch.equal(c0, c1) and torch.equal(r0, r1)

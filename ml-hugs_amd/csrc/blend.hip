@@ -116,20 +116,21 @@ struct PixBwd {
     uint32_t last_contributor;
 };
 
-// Adds pixel `p`'s contribution for splat `s` (list position pos1) into the lane-private partial sums v[9] and raises
-// the lane's `contributed` flag.  The body is one exec-masked region: a quad none of whose pixels takes the splat
-// costs the alpha evaluation and a branch.
+// Adds pixel `p`'s contribution for splat `s` (list position pos1) to the lane-private partial sums v[9]; returns the
+// lanes that took the splat (a scalar mask -- no per-lane "contributed" flag to carry).
 // (dy, bdy = B dy, q = C dy^2 + L: the row terms of log2_alpha, shared by the two quads of a tile row)
-__device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float dy, float bdy, float q,
-                                          float (&v)[9], uint32_t& contributed)
+__device__ __forceinline__ unsigned long long bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float dy, float bdy,
+                                                        float q, float (&v)[9])
 {
     const float dx = s.x - p.pxf;
     const float e = __builtin_fmaf(dx, __builtin_fmaf(s.A, dx, bdy), q);  // == log2_alpha(s, dx, dy), same rounding
     const float alpha_uncapped = __builtin_amdgcn_exp2f(e);  // = opacity * G
     const float alpha = fminf(ALPHA_MAX, alpha_uncapped);
     const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
+    const unsigned long long took = __builtin_amdgcn_ballot_w64(act_lane);
+    // (a branch-free body -- alphas forced to 0 for lanes that do not take the splat -- and a first-quad-assigns variant
+    //  that spares the zero fill of v[] were both measured: equal or slower, the exec-masked region stays)
     if (act_lane) {
-        contributed = 1u;
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         p.T = p.T * inv;  // transmittance in front of this entry
         const float cg = __builtin_fmaf(s.r, p.g0, __builtin_fmaf(s.g, p.g1, s.b * p.g2));
@@ -154,6 +155,7 @@ __device__ __forceinline__ void bwd_pixel(const SplatRec& s, uint32_t pos1, PixB
         v[7] = __builtin_fmaf(dch, p.g1, v[7]);
         v[8] = __builtin_fmaf(dch, p.g2, v[8]);
     }
+    return took;
 }
 
 // NQ = 4: one wave per tile (four tiles per 256-thread workgroup, no LDS, no barrier).  A lane's four pixels sit in
@@ -226,20 +228,20 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
     auto backward_entry = [&](const SplatRec& s, uint32_t val, uint32_t pos1) {
         if (pos1 > wmax) return;
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        uint32_t contributed = 0u;
+        unsigned long long took = 0ull;  // lanes (of any quad) that took the splat: scalar
         if constexpr (NQ == 4) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (((val >> (GID_BITS + 2 * r)) & 3u) == 0u) continue;
                 const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
-                if ((val >> (GID_BITS + 2 * r)) & 1u) bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v, contributed);
-                if ((val >> (GID_BITS + 2 * r + 1)) & 1u) bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v, contributed);
+                if ((val >> (GID_BITS + 2 * r)) & 1u) took |= bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v);
+                if ((val >> (GID_BITS + 2 * r + 1)) & 1u) took |= bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v);
             }
         } else {  // every entry of a quad's list covers the quad
             const float dy = s.y - p[0].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
-            bwd_pixel(s, pos1, p[0], dy, bdy, q, v, contributed);
+            took = bwd_pixel(s, pos1, p[0], dy, bdy, q, v);
         }
-        if (__builtin_amdgcn_ballot_w64(contributed != 0u) == 0ull) return;
+        if (took == 0ull) return;
         // ---- transpose-reduce of v0..v7 over the wave: each step adds partner lanes AND halves the number of live
         // registers.  Lane-half and row exchanges are gfx950's v_permlane{32,16}_swap (no select needed: the swap
         // itself routes value a to one half and value b to the other), then one select step inside the row and three

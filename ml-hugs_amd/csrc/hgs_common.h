@@ -60,7 +60,10 @@ inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + T
 inline int bin_group_for(int P, int num_tiles)
 {
     if (num_tiles > BIN_LDS_TILES) return 0;
-    const long long want = ((long long)P + 249) / 250;                                   // ~250 groups
+    // ~250 groups per "round" of the 256 CUs, and whole rounds: 300 000 Gaussians are 469 groups of 640 (two rounds),
+    // not 293 of 1024 (one round and a nearly empty second one that takes just as long)
+    const long long rounds = ((long long)P + 250 * BIN_GROUP - 1) / (250 * BIN_GROUP);
+    const long long want = ((long long)P + 250 * rounds - 1) / (250 * rounds);
     const long long floor_by_tiles = ((long long)P * num_tiles + (4ll << 20) - 1) / (4ll << 20);  // <= 4 Mi tile visits
     long long g = want > floor_by_tiles ? want : floor_by_tiles;
     g = (g + 63) / 64 * 64;

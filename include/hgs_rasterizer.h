@@ -230,6 +230,9 @@ enum {
     HGS_STAGE_PREPROCESS_BACKWARD = 6, HGS_NUM_STAGES = 7
 };
 void hgs_profile_enable(uint32_t stage_mask);
+/* Time only every n-th launch of an enabled stage (default 1: every launch).  An event pair costs a few microseconds of
+ * GPU time around the kernel it brackets: a throughput measurement that also wants a live per-kernel figure samples. */
+void hgs_profile_set_sampling(uint32_t every_nth);
 int32_t hgs_profile_read(int32_t stage, double *total_ms, int64_t *launches);
 void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);

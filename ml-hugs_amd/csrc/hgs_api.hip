@@ -48,6 +48,8 @@ namespace {
 struct ProfState {
     std::mutex mu;
     uint32_t mask = 0;
+    uint32_t every = 1;                       // time every `every`-th launch of a stage (event pairs cost ~5 us of GPU time each)
+    uint32_t seen[HGS_NUM_STAGES] = {0};
     struct Pending { int stage; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -81,6 +83,7 @@ struct ProfScope {
     {
         if (g_prof.mask & (1u << stage)) {
             std::lock_guard<std::mutex> lk(g_prof.mu);
+            if (g_prof.seen[stage]++ % g_prof.every) return;
             a = g_prof.get();
             (void)hipEventRecord(a, st);
         }
@@ -251,7 +254,12 @@ void hgs_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.drain();
-    for (int i = 0; i < HGS_NUM_STAGES; ++i) g_prof.total_ms[i] = 0, g_prof.launches[i] = 0;
+    for (int i = 0; i < HGS_NUM_STAGES; ++i) g_prof.total_ms[i] = 0, g_prof.launches[i] = 0, g_prof.seen[i] = 0;
+}
+void hgs_profile_set_sampling(uint32_t every_nth)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.every = every_nth ? every_nth : 1;
 }
 int32_t hgs_profile_read(int32_t stage, double* total_ms, int64_t* launches)
 {

@@ -103,6 +103,8 @@ def _load():
     lib.hgs_profile_enable.argtypes = [C.c_uint32]
     lib.hgs_profile_enable.restype = None
     lib.hgs_profile_reset.restype = None
+    lib.hgs_profile_set_sampling.argtypes = [C.c_uint32]
+    lib.hgs_profile_set_sampling.restype = None
     lib.hgs_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.hgs_profile_read.restype = C.c_int32
     lib.hgs_stage_name.argtypes = [C.c_int32]
@@ -114,13 +116,14 @@ def _load():
 STAGES = ("preprocess", "scan", "emit_keys", "sort", "blend_forward", "blend_backward", "preprocess_backward")
 
 
-def profile_enable(stages=STAGES):
-    """Time the named stages with HIP events on the launch stream (empty tuple disables)."""
+def profile_enable(stages=STAGES, every_nth=1):
+    """Time the named stages with HIP events on the launch stream (empty tuple disables); every_nth > 1 samples."""
     lib = _load()
     mask = 0
     for s in stages:
         mask |= 1 << STAGES.index(s)
     lib.hgs_profile_reset()
+    lib.hgs_profile_set_sampling(every_nth)
     lib.hgs_profile_enable(mask)
 
 

@@ -206,6 +206,8 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
     __shared__ uint32_t excl[BIN_GROUP];
     __shared__ __attribute__((aligned(16))) uint16_t own[EMIT_SLOTS];
     __shared__ uint32_t wtot[NT / 64];
+    static_assert(sizeof(rec) + sizeof(excl) + sizeof(own) + sizeof(wtot) + sizeof(uint32_t) * BIN_LDS_TILES <= 160 * 1024,
+                  "emit's static LDS plus the per-tile array of the largest LDS-path frame must fit one CU's LDS");
     const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : cursor;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

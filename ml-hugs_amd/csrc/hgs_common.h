@@ -48,7 +48,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
 constexpr int BIN_GROUP = 1024;           // most Gaussians per binning workgroup (one per thread)
-constexpr int BIN_LDS_TILES = 27 * 1024;  // largest tile count whose u32 array fits LDS next to emit's 48 KB of staging
+constexpr int BIN_LDS_TILES = 22 * 1024;  // largest tile count whose u32 array fits the 160 KB of LDS next to emit's 68 KB of staging
 inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
 // Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
 // (a group = a workgroup).  A group is the unit of parallelism of both kernels, and either runs one workgroup per CU, so

@@ -757,6 +757,23 @@ def test_fused_sort_blend_reads_its_own_lists_coherently(device):
                 assert torch.equal(color, first), f"frame {rep} differs from frame 0"
 
 
+def test_largest_frame_of_the_lds_binning_path(device):
+    """2800 x 2048 has 22 400 tiles, just under the 22 528 whose per-tile array still fits LDS next to emit's staging
+    (hgs_common.h BIN_LDS_TILES): the LDS path's largest launch must work and give the oracle's list."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(P=4000, H=2048, W=2800, seed=51, D=1, sigma_px=18.0, with_culled=True)
+    sc["dL_dpix"] = None
+    ref = ho.forward(oracle_inputs(sc))
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], "22k tiles")
+
+
 def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):
     """A 4096 x 2304 image has 36 864 tiles: the binning kernels cannot keep a per-tile array in LDS and fall back
     to direct global atomics; results must not change."""

@@ -156,7 +156,8 @@ typedef struct hgs_backward_args {
 int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);
 
 /* For a frame enqueued with defer_n: N (and state->num_rendered / sparse_frame / has_long_tiles filled in), HGS_PENDING
- * when block == 0 and the frame's tile scan has not run yet, HGS_ERR_OVERFLOW (see defer_n), or another error code. */
+ * when block == 0 and the frame's tile scan has not run yet, HGS_ERR_OVERFLOW (see defer_n), or another error code.
+ * hgs_rasterize_backward refuses a state this call has not resolved (num_rendered < 0). */
 int64_t hgs_forward_poll(hgs_forward_state *state, int32_t block, void *stream);
 
 /* Replaces _C.mark_visible: present[i] = (z_view(means3D[i]) > 0.2). */

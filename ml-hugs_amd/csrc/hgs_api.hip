@@ -461,6 +461,8 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     if (f.P == 0) return HGS_OK;
     if (!a.state.geom || !a.state.image || !a.state.binning)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state is missing");
+    if (a.state.num_rendered < 0)
+        return fail(HGS_ERR_INVALID_ARGUMENT, "forward state belongs to a deferred frame that hgs_forward_poll has not resolved");
     if (!a.dL_dout_color || !a.dL_dmeans2D || !a.grad_accum || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmeans3D ||
         !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
         return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");

@@ -11,9 +11,11 @@ Same two public names, same field order / kwargs / return values / error behavio
     GaussianRasterizer.markVisible(positions) -> bool[P]
 
 All arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI of
-include/hgs_rasterizer.h (libhgs_rasterizer.so, bound here with ctypes).  There is NO CPU or
-PyTorch fallback: if the library is missing or a tensor is not on the GPU this module raises.
-PyTorch is used only for device memory, streams and autograd plumbing.
+include/hgs_rasterizer.h (libhgs_rasterizer.so).  Two bindings of that ABI live here: a C++
+autograd node (lib/_hgs_torch.so, the default when built) and a ctypes autograd.Function
+(HGS_BINDING=ctypes, and everything outside the per-frame path: deferred frames, profiling,
+markVisible).  There is NO CPU or PyTorch fallback: if the library is missing or a tensor is not
+on the GPU this module raises.  PyTorch is used only for device memory, streams and autograd plumbing.
 """
 import ctypes as C
 import os

@@ -3,6 +3,10 @@
 // buffers and a hipMalloc allocation callback, and writes the results back for tests/test_c_host.py to compare with
 // the oracle.  Built by __graft_entry__.build():  hipcc -O2 raster_host.cpp -L<lib> -lhgs_rasterizer
 //
+// use_hint = 2 adds what a frame loop does: a DEFERRED frame (defer_n) into caller-provided scratch sized by hgs_*_bytes,
+// resolved by hgs_forward_poll -- backward refused before that -- and a deferred frame with too small a capacity, which must
+// come back as HGS_ERR_OVERFLOW.
+//
 //   in.bin : int32 P, M, H, W, D, use_hint | float tanfovx, tanfovy, scale_modifier | bg[3] view[16] proj[16] campos[3]
 //            means3D[3P] shs[3MP] opacities[P] scales[3P] rotations[4P] dL_dcolor[3HW]
 //   out.bin: int64 N | color[3HW] | int32 radii[P] | dL_dmeans3D[3P] dL_dmeans2D[3P] dL_dopacity[P] dL_dsh[3MP]
@@ -105,6 +109,30 @@ int main(int argc, char** argv)
         a.binning_capacity_hint = frame == 0 ? 0 : N + N / 8 + 4096;
         N = hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream);
         if (N < 0) return fprintf(stderr, "forward: %s\n", hgs_last_error()), 3;
+    }
+    if (use_hint == 2) {
+        const int64_t cap = N + N / 8 + 4096;
+        const size_t bytes[3] = {hgs_geom_bytes(P, H, W), hgs_binning_bytes(cap, H, W), hgs_image_bytes(H, W)};
+        for (int k = 0; k < 3; ++k) {
+            a.scratch[k] = alloc_cb(nullptr, k, bytes[k]), a.scratch_bytes[k] = bytes[k];
+            if (!a.scratch[k]) return fprintf(stderr, "scratch allocation failed\n"), 2;
+        }
+        // a deferred frame with too small a capacity: enqueued without complaint, found out by the poll
+        a.defer_n = 1, a.binning_capacity_hint = N > 1 ? N / 2 : 1;
+        if (hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream) != 0 || bw.state.num_rendered != -1)
+            return fprintf(stderr, "deferred forward: %s\n", hgs_last_error()), 3;
+        if (N > 1 && hgs_forward_poll(&bw.state, 1, stream) != HGS_ERR_OVERFLOW) return fprintf(stderr, "an overflowed deferred frame was not reported\n"), 3;
+        // the real one
+        const size_t n_scratch = g_scratch.size();
+        a.binning_capacity_hint = cap;
+        if (hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream) != 0 || bw.state.num_rendered != -1)
+            return fprintf(stderr, "deferred forward: %s\n", hgs_last_error()), 3;
+        if (g_scratch.size() != n_scratch) return fprintf(stderr, "the allocation callback ran although scratch was provided\n"), 3;
+        if (hgs_rasterize_backward(&bw, stream) != HGS_ERR_INVALID_ARGUMENT) return fprintf(stderr, "backward accepted an unresolved deferred frame\n"), 3;
+        const int64_t n_deferred = hgs_forward_poll(&bw.state, 1, stream);
+        if (n_deferred != N || bw.state.num_rendered != N)
+            return fprintf(stderr, "poll: %lld, expected %lld (%s)\n", (long long)n_deferred, (long long)N, hgs_last_error()), 3;
+        if (hgs_forward_poll(&bw.state, 0, stream) != N) return fprintf(stderr, "a second poll must repeat N\n"), 3;
     }
     if (hgs_rasterize_backward(&bw, stream) < 0) return fprintf(stderr, "backward: %s\n", hgs_last_error()), 3;
     CHECK(hipStreamSynchronize(stream));

@@ -38,15 +38,15 @@ __device__ __forceinline__ SplatRect load_rect(int P, const Camera& cam, const S
             const int miny = (int)fminf((float)cam.gy, fmaxf(0.0f, (py - radf) / 16.0f));
             const int maxy = (int)fminf((float)cam.gy, fmaxf(0.0f, (py + radf + 15.0f) / 16.0f));
             r.cnt = (uint32_t)((maxx - minx) * (maxy - miny));
-            r.x = px, r.y = py, r.A = head.z, r.B = head.w;
+            r.x = px, r.y = py;
             r.minx = minx, r.miny = miny, r.width = maxx - minx;
             r.depth_bits = __float_as_uint(tail.y);
             if (with_mask_inputs) {
-                const float4 mid = reinterpret_cast<const float4*>(splats + g)[1];
-                r.C = mid.x;
+                const float4 hc = reinterpret_cast<const float4*>(splats + g)[3];  // (ca, cb, cc, L): the half-conic quarter
+                r.A = hc.x, r.B = hc.y, r.C = hc.z;
                 // log2 domain (hgs_common.h): contributes iff exp2(power + L) >= 1/255  <=>  power >= -(log2 255 + L);
                 // 0.07 of slack covers the blend kernels' rounding (and makes the mask a strict superset)
-                r.thr = -(7.9943534f + mid.y) - 0.07f;
+                r.thr = -(7.9943534f + hc.w) - 0.07f;
             }
         }
     }

@@ -118,15 +118,20 @@ struct PixBwd {
 
 // Adds pixel `p`'s contribution for splat `s` (list position pos1) to the lane-private partial sums v[9]; returns the
 // lanes that took the splat (a scalar mask -- no per-lane "contributed" flag to carry).
-// (dy, bdy = B dy, q = C dy^2 + L: the row terms of log2_alpha, shared by the two quads of a tile row)
+// (dy, bdy = B dy, q = L - (C dy)^2: the row terms of log2_alpha, shared by the two quads of a tile row)
 __device__ __forceinline__ unsigned long long bwd_pixel(const SplatRec& s, uint32_t pos1, PixBwd& p, float dy, float bdy,
                                                         float q, float (&v)[9])
 {
     const float dx = s.x - p.pxf;
-    const float e = __builtin_fmaf(dx, __builtin_fmaf(s.A, dx, bdy), q);  // == log2_alpha(s, dx, dy), same rounding
+    const float t = __builtin_fmaf(s.A, dx, bdy);
+    const float e = __builtin_fmaf(-t, t, q);  // == log2_alpha(s, dx, dy), same rounding; e <= L by construction
     const float alpha_uncapped = __builtin_amdgcn_exp2f(e);  // = opacity * G
     const float alpha = fminf(ALPHA_MAX, alpha_uncapped);
-    const bool act_lane = pos1 <= p.last_contributor && e <= s.L && alpha >= ALPHA_MIN;
+    // (ONE final compare -- of an alpha zeroed where the pixel has not been reached yet -- so that the ballot below is that
+    //  compare's own SGPR result; the ballot of an AND of compares is materialised with a v_cndmask + v_cmp_ne pair)
+    float alpha_if_reached = pos1 <= p.last_contributor ? alpha : 0.0f;
+    asm("" : "+v"(alpha_if_reached));  // (opaque: otherwise the optimiser folds the select back into the AND)
+    const bool act_lane = alpha_if_reached >= ALPHA_MIN;
     const unsigned long long took = __builtin_amdgcn_ballot_w64(act_lane);
     // (a branch-free body -- alphas forced to 0 for lanes that do not take the splat -- and a first-quad-assigns variant
     //  that spares the zero fill of v[] were both measured: equal or slower, the exec-masked region stays)
@@ -248,12 +253,12 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (((val >> (GID_BITS + 2 * r)) & 3u) == 0u) continue;
-                const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
+                const float dy = s.y - p[2 * r].pyf, bdy = s.B * dy, cdy = s.C * dy, q = __builtin_fmaf(-cdy, cdy, s.L);
                 if ((val >> (GID_BITS + 2 * r)) & 1u) took |= bwd_pixel(s, pos1, p[2 * r], dy, bdy, q, v);
                 if ((val >> (GID_BITS + 2 * r + 1)) & 1u) took |= bwd_pixel(s, pos1, p[2 * r + 1], dy, bdy, q, v);
             }
         } else {  // every entry of a quad's list covers the quad
-            const float dy = s.y - p[0].pyf, bdy = s.B * dy, q = __builtin_fmaf(s.C * dy, dy, s.L);
+            const float dy = s.y - p[0].pyf, bdy = s.B * dy, cdy = s.C * dy, q = __builtin_fmaf(-cdy, cdy, s.L);
             took = bwd_pixel(s, pos1, p[0], dy, bdy, q, v);
         }
         if (took == 0ull) return;

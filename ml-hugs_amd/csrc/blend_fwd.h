@@ -13,8 +13,8 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
 typedef const __attribute__((address_space(4))) uint64_t* const_u64p;
 typedef const __attribute__((address_space(4))) v2u* const_u2p;
 
-struct SplatRec {  // wave-uniform (lives in SGPRs); log2 domain: alpha = exp2(A dx^2 + B dx dy + C dy^2 + L)
-    float x, y, A, B, C, L, r, g, b;
+struct SplatRec {  // wave-uniform (lives in SGPRs); log2 domain: alpha = exp2(L - (A dx + B dy)^2 - (C dy)^2),
+    float x, y, A, B, C, L, r, g, b;  // (A, B, C) = the conic's Cholesky factors (la, lb, lc) of hgs_common.h
 };
 
 // `entry_low` = low word of a list entry (mask << 28 | gaussian); the index is clamped because the software
@@ -33,12 +33,12 @@ __device__ __forceinline__ SplatRec load_rec(const Splat* splats, uint32_t entry
     return s;
 }
 
-// log2 of the uncapped alpha: (A dx^2 + B dx dy + C dy^2) + L, five VALU ops
+// log2 of the uncapped alpha: L - (A dx + B dy)^2 - (C dy)^2, five VALU ops; never above L (hgs_common.h)
 __device__ __forceinline__ float log2_alpha(const SplatRec& s, float dx, float dy)
 {
-    float t = __builtin_fmaf(s.A, dx, s.B * dy);
-    float u = s.C * dy;
-    return __builtin_fmaf(dx, t, __builtin_fmaf(u, dy, s.L));
+    const float t = __builtin_fmaf(s.A, dx, s.B * dy);
+    const float u = s.C * dy;
+    return __builtin_fmaf(-t, t, __builtin_fmaf(-u, u, s.L));
 }
 
 // Tile order: workgroup / wave id == tile id.  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
@@ -65,7 +65,7 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
     const float dx = s.x - pxf, dy = s.y - pyf;
     const float e = log2_alpha(s, dx, dy);
     const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(e));
-    const bool ok = e <= s.L && alpha >= ALPHA_MIN;  // e <= L: the exponent of the Gaussian is not positive
+    const bool ok = alpha >= ALPHA_MIN;  // (the reference's `power > 0` test cannot fire: e <= L by construction)
     const float test_T = T * (1.0f - alpha);
     const bool upd = ok && test_T >= T_STOP;
     const float wgt = upd ? alpha * T : 0.0f;

@@ -26,15 +26,24 @@ constexpr uint32_t GID_MASK = (1u << GID_BITS) - 1u;
 // which waits on the scalar cache a quarter of its time, runs ~10 % faster with one line per record.)
 struct alignas(64) Splat {
     float x, y;        // pixel-space mean
-    // The blend kernels work in the log2 domain: alpha = exp2(A dx^2 + B dx dy + C dy^2 + L), one v_exp_f32 with no
-    // multiply before or after.  (A,B,C) = fl(LOG2E * (-conic.xx/2, -conic.xy, -conic.yy/2)); L = log2(opacity).
-    float ca, cb, cc;
+    // The blend kernels work in the log2 domain: alpha = exp2(e), one v_exp_f32 with no multiply before or after, and
+    // evaluate the exponent through the conic's Cholesky factors,
+    //     e = L - (la dx + lb dy)^2 - (lc dy)^2,     L = log2(opacity),
+    // la = sqrt(A'), lb = B' / (2 la), lc = sqrt(C' - lb^2) for (A', B', C') = fl(LOG2E * (conic.xx/2, conic.xy, conic.yy/2)):
+    // the same five instructions as A dx^2 + B dx dy + C dy^2 + L, but e <= L holds in floating point BY CONSTRUCTION
+    // (two squares are subtracted, rounding is monotonic), so the reference's `if (power > 0) continue` can never fire and
+    // the blend kernels do not test it -- one compare less per pixel and list entry in both of them.
+    float la, lb, lc;
     float log2_opacity;
     float r, g, b;     // view-dependent colour after +0.5 / clamp
     float depth;       // view-space z; its raw bits are the low half of the sort key
     int32_t radius;    // 0 => culled
     uint32_t clamped;  // bit c set => colour channel c was clamped at 0
-    uint32_t pad[4];
+    // fourth 16-byte quarter (not fetched by the blend kernels): the half-conic itself, (ca, cb, cc) = fl(LOG2E *
+    // (-conic.xx/2, -conic.xy, -conic.yy/2)), for emit's coverage masks and the per-Gaussian backward; and L again, so that
+    // emit needs three quarters of the record, not four
+    float ca, cb, cc;
+    float log2_opacity_again;
 };
 static_assert(sizeof(Splat) == 64, "Splat layout");
 

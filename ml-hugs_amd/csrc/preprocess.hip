@@ -155,7 +155,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     }
 
     Splat out;
-    out.x = out.y = out.ca = out.cb = out.cc = out.log2_opacity = out.r = out.g = out.b = out.depth = 0.0f;
+    out.x = out.y = out.la = out.lb = out.lc = out.ca = out.cb = out.cc = out.log2_opacity = out.r = out.g = out.b = out.depth = 0.0f;
     out.radius = 0;
     out.clamped = 0;
     uint32_t touched = 0;
@@ -211,6 +211,11 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                     out.ca = (-0.5f * (e.c * det_inv)) * LOG2E;
                     out.cb = (-(-e.b * det_inv)) * LOG2E;
                     out.cc = (-0.5f * (e.a * det_inv)) * LOG2E;
+                    // ... and its Cholesky factors for the blend kernels (hgs_common.h): with A' = -ca etc.,
+                    // C' - lb^2 = (A'C' - B'^2/4) / A' = (LOG2E/2)^2 / (det A') = (LOG2E/2) / cov2D.yy -- no cancellation
+                    out.la = sqrtf(-out.ca);
+                    out.lb = (-0.5f * out.cb) / out.la;
+                    out.lc = sqrtf((0.5f * LOG2E) / e.c);
                     out.log2_opacity = __log2f(opacities[i]);
                     out.depth = pv[2];
                     out.radius = (int32_t)radf;
@@ -243,14 +248,15 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
             }
         }
         if (!alive) {
-            out.x = out.y = out.ca = out.cb = out.cc = out.log2_opacity = out.depth = 0.0f;
+            out.x = out.y = out.la = out.lb = out.lc = out.ca = out.cb = out.cc = out.log2_opacity = out.depth = 0.0f;
             out.radius = 0;
             touched = 0;
         }
         float4* dst = reinterpret_cast<float4*>(splats + i);
-        dst[0] = make_float4(out.x, out.y, out.ca, out.cb);
-        dst[1] = make_float4(out.cc, out.log2_opacity, out.r, out.g);
+        dst[0] = make_float4(out.x, out.y, out.la, out.lb);
+        dst[1] = make_float4(out.lc, out.log2_opacity, out.r, out.g);
         dst[2] = make_float4(out.b, out.depth, __int_as_float(out.radius), __uint_as_float(out.clamped));
+        dst[3] = make_float4(out.ca, out.cb, out.cc, out.log2_opacity);
         tiles_touched[i] = touched;
         radii[i] = out.radius;
     }
@@ -321,10 +327,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
     float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
     const float acc_b = grad_accum[12 * (size_t)i + 8];
     {
-        const float4 h0 = reinterpret_cast<const float4*>(splats + i)[0];
-        const float4 h1 = reinterpret_cast<const float4*>(splats + i)[1];
+        const float4 hc = reinterpret_cast<const float4*>(splats + i)[3];   // the half-conic quarter of the record
         const bool live = __float_as_int(reinterpret_cast<const float4*>(splats + i)[2].z) > 0;  // else: record unset
-        const float A = live ? h0.z * LN2 : 0.0f, B = live ? h0.w * LN2 : 0.0f, C = live ? h1.x * LN2 : 0.0f;
+        const float A = live ? hc.x * LN2 : 0.0f, B = live ? hc.y * LN2 : 0.0f, C = live ? hc.z * LN2 : 0.0f;
         const float op = live ? opacities[i] : 0.0f;
         const float sx = acc0.x, sy = acc0.y;
         acc0.x = (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);

@@ -648,7 +648,7 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         return buf[o:o + nbytes].view(dtype)
 
     if P > 0:
-        holder["splats"] = sub(geom, "splats", 64 * P, torch.float32).view(P, 16)[:, :12].contiguous()
+        holder["splats"] = sub(geom, "splats", 64 * P, torch.float32).view(P, 16).contiguous()   # 64-byte records (hgs_common.h)
         holder["tiles_touched"] = sub(geom, "tiles_touched", 4 * P, torch.int32)
         holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
         holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W) & 0x0FFFFFFF  # top bits: clamp mask

@@ -104,9 +104,9 @@ def test_forward_stages_and_image(name, device):
     # in place of the opacity (v_log_f32: ~1 ulp, the one field that is not bit-exact)
     half, log2e = np.float32(-0.5), np.float32(1.4426950408889634)
     for col, (refarr, label) in {0: (ref["xy"][:, 0], "x"), 1: (ref["xy"][:, 1], "y"),
-                                 2: (half * ref["conic_opacity"][:, 0] * log2e, "conic.x"),
-                                 3: (-ref["conic_opacity"][:, 1] * log2e, "conic.y"),
-                                 4: (half * ref["conic_opacity"][:, 2] * log2e, "conic.z"),
+                                 12: (half * ref["conic_opacity"][:, 0] * log2e, "conic.x"),
+                                 13: (-ref["conic_opacity"][:, 1] * log2e, "conic.y"),
+                                 14: (half * ref["conic_opacity"][:, 2] * log2e, "conic.z"),
                                  6: (ref["rgb"][:, 0], "r"), 7: (ref["rgb"][:, 1], "g"), 8: (ref["rgb"][:, 2], "b"),
                                  9: (ref["depths"], "depth")}.items():
         assert refarr.dtype == np.float32
@@ -114,6 +114,14 @@ def test_forward_stages_and_image(name, device):
         assert np.array_equal(a, b), f"{name}: splat field {label} not bit-exact ({(a != b).sum()} of {vis.sum()})"
     l2 = np.log2(ref["conic_opacity"][vis, 3].astype(np.float64))
     assert np.abs(sp[vis, 5] - l2).max() <= 4e-7 * np.maximum(1.0, np.abs(l2)).max(), f"{name}: log2(opacity)"
+    assert np.array_equal(sp[vis, 15].view(np.uint32), sp[vis, 5].view(np.uint32))
+    # what the blend kernels evaluate is that conic's Cholesky form, L - (la dx + lb dy)^2 - (lc dy)^2 (columns 2..4):
+    # it must reproduce the half-conic, A' = la^2, B' = 2 la lb, C' = lb^2 + lc^2, to fp32 rounding of a sqrt and a divide
+    la, lb, lc = (sp[vis, k].astype(np.float64) for k in (2, 3, 4))
+    Ap, Bp, Cp = (-sp[vis, k].astype(np.float64) for k in (12, 13, 14))
+    assert (la > 0).all() and (lc > 0).all()
+    for got, want, label in ((la * la, Ap, "A'"), (2 * la * lb, Bp, "B'"), (lb * lb + lc * lc, Cp, "C'")):
+        assert (np.abs(got - want) <= 1e-6 * np.maximum(np.abs(want), np.sqrt(Ap * Cp))).all(), f"{name}: Cholesky form, {label}"
     clamp_bits = ref["clamped"][:, 0] | (ref["clamped"][:, 1] << 1) | (ref["clamped"][:, 2] << 2)
     assert np.array_equal(sp[vis, 11].view(np.uint32), clamp_bits[vis].astype(np.uint32))
     # ---- K2..K5 exact

@@ -71,7 +71,8 @@ def check_image(gpu, ref, what):
     d = np.abs(gpu.astype(np.float64) - ref.astype(np.float64))
     assert d.max() <= COLOR_OUTLIER_TOL, f"{what}: max |d| = {d.max():.3e}"
     frac = float((d <= COLOR_TOL).mean())
-    assert frac >= COLOR_INLIER_FRAC or (d > COLOR_TOL).sum() <= 2, f"{what}: only {frac:.6f} within {COLOR_TOL}"
+    flipped = int(((d > COLOR_TOL).any(axis=0) if d.ndim == 3 else (d > COLOR_TOL)).sum())   # PIXELS (all channels of one count once)
+    assert frac >= COLOR_INLIER_FRAC or flipped <= 2, f"{what}: only {frac:.6f} within {COLOR_TOL} ({flipped} pixels outside)"
     assert d.mean() <= COLOR_MEAN_TOL, f"{what}: mean |d| = {d.mean():.3e}"
 
 

@@ -15,7 +15,7 @@ import torch
 
 from oracle import hgs_oracle as ho
 from scenes import make_scene, oracle_inputs
-from test_gpu_parity import COLOR_TOL, GRAD_REL_TOL, check_image, rel_l2, run_gpu, to_dev
+from test_gpu_parity import COLOR_TOL, GRAD_REL_TOL, _stacked_scene, check_image, rel_l2, run_gpu, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -40,9 +40,14 @@ def test_random_scenes_match_the_oracle(device):
     rng = np.random.default_rng(int(os.environ.get("HGS_FUZZ_SEED", "0")))
     n_scenes = int(os.environ.get("HGS_FUZZ_SCENES", "48"))
     for k in range(n_scenes):
-        kw = draw(rng)
+        if rng.random() < 0.06:   # a pile of small Gaussians over a few tiles: lists of 1k..10k entries (the long-list sort paths)
+            kw = dict(P=int(rng.integers(1200, 9000)), H=int(rng.integers(40, 150)), W=int(rng.integers(40, 150)),
+                      seed=int(rng.integers(0, 1 << 20)), spread_px=float(rng.uniform(3.0, 20.0)))
+            sc = _stacked_scene(**kw)
+        else:
+            kw = draw(rng)
+            sc = make_scene(**kw)
         what = f"scene {k}: {kw}"
-        sc = make_scene(**kw)
         inp = oracle_inputs(sc)
         ref = ho.forward(inp)
         ref_g = ho.backward(inp, ref, sc["dL_dpix"])

@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--cluster", type=float, default=0.0, help="fraction of the Gaussians in a central blob (not the headline workload)")
+    ap.add_argument("--spatial-order", action="store_true", help="store the Gaussians in 3-D Morton order (not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-frames-in-flight figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
@@ -183,6 +184,10 @@ def main():
     P, H, W, D = args.gaussians, args.height, args.width, args.sh_degree
     cam0 = syn.pinhole_camera(H, W)
     g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0, cluster=args.cluster)
+    if args.spatial_order:   # not the headline workload: the same Gaussians stored in 3-D Morton order
+        from hugs_amd.spatial import morton_order
+        order = morton_order(g["means3D"])
+        g = {k: (v[order] if isinstance(v, np.ndarray) and v.shape[:1] == (P,) else v) for k, v in g.items()}
     # frame r of the batch: the same scene seen from a slightly yawed camera (frame 0 = identity pose)
     yaw = math.radians(1.5) * rank
     w2c = np.eye(4)

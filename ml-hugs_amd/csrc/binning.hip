@@ -51,13 +51,15 @@ constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
 
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total, uint32_t* __restrict__ large_tiles,
-                 uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
+tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
+                 uint2* __restrict__ ranges, uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total,
+                 uint32_t* __restrict__ large_tiles, uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t n_large, n_nonempty;
     if (threadIdx.x == 0) n_large = 0, n_nonempty = 0;
+    // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
+    for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
@@ -135,12 +137,12 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint2* __rest
     }
 }
 
-void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
+void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
                       hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, ranges, cursor, n_total,
-                       large_tiles, capacity, host_slot, ticket);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
+                       ranges, cursor, n_total, large_tiles, capacity, host_slot, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +172,114 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
     return (x_in && y_in) ? 0.0f : best;
 }
 
-// count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise the preprocess kernel counts):
+// ---------------------------------------------------------------------------------------------
+// Spatially coherent binning groups (the LDS binning path).  The preprocess kernel has counting-sorted the Gaussians by
+// binning cell up to the last step: cell_count[c] = population of cell c, cell_slot[i] = (cell, slot inside the cell).
+// cell_scatter: every workgroup prefix-sums the (<= BIN_MAX_CELLS) populations for itself and writes its Gaussians'
+// indices to order[start(cell) + slot]; the total -- the Gaussians that touch a tile at all -- goes to windows[groups].x.
+__global__ void __launch_bounds__(256)
+cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_count, const uint2* __restrict__ cell_slot,
+                    uint32_t* __restrict__ order, uint4* __restrict__ total_out)
+{
+    __shared__ uint32_t start[BIN_MAX_CELLS];
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int PER = BIN_MAX_CELLS / 256;  // consecutive cells per thread
+    uint32_t c[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) c[k] = tid * PER + k < num_cells ? cell_count[tid * PER + k] : 0u, mine += c[k];
+    const uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t v = wsum[k];
+        if (k < w) before += v;
+        total += v;
+    }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) start[tid * PER + k] = run, run += c[k];
+    if (blockIdx.x == 0 && tid == 0) *total_out = make_uint4(total, 0u, 0u, 0u);
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i < P) {
+        const uint2 cs = cell_slot[i];
+        if (cs.x != 0xFFFFFFFFu) order[start[cs.x] + cs.y] = (uint32_t)i;
+    }
+}
+
+// group_count: workgroup g owns entries [g G, (g + 1) G) of `order` -- Gaussians of one cell or of neighbouring cells.  It
+// finds the tile window their rectangles span, counts the group's pairs per tile of the window in LDS, takes ONE returning
+// atomic per touched tile on the global per-tile counters -- the value returned is where this group's run starts inside
+// the tile's segment -- and leaves it in run_start[g][tile] for emit, which shares the partition.
+__global__ void __launch_bounds__(BIN_GROUP)
+group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ order,
+                   uint4* __restrict__ windows, int groups, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start)
+{
+    extern __shared__ uint32_t hist[];  // [num_tiles], only the window is used
+    __shared__ int win[4];              // min x, min y, max x (exclusive), max y (exclusive), in tiles
+    const int NT = (int)blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_alive = windows[groups].x;
+    const uint32_t first = (uint32_t)blockIdx.x * (uint32_t)G;
+    if (first >= n_alive) {  // (uniform) nothing left for this group
+        if (tid == 0) windows[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    if (tid == 0) win[0] = win[1] = 0x7FFFFFFF, win[2] = win[3] = 0;
+    SplatRect mine = load_rect(P, cam, splats, first + (uint32_t)tid < n_alive ? (int)order[first + tid] : P, false);
+    // the window: wave-level min / max, then one LDS atomic per wave and bound
+    int lo_x = mine.cnt ? mine.minx : 0x7FFFFFFF, lo_y = mine.cnt ? mine.miny : 0x7FFFFFFF;
+    int hi_x = mine.cnt ? mine.minx + mine.width : 0, hi_y = mine.cnt ? mine.miny + (int)(mine.cnt / (uint32_t)mine.width) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo_x = min(lo_x, __shfl_xor(lo_x, d, 64)), lo_y = min(lo_y, __shfl_xor(lo_y, d, 64));
+        hi_x = max(hi_x, __shfl_xor(hi_x, d, 64)), hi_y = max(hi_y, __shfl_xor(hi_y, d, 64));
+    }
+    __syncthreads();  // win initialised
+    if (lane == 0 && hi_x > lo_x) atomicMin(&win[0], lo_x), atomicMin(&win[1], lo_y), atomicMax(&win[2], hi_x), atomicMax(&win[3], hi_y);
+    __syncthreads();
+    const int wx0 = win[0], wy0 = win[1], ww = win[2] - win[0], wh = win[3] - win[1];
+    const int n_win = ww * wh;  // (> 0: every Gaussian in `order` touches a tile)
+    const float inv_ww = 1.0f / (float)ww;
+    // tile of window index k: row = k / ww exactly (k < 2^22, see emit) without an integer divide
+    auto tile_of = [&](int k) { const int r = (int)(((float)k + 0.5f) * inv_ww); return (wy0 + r) * cam.gx + wx0 + (k - r * ww); };
+    for (int k = tid; k < n_win; k += NT) hist[tile_of(k)] = 0;
+    __syncthreads();
+    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
+    __syncthreads();
+    // eight tiles per thread and round: the returning atomics of a round are all in flight together
+    uint32_t* my_runs = run_start + (size_t)blockIdx.x * (size_t)(cam.gx * cam.gy);
+    for (int k0 = tid; k0 < n_win; k0 += 8 * NT) {
+        uint32_t c[8], base[8];
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * NT;
+            t[u] = k < n_win ? tile_of(k) : 0;
+            c[u] = k < n_win ? hist[t[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&tile_count[t[u]], c[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c[u]) my_runs[t[u]] = base[u];
+    }
+    if (tid == 0) windows[blockIdx.x] = make_uint4((uint32_t)wx0, (uint32_t)wy0, (uint32_t)ww, (uint32_t)wh);
+}
+
+void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
+                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st)
+{
+    const int groups = (P + group - 1) / group;
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, num_cells_of(cam.gx, cam.gy), cell_count,
+                       cell_slot, order, windows + groups);
+    hipLaunchKernelGGL(group_count_kernel, dim3(groups), dim3(group), sizeof(uint32_t) * cam.gx * cam.gy, st, P, group, cam, splats,
+                       order, windows, groups, tile_count, run_start);
+}
+
+// count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise group_count_kernel counts):
 // tile_count[t] += number of Gaussians touching tile t, global atomics
 __global__ void __launch_bounds__(BIN_THREADS)
 count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ tile_count)
@@ -197,9 +306,19 @@ constexpr int EMIT_SLOTS = 8192;  // pair slots dealt per round (LDS: 2 bytes ea
 template <bool USE_LDS>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
-            const uint32_t* __restrict__ run_start, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
+            const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
+            int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
 {
     if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
+    // BIN_BY_CELL (order != nullptr): the group is a run of `order` and spans a window of tiles; BIN_IN_ORDER: consecutive
+    // Gaussians, the whole grid
+    uint4 window = make_uint4(0u, 0u, (uint32_t)cam.gx, (uint32_t)cam.gy);
+    uint32_t n_alive = 0;
+    if (USE_LDS && order) {
+        window = windows[blockIdx.x];
+        if (window.z == 0u) return;  // the group is empty
+        n_alive = windows[groups].x;
+    }
     constexpr int NT = EMIT_THREADS, PER = EMIT_SLOTS / NT;
     extern __shared__ uint32_t hist[];
     __shared__ float4 rec[BIN_GROUP][3];
@@ -214,12 +333,21 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
     const int g0 = blockIdx.x * G;
     SplatRect mine;
     mine.cnt = 0;
-    if (tid < G) mine = load_rect(P, cam, splats, g0 + tid, true);  // (g0 + tid >= P: an empty rectangle)
+    // the group's Gaussians: entries of `order` (LDS path: neighbours on screen), else consecutive indices
+    int gid = P;
+    if (tid < G) gid = (USE_LDS && order) ? ((uint32_t)(g0 + tid) < n_alive ? (int)order[g0 + tid] : P) : g0 + tid;
+    if (tid < G) mine = load_rect(P, cam, splats, gid, true);  // (gid >= P: an empty rectangle)
     if (USE_LDS) {
-        // this group's cursor into every tile segment (entries of tiles the group does not touch are never used, and
-        // run_start holds nothing meaningful for them)
+        // this group's cursor into the tile segments of its window (entries of tiles the group does not touch are never
+        // used, and run_start holds nothing meaningful for them)
         const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
-        for (int t = tid; t < num_tiles; t += NT) hist[t] = cursor[t] + my_runs[t];
+        const int ww = (int)window.z, n_win = ww * (int)window.w;
+        const float inv_ww = 1.0f / (float)ww;
+        for (int k = tid; k < n_win; k += NT) {
+            const int r = (int)(((float)k + 0.5f) * inv_ww);  // k / ww, exactly (k < 2^22)
+            const int t = ((int)window.y + r) * cam.gx + (int)window.x + (k - r * ww);
+            hist[t] = cursor[t] + my_runs[t];
+        }
     }
     // exclusive prefix sum of the pair counts over the group
     const uint32_t incl = wave_inclusive_scan(mine.cnt);
@@ -237,7 +365,7 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
         excl[tid] = first;
         rec[tid][0] = make_float4(mine.x, mine.y, mine.A, mine.B);
         rec[tid][1] = make_float4(mine.C, mine.thr, __uint_as_float(mine.depth_bits), 1.0f / (float)mine.width);
-        rec[tid][2] = make_float4(__int_as_float(mine.minx), __int_as_float(mine.miny), __int_as_float(mine.width), 0.f);
+        rec[tid][2] = make_float4(__int_as_float(mine.minx), __int_as_float(mine.miny), __int_as_float(mine.width), __int_as_float(gid));
     }
     for (uint32_t base = 0; base < total; base += EMIT_SLOTS) {
         // owner of every slot of this round: scatter (index + 1) at each Gaussian's first slot, then fill forward (the
@@ -295,7 +423,7 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
             }
             const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
             // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
-            keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)(g0 + (int)o) << 4) | mask);
+            keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)__float_as_int(c.w) << 4) | mask);
         }
     }
 }
@@ -305,15 +433,15 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
     hipLaunchKernelGGL(count_kernel, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(BIN_THREADS), 0, st, P, cam, splats, tile_count);
 }
 
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, int group,
-                 uint64_t* keys, const uint32_t* gate, hipStream_t st)
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
+                 const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st)
 {
     if (group)
         hipLaunchKernelGGL(emit_kernel<true>, dim3((P + group - 1) / group), dim3(EMIT_THREADS), sizeof(uint32_t) * cam.gx * cam.gy, st,
-                           P, group, cam, splats, cursor, run_start, keys, gate);
+                           P, group, cam, splats, cursor, run_start, order, windows, (P + group - 1) / group, keys, gate);
     else
         hipLaunchKernelGGL(emit_kernel<false>, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(EMIT_THREADS), 0, st, P, BIN_GROUP, cam, splats,
-                           cursor, nullptr, keys, gate);
+                           cursor, nullptr, nullptr, nullptr, 0, keys, gate);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -327,17 +327,28 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
     // the preprocess kernel counts pairs per tile itself when the tile array fits LDS (any frame up to ~7 Mpixel)
     const int group = bin_group_for(a.P, num_tiles);
+    const int num_cells = num_cells_of(cam.gx, cam.gy);
     uint32_t* run_start = group ? (uint32_t*)(geom + gl.run_start) : nullptr;
+    uint2* cell_slot = (uint2*)(geom + gl.cell_slot);
+    uint32_t* order = (uint32_t*)(geom + gl.order);
+    uint4* windows = (uint4*)(geom + gl.windows);
     uint2* ranges = (uint2*)(image + il.ranges);
     uint32_t* cursor = (uint32_t*)(image + il.cursor);
     uint32_t* n_total = (uint32_t*)(image + il.n_total);
     uint32_t* large_tiles = (uint32_t*)(image + il.large_tiles);
     uint32_t* tile_count = nullptr;
     size_t tc_index = 0;
-    if (int rc = acquire_tile_counters(st, (size_t)num_tiles, &tile_count, &tc_index)) return rc;
+    // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
+    const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
+    if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_index)) return rc;
+    int bin_mode = bin_mode_for(a.P, num_tiles, group);
+    // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
+    if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr) bin_mode = e[0] == 'c' ? BIN_BY_CELL : e[0] == 'o' ? BIN_IN_ORDER : bin_mode;
+    uint32_t* cell_count = bin_mode == BIN_BY_CELL ? tile_count + cell_counters_at : nullptr;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
-      launch_preprocess(a, cam, splats, tiles_touched, tile_count, run_start, group, st); }
+      launch_preprocess(a, cam, splats, tiles_touched, bin_mode, bin_mode == BIN_BY_CELL ? cell_count : tile_count, cell_slot, run_start,
+                        group, st); }
     STAGE_CHECK(dbg, st, "preprocess");
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
@@ -345,8 +356,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
-      if (!group) launch_count(a.P, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, ranges, cursor, n_total, large_tiles, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
+      if (bin_mode == BIN_BY_CELL) launch_spatial_groups(a.P, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
+      else if (bin_mode == BIN_NONE) launch_count(a.P, cam, splats, tile_count, st);
+      launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, cap32,
+                       (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
     tile_counters_clean(tc_index);  // the scan, which re-zeroes them, is enqueued
 
@@ -382,7 +395,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, group, keys, gate, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total,

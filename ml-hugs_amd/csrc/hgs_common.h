@@ -59,6 +59,20 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 constexpr int BIN_GROUP = 1024;           // most Gaussians per binning workgroup (one per thread)
 constexpr int BIN_LDS_TILES = 22 * 1024;  // largest tile count whose u32 array fits the 160 KB of LDS next to emit's 68 KB of staging
 inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
+// Binning cells: BIN_CELL x BIN_CELL tiles.  The Gaussians are counting-sorted by the cell of their rectangle's first
+// tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
+enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binning groups (preprocess.hip, binning.hip)
+// BIN_BY_CELL costs two more launches (scatter, group count) and saves the per-group passes over all tiles plus most of the
+// atomics and partial-line key stores: it pays on frames with many Gaussians AND many tiles.  (Measured: 200k / 1080p +1.4 %,
+// 310k / 1080p +2 %; 110k at 512x512 -2.7 %, the 6 890-Gaussian SMPL template at 512x512 -7.5 %.)
+inline int bin_mode_for(int P, int num_tiles, int group)
+{
+    if (!group) return BIN_NONE;
+    return (P >= 65536 && num_tiles >= 4096) ? BIN_BY_CELL : BIN_IN_ORDER;
+}
+constexpr int BIN_CELL = 4;
+constexpr int BIN_MAX_CELLS = 2048;       // >= cells of the largest LDS-path frame (BIN_LDS_TILES / 16, plus ragged edges)
+inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL); }
 // Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
 // (a group = a workgroup).  A group is the unit of parallelism of both kernels, and either runs one workgroup per CU, so
 // the groups should just fill the 256 CUs in one round: ~250 groups when P allows it (200 000 Gaussians: 241 groups of
@@ -79,16 +93,24 @@ inline int bin_group_for(int P, int num_tiles)
     return (int)(g < 64 ? 64 : (g > BIN_GROUP ? BIN_GROUP : g));
 }
 struct GeomLayout {
-    size_t splats, tiles_touched, run_start, total;
+    size_t splats, tiles_touched, cell_slot, order, windows, run_start, total;
     GeomLayout(int P, int num_tiles) {
         size_t o = 0;
         splats = o;         o = align_up(o + sizeof(Splat) * (size_t)P);
         tiles_touched = o;  o = align_up(o + 4 * (size_t)P);
-        // run_start[group][tile]: where, inside the tile's segment, the run of binning group `group` (BIN_GROUP
-        // consecutive Gaussians) begins -- handed out by the preprocess kernel's returning atomics, consumed by emit.
-        // Only (group, tile) pairs with at least one entry are ever written or read.
-        run_start = o;
-        if (const int g = bin_group_for(P, num_tiles)) o = align_up(o + 4 * (size_t)((P + g - 1) / g) * (size_t)num_tiles);
+        cell_slot = order = windows = run_start = o;
+        if (const int g = bin_group_for(P, num_tiles)) {
+            const size_t groups = (size_t)((P + g - 1) / g);
+            cell_slot = o;  o = align_up(o + 8 * (size_t)P);   // uint2 per Gaussian: its binning cell, its slot inside the cell
+            order = o;      o = align_up(o + 4 * (size_t)P);   // the Gaussians that touch a tile, sorted by cell
+            // uint4 per binning group: the tile window (x0, y0, width, height) its rectangles span; then one more whose .x
+            // is the number of Gaussians in `order`
+            windows = o;    o = align_up(o + 16 * (groups + 1));
+            // run_start[group][tile]: where, inside the tile's segment, the run of binning group `group` begins -- handed
+            // out by the group-count kernel's returning atomics, consumed by emit.  Only (group, tile) pairs with at
+            // least one entry are ever written or read.
+            run_start = o;  o = align_up(o + 4 * groups * (size_t)num_tiles);
+        }
         total = o;
     }
 };
@@ -130,21 +152,26 @@ struct BinningLayout {
 // kernels / launchers (defined in the .hip files)
 void set_last_error(const char* msg);  // hgs_api.hip
 
-// tile_count: ZERO on entry (hgs_api.hip keeps a self-cleaning counter array per stream).  group = bin_group_for() != 0: the
-// kernel also counts the (Gaussian, tile) pairs per tile (LDS histogram per BIN_GROUP Gaussians, one returning atomic per
-// touched tile) and records every group's run offsets in run_start; 0: count_kernel does the counting (very large tile counts).
-void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
+// mode = bin_mode_for(): what the kernel does for the binning besides its own work (see preprocess.hip).  `counters`: the
+// per-cell (BIN_BY_CELL) or per-tile (BIN_IN_ORDER) counters, ZERO on entry (hgs_api.hip keeps self-cleaning counter
+// arrays per stream).
+void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched, int mode,
+                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st);
-// (re-zeroes tile_count behind itself)
-void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
-                      uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
+// BIN_BY_CELL, between the preprocess kernel and the tile scan: `order` (the Gaussians sorted by cell), then per
+// binning group (`group` consecutive entries of `order`) the tile window, the per-tile pair counts (added to tile_count with
+// one returning atomic per touched tile) and the group's run offsets
+void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
+                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
+// (re-zeroes tile_count, and cell_count if given, behind itself)
+void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
                       hipStream_t st);
-void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, int group,
-                 uint64_t* keys, const uint32_t* gate, hipStream_t st);
+void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
+                 const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 // fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
 struct FusedBlend {

@@ -124,27 +124,37 @@ __device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one thread per Gaussian.  FUSED_COUNT: the workgroup (a binning group, bin_group_for()) also counts its (Gaussian, tile)
-// pairs per tile in an LDS histogram while the rectangles are still in registers, takes ONE returning atomic per touched
-// tile on the global per-tile counters -- the value returned is where this group's run starts inside the tile's segment
-// -- and leaves it in run_start[group][tile] for the emit kernel.  (The separate count kernel, its launch gap and emit's
-// own counting + reservation pass are gone: 11 + 1 + ~12 us on the 200k / 1080p frame.)
-template <bool FUSED_COUNT>  // true: blockDim.x = the binning group (bin_group_for(), <= 1024); false: 256 threads, no counting
-__global__ void __launch_bounds__(FUSED_COUNT ? BIN_GROUP : 256)
+// K1: one thread per Gaussian, plus the first step of the binning (hgs_common.h, BIN_*):
+// BIN_BY_CELL (large frames): the workgroup takes part in a counting sort of the Gaussians by binning cell (the BIN_CELL x
+//   BIN_CELL tiles that hold the first tile of the rectangle) -- an LDS histogram whose returning adds rank the workgroup's
+//   Gaussians inside each cell, ONE returning atomic per touched cell on the global cell counters, and (cell, slot inside
+//   the cell) left in cell_slot for the scatter kernel (binning.hip).  The binning groups of the count and emit kernels are
+//   runs of that order: neighbours on screen, so a group touches a few dozen tiles, many times each, instead of every tile
+//   once or twice.
+// BIN_IN_ORDER (small frames, where two more launches cost more than they save): the workgroup IS a binning group of
+//   consecutive Gaussians and counts its pairs per tile in an LDS histogram while the rectangles are in registers, takes
+//   ONE returning atomic per touched tile on the global per-tile counters -- the value returned is where this group's run
+//   starts inside the tile's segment -- and leaves it in run_start[group][tile] for emit.
+// BIN_NONE: no binning work (very large tile counts: count_kernel / emit_kernel<false> on global atomics).
+template <int MODE>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256
+__global__ void __launch_bounds__(MODE != BIN_NONE ? BIN_GROUP : 256)
 preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rots,
                   const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
                   uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
-                  uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start, float4* __restrict__ zero_accum)
+                  uint32_t* __restrict__ counters, uint2* __restrict__ cell_slot, uint32_t* __restrict__ run_start,
+                  float4* __restrict__ zero_accum)
 {
-    const int NT = FUSED_COUNT ? (int)blockDim.x : 256;
-    extern __shared__ uint32_t hist[];
+    const int NT = MODE != BIN_NONE ? (int)blockDim.x : 256;
+    // BIN_BY_CELL: [num_cells] population of each cell in this workgroup, [num_cells] its base; BIN_IN_ORDER: [num_tiles] pairs
+    extern __shared__ uint32_t bin_lds[];
     const int num_tiles = cam.gx * cam.gy;
+    const int cells_x = (cam.gx + BIN_CELL - 1) / BIN_CELL, num_cells = cells_x * ((cam.gy + BIN_CELL - 1) / BIN_CELL);
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (FUSED_COUNT)
-        for (int t = threadIdx.x; t < num_tiles; t += NT) hist[t] = 0;  // visible after the barrier below
+    if (MODE != BIN_NONE)
+        for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
     // Housekeeping that would otherwise be another launch: when the caller will run backward, its [P,12] gradient
     // accumulator is zeroed here, fully coalesced.
     if (zero_accum) {
@@ -261,7 +271,22 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
         radii[i] = out.radius;
     }
 
-    if (FUSED_COUNT) {
+    if (MODE == BIN_BY_CELL) {
+        uint32_t* population = bin_lds;
+        uint32_t* base = bin_lds + num_cells;
+        const int cell = touched ? (rect_miny / BIN_CELL) * cells_x + rect_minx / BIN_CELL : -1;
+        __syncthreads();  // population zeroed
+        const uint32_t rank = cell >= 0 ? atomicAdd(&population[cell], 1u) : 0u;
+        __syncthreads();
+        for (int c = threadIdx.x; c < num_cells; c += NT) {
+            const uint32_t n = population[c];
+            if (n) base[c] = atomicAdd(&counters[c], n);
+        }
+        __syncthreads();
+        if (i < P) cell_slot[i] = cell >= 0 ? make_uint2((uint32_t)cell, base[cell] + rank) : make_uint2(0xFFFFFFFFu, 0u);
+    }
+    if (MODE == BIN_IN_ORDER) {
+        uint32_t* hist = bin_lds;
         SplatRect mine;
         mine.x = mine.y = 0.f, mine.A = mine.C = -1.f, mine.B = 0.f, mine.thr = 0.f, mine.depth_bits = 0;
         mine.minx = rect_minx, mine.miny = rect_miny, mine.width = rect_width, mine.cnt = touched;
@@ -278,7 +303,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                 c[u] = t < num_tiles ? hist[t] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&tile_count[t0 + u * NT], c[u]) : 0u;
+            for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&counters[t0 + u * NT], c[u]) : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (c[u]) my_runs[t0 + u * NT] = base[u];
@@ -286,19 +311,22 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
     }
 }
 
-void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched,
-                       uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st)
+void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched, int mode,
+                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, hipStream_t st)
 {
-    if (group)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + group - 1) / group), dim3(group), sizeof(uint32_t) * cam.gx * cam.gy,
-                           st, a.P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp,
-                           a.s.viewmatrix, a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, run_start,
+#define HGS_K1_ARGS a.P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix, \
+                    a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii
+    if (mode == BIN_BY_CELL)
+        hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((a.P + group - 1) / group), dim3(group),
+                           2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy), st, HGS_K1_ARGS, counters, cell_slot, nullptr,
                            (float4*)a.grad_accum_to_zero);
+    else if (mode == BIN_IN_ORDER)
+        hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((a.P + group - 1) / group), dim3(group),
+                           sizeof(uint32_t) * cam.gx * cam.gy, st, HGS_K1_ARGS, counters, nullptr, run_start, (float4*)a.grad_accum_to_zero);
     else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, st, a.P, cam, a.means3D, a.shs,
-                           a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix,
-                           a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, tile_count, nullptr,
-                           (float4*)a.grad_accum_to_zero);
+        hipLaunchKernelGGL(preprocess_kernel<BIN_NONE>, dim3((a.P + 255) / 256), dim3(256), 0, st, HGS_K1_ARGS, nullptr, nullptr,
+                           nullptr, (float4*)a.grad_accum_to_zero);
+#undef HGS_K1_ARGS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,7 +18,8 @@ import torch
 
 from hugs_amd import synthetic as syn
 from oracle import hgs_oracle as ho
-from test_gpu_parity import GRAD_REL_TOL, check_image, rel_l2, to_dev
+from scenes import make_scene
+from test_gpu_parity import GRAD_REL_TOL, check_image, rel_l2, run_gpu, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -228,3 +229,26 @@ def test_c5_one_frame_of_the_300k_batch(device):
                      bg_color=torch.ones(3, device=device), active_sh_degree=3)
     assert np.array_equal(pkg["radii"].cpu().numpy(), ref_f["radii"])
     check_image(pkg["render"].cpu().numpy(), np.clip(ref_f["color"], 0, 1), "C5 frame")
+
+
+def test_storage_order_changes_nothing_but_speed(device):
+    """hugs_amd.spatial.morton_order: the same Gaussians stored in Morton order render the same image -- bit for bit when no
+    two of them share a depth (the tie-break is the index) -- and the same gradients once un-permuted (float atomics:
+    summation order).  Long runs per (binning group, tile) are what the reordering buys."""
+    from hugs_amd.spatial import morton_order, permute_model
+    sc = make_scene(P=5000, H=270, W=480, seed=21, D=2, with_culled=True)
+    order = morton_order(sc["means3D"])
+    assert sorted(order.tolist()) == list(range(5000)) and not np.array_equal(order, np.arange(5000))
+    assert np.array_equal(order, morton_order(torch.from_numpy(sc["means3D"]).to(device)).cpu().numpy())
+    t0, c0, r0 = run_gpu(sc, device)
+    c0.backward(to_dev(sc["dL_dpix"], device))
+    sc1 = dict(sc)
+    sc1.update(permute_model({k: sc[k] for k in ("means3D", "opacities", "shs", "scales", "rotations")}, order))
+    t1, c1, r1 = run_gpu(sc1, device)
+    c1.backward(to_dev(sc["dL_dpix"], device))
+    assert torch.equal(c0, c1)
+    assert torch.equal(r0[torch.from_numpy(order).to(device)], r1)
+    o = torch.from_numpy(order).to(device)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations", "means2D"):
+        a, b = t0[k].grad[o], t1[k].grad
+        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) <= 1e-5, k

@@ -171,6 +171,16 @@ def test_backward_gradients(name, device):
     assert float(t["means2D"].grad[:, 2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["cell", "order"])
+@pytest.mark.parametrize("name", ["basic_d3", "deg1_ragged", "big_splats", "wide_clamp", "single"])
+def test_both_binning_paths_give_the_same_lists_and_gradients(name, mode, device, monkeypatch):
+    """Large frames sort the Gaussians by screen cell before they are binned (BIN_BY_CELL, hgs_common.h), small ones bin them
+    in storage order (BIN_IN_ORDER); HGS_BIN_MODE forces either, and the stage-level test above must hold for both."""
+    monkeypatch.setenv("HGS_BIN_MODE", mode)
+    test_forward_stages_and_image(name, device)
+    test_backward_gradients(name, device)
+
+
 def test_empty_input_gives_zero_image_not_background(device):
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = make_scene(P=0, H=32, W=48, seed=0, with_culled=False)

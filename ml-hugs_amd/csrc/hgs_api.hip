@@ -341,9 +341,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
     const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
     if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_index)) return rc;
-    int bin_mode = bin_mode_for(a.P, num_tiles, group);
+    int bin_mode = bin_mode_for(a.P, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
-    if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr) bin_mode = e[0] == 'c' ? BIN_BY_CELL : e[0] == 'o' ? BIN_IN_ORDER : bin_mode;
+    if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr)
+        bin_mode = (e[0] == 'c' && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : e[0] == 'o' ? BIN_IN_ORDER : bin_mode;
     uint32_t* cell_count = bin_mode == BIN_BY_CELL ? tile_count + cell_counters_at : nullptr;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);

@@ -59,20 +59,20 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 constexpr int BIN_GROUP = 1024;           // most Gaussians per binning workgroup (one per thread)
 constexpr int BIN_LDS_TILES = 22 * 1024;  // largest tile count whose u32 array fits the 160 KB of LDS next to emit's 68 KB of staging
 inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
-// Binning cells: BIN_CELL x BIN_CELL tiles.  The Gaussians are counting-sorted by the cell of their rectangle's first
-// tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
+// Binning cells: BIN_CELL x BIN_CELL tiles.  On large frames the Gaussians are counting-sorted by the cell of their
+// rectangle's first tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
+constexpr int BIN_CELL = 4;
+constexpr int BIN_MAX_CELLS = 2048;  // cells whose populations one scatter workgroup prefix-sums (a 1080p frame has 510)
+inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL); }
 enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binning groups (preprocess.hip, binning.hip)
 // BIN_BY_CELL costs two more launches (scatter, group count) and saves the per-group passes over all tiles plus most of the
 // atomics and partial-line key stores: it pays on frames with many Gaussians AND many tiles.  (Measured: 200k / 1080p +1.4 %,
 // 310k / 1080p +2 %; 110k at 512x512 -2.7 %, the 6 890-Gaussian SMPL template at 512x512 -7.5 %.)
-inline int bin_mode_for(int P, int num_tiles, int group)
+inline int bin_mode_for(int P, int num_tiles, int num_cells, int group)
 {
     if (!group) return BIN_NONE;
-    return (P >= 65536 && num_tiles >= 4096) ? BIN_BY_CELL : BIN_IN_ORDER;
+    return (P >= 65536 && num_tiles >= 4096 && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : BIN_IN_ORDER;
 }
-constexpr int BIN_CELL = 4;
-constexpr int BIN_MAX_CELLS = 2048;       // >= cells of the largest LDS-path frame (BIN_LDS_TILES / 16, plus ragged edges)
-inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL); }
 // Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
 // (a group = a workgroup).  A group is the unit of parallelism of both kernels, and either runs one workgroup per CU, so
 // the groups should just fill the 256 CUs in one round: ~250 groups when P allows it (200 000 Gaussians: 241 groups of

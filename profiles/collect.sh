@@ -22,8 +22,8 @@ python3 profiles/timeline_gaps.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_
 F=$(find "$OUT/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 Wc=$(find "$OUT/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 profiles/pmc_traffic.py "$F" "$Wc" $TAG 200000 1080 1920 3 > "$OUT/${TAG}_pmc_traffic.json"
-python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
-python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
+python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
+python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
 python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_pmc_sq_set2.txt" > "$OUT/${TAG}_valu_utilization.json"
 find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete
 ls -la "$OUT"

@@ -225,9 +225,13 @@ size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t ima
  * stage k; 0 disables (default).  hgs_profile_read synchronises the recorded events of that stage,
  * adds them up since the last reset and returns the number of timed launches through *launches. */
 enum {
-    HGS_STAGE_PREPROCESS = 0,    /* projection + SH + per-tile pair counts */
-    HGS_STAGE_SCAN = 1,          /* tile scan -> ranges, N */
-    HGS_STAGE_EMIT_KEYS = 2, HGS_STAGE_SORT = 3, HGS_STAGE_BLEND_FORWARD = 4, HGS_STAGE_BLEND_BACKWARD = 5,
+    HGS_STAGE_PREPROCESS = 0,    /* projection + SH + the first step of the binning (ranks inside screen cells on large
+                                    frames, per-tile pair counts on small ones) */
+    HGS_STAGE_SCAN = 1,          /* large frames: cell scatter + per-group pair counts; then the tile scan -> ranges, N */
+    HGS_STAGE_EMIT_KEYS = 2,
+    HGS_STAGE_SORT = 3,          /* per-tile sort, fused with the forward blend unless HGS_FUSED_SORT_BLEND=0 */
+    HGS_STAGE_BLEND_FORWARD = 4, /* stand-alone forward blend (unfused runs, repaired long tiles) */
+    HGS_STAGE_BLEND_BACKWARD = 5,
     HGS_STAGE_PREPROCESS_BACKWARD = 6, HGS_NUM_STAGES = 7
 };
 void hgs_profile_enable(uint32_t stage_mask);
@@ -240,7 +244,7 @@ const char *hgs_stage_name(int32_t stage);
 
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
  * Names: geom: "splats" (64-byte records), "tiles_touched"; binning: "list" (the sorted list, one u64 per entry:
- * (1-based position inside the tile << 32) | quad coverage mask << 28 | Gaussian index), "bitmaps";
+ * (1-based position inside the tile << 32) | quad coverage mask << 28 | Gaussian index);
  * image: "final_T", "n_contrib" (low 28 bits: position of the last contributing entry; bits 29..31: which colour channels
  * pass dL/dout_color, all set unless clamp_output clipped them), "ranges". Returns (size_t)-1 for an unknown name. */
 size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int32_t image_height,

@@ -3,7 +3,7 @@
 streams and between the two bindings (C++ autograd node, Python ctypes), forced hint misses (too-small capacity, wrong
 "no long tiles", absent hints), forward-only (incl. deferred render_batch frames) and forward+backward, for SOAK_SECONDS
 (default 40).  Every image is compared bit-for-bit with the first render of its scene (the forward is deterministic), every
-gradient within 1e-4 relative of its first value.  Prints "soak ok: <frames> ..." or raises.   python tools/soak.py"""
+gradient within 1e-4 relative of its first value (1e-3 for scenes of <= 50 Gaussians).  Prints "soak ok: <frames> ..." or raises.   python tools/soak.py"""
 import math
 import os
 import random
@@ -95,9 +95,13 @@ while time.time() - t0 < budget:
             if grads is not None:
                 if first[key][1] is None:
                     first[key][1] = grads
-                for a, b in zip(grads, first[key][1]):
+                for name, a, b in zip(("means3D", "opacities", "scales"), grads, first[key][1]):
                     rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
-                    assert rel <= 1e-4, f"gradient of {key} drifted: {rel:.2e}"
+                    # (float atomics: the summation order varies from run to run.  With one Gaussian under a random-sign
+                    #  dL/dpixel the thousands of per-quad sums cancel to a tenth of their random walk, and the order
+                    #  alone moves the result by ~2e-4 -- seen on (1, 2304, 4096) and (1, 128, 128); hence the wider bar
+                    #  for the tiny scenes)
+                    assert rel <= (1e-3 if key[0] <= 50 else 1e-4), f"gradient {name} of {key} drifted: {rel:.2e}\n now   {a.flatten()[:8].tolist()}\n first {b.flatten()[:8].tolist()}"
         pending.clear()
 torch.cuda.synchronize()
 print(f"soak ok: {n} frames (+{n_batch} deferred) in {time.time() - t0:.1f} s over {len(scenes)} scenes, C++ binding {'used' if cpp else 'absent'}")

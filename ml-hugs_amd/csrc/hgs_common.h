@@ -67,11 +67,12 @@ inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL
 enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binning groups (preprocess.hip, binning.hip)
 // BIN_BY_CELL costs two more launches (scatter, group count) and saves the per-group passes over all tiles plus most of the
 // atomics and partial-line key stores: it pays on frames with many Gaussians AND many tiles.  (Measured: 200k / 1080p +1.4 %,
-// 310k / 1080p +2 %; 110k at 512x512 -2.7 %, the 6 890-Gaussian SMPL template at 512x512 -7.5 %.)
+// 310k / 1080p +2 %, 35k-100k / 1080p +0.3 .. +1.5 %, 20k / 1080p even; 110k at 512x512 -2.7 %, the 6 890-Gaussian SMPL
+// template at 512x512 -7.5 %.)
 inline int bin_mode_for(int P, int num_tiles, int num_cells, int group)
 {
     if (!group) return BIN_NONE;
-    return (P >= 65536 && num_tiles >= 4096 && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : BIN_IN_ORDER;
+    return (P >= 32768 && num_tiles >= 4096 && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : BIN_IN_ORDER;
 }
 // Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
 // (a group = a workgroup).  A group is the unit of parallelism of both kernels, and either runs one workgroup per CU, so

@@ -1,7 +1,7 @@
 """Storage order of the Gaussians.  The rasterizer's results do not depend on it (up to the summation order of float
 atomics and the index tie-break of exactly equal depths).  Its binning kernels work on groups of ~800 Gaussians, and a
 group whose members are neighbours on screen touches few tiles -- long runs per tile instead of one or two entries, few
-returning atomics, coalesced key stores ("Binning").  Large frames (>= 65 536 Gaussians, >= 4 096
+returning atomics, coalesced key stores ("Binning").  Large frames (≥ 32 768 Gaussians, ≥ 4 096
 tiles) form such groups themselves, with a counting sort by screen cell; smaller ones bin in STORAGE order, and a model
 whose Gaussians are appended in arbitrary order (densification does that: /root/reference/hugs/models/scene.py:333-361)
 can be put in Morton order now and then; `permute_model` applies one permutation to every per-Gaussian tensor of a dict."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that refreshes everything under profiles/ for a round tag:
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r1h'
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r1h'      then copy gpurun_out/<tag>/<tag>_* into profiles/
 # kernel-trace/stats and each PMC set are separate rocprofv3 runs (never --pmc together with other trace domains).
 set -u
 TAG=${1:?tag}
@@ -8,7 +8,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o $TAG -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-two-streams \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/trace.err"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -25,6 +24,10 @@ python3 profiles/pmc_traffic.py "$F" "$Wc" $TAG 200000 1080 1920 3 > "$OUT/${TAG
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
 python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_pmc_sq_set2.txt" > "$OUT/${TAG}_valu_utilization.json"
+# the bench line LAST, with this build's own PMC summaries in place (bench.py attaches traffic / VALU figures only from
+# summaries whose recorded source hash is the running build's)
+cp "$OUT/${TAG}_pmc_traffic.json" "$OUT/${TAG}_valu_utilization.json" "$ROOT/profiles/"
+python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete
 ls -la "$OUT"
 cat "$OUT/${TAG}_timeline.txt"

@@ -22,6 +22,8 @@ def morton_order(means3D):
     """Permutation (int64) that sorts [P,3] positions (numpy array or torch tensor, any device) by their 30-bit Morton
     code inside the positions' bounding box; non-finite positions go last."""
     if isinstance(means3D, torch.Tensor):
+        if means3D.shape[0] == 0:
+            return torch.zeros(0, dtype=torch.int64, device=means3D.device)
         x = means3D.detach().float()
         ok = torch.isfinite(x).all(dim=1)
         lo = torch.where(ok[:, None], x, torch.full_like(x, float("inf"))).amin(dim=0)

@@ -32,10 +32,10 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 5
+#define HGS_ABI_VERSION 6
 
 /* scratch buffer ids passed to the allocation callback */
-enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2 };
+enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
 
 /* error codes (negative return values) */
 enum {
@@ -109,12 +109,19 @@ typedef struct hgs_forward_args {
      * the hint -- its kernels then did nothing and out_color / radii are NOT valid until the frame is run again.  Use a
      * generous hint (the scratch is the caller's: e.g. a persistent arena per stream). */
     int32_t defer_n;
-    int32_t reserved;
+    /* !=0: the caller is going to run hgs_rasterize_backward on this frame and offers the forward blend a fourth scratch
+     * buffer (HGS_BUF_CKPT, hgs_ckpt_bytes(capacity, H, W)) for per-pixel CHECKPOINTS: on a sparse frame (few non-empty
+     * tiles with deep lists: a human-only render) the forward then stores (T, colour prefix) of every pixel every 32
+     * positions of its quad's list, and backward splits every list into 32-entry segments that run as independent waves
+     * instead of one chain of dependent entries per quad.  Dense frames write and read nothing there.  Results are the
+     * same up to fp32 summation order either way; 0 (or a failed HGS_BUF_CKPT allocation is an error) keeps the
+     * one-wave-per-quad backward. */
+    int32_t backward_checkpoints;
     /* Optional caller-provided scratch (e.g. persistent arenas for frames that need no backward): buffer k
-     * (HGS_BUF_GEOM / HGS_BUF_BINNING / HGS_BUF_IMAGE) is used when scratch[k] != NULL and scratch_bytes[k] suffices,
-     * otherwise the allocation callback is asked as usual.  256-byte aligned device pointers. */
-    void *scratch[3];
-    size_t scratch_bytes[3];
+     * (HGS_BUF_GEOM / HGS_BUF_BINNING / HGS_BUF_IMAGE / HGS_BUF_CKPT) is used when scratch[k] != NULL and
+     * scratch_bytes[k] suffices, otherwise the allocation callback is asked as usual.  256-byte aligned device pointers. */
+    void *scratch[4];
+    size_t scratch_bytes[4];
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -122,9 +129,10 @@ typedef struct hgs_forward_state {
     void *geom;    size_t geom_bytes;
     void *binning; size_t binning_bytes;
     void *image;   size_t image_bytes;
+    void *ckpt;    size_t ckpt_bytes;   /* NULL / 0 unless backward_checkpoints was set */
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
-    int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad its own wave */
+    int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
     int32_t has_long_tiles;   /* !=0: some tile list is longer than 2048 entries (feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
 } hgs_forward_state;
@@ -219,6 +227,7 @@ int32_t hgs_abi_version(void);
 size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_image_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
+size_t hgs_ckpt_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 
 /* Per-stage device timing with HIP events recorded on the launch stream (the
  * reference has no profiling hooks; this is the build's own).  `stage_mask` has bit k set to time

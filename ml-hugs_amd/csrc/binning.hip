@@ -53,7 +53,8 @@ constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 t
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
                  uint2* __restrict__ ranges, uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total,
-                 uint32_t* __restrict__ large_tiles, uint32_t capacity, unsigned long long* __restrict__ host_slot, uint32_t ticket)
+                 uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ seg_first, uint32_t capacity,
+                 unsigned long long* __restrict__ host_slot, uint32_t ticket)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t n_large, n_nonempty;
@@ -114,12 +115,20 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
                                        c[k + 1] ? st[k + 1] + c[k + 1] : 0u);
             reinterpret_cast<uint4*>(cursor + t0)[0] = make_uint4(st[0], st[1], st[2], st[3]);
             reinterpret_cast<uint4*>(cursor + t0)[1] = make_uint4(st[4], st[5], st[6], st[7]);
+            if (seg_first) {  // first checkpoint slot of each tile (hgs_common.h, CKPT_*)
+                const uint32_t b = (uint32_t)t0;
+                reinterpret_cast<uint4*>(seg_first + t0)[0] = make_uint4((st[0] >> CKPT_SHIFT) + b, (st[1] >> CKPT_SHIFT) + b + 1u,
+                                                                         (st[2] >> CKPT_SHIFT) + b + 2u, (st[3] >> CKPT_SHIFT) + b + 3u);
+                reinterpret_cast<uint4*>(seg_first + t0)[1] = make_uint4((st[4] >> CKPT_SHIFT) + b + 4u, (st[5] >> CKPT_SHIFT) + b + 5u,
+                                                                         (st[6] >> CKPT_SHIFT) + b + 6u, (st[7] >> CKPT_SHIFT) + b + 7u);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < SCAN_ITEMS; ++k)
                 if (t0 + k < num_tiles) {
                     ranges[t0 + k] = c[k] ? make_uint2(st[k], st[k] + c[k]) : make_uint2(0u, 0u);
                     cursor[t0 + k] = st[k];
+                    if (seg_first) seg_first[t0 + k] = (st[k] >> CKPT_SHIFT) + (uint32_t)(t0 + k);
                 }
         }
         carry += total;
@@ -127,6 +136,7 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u, n_total[2] = n_large;
+        if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
         // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
         // the backward blend then splits long tiles over four waves
         const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
@@ -138,11 +148,11 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
-                      uint32_t* n_total, uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
-                      hipStream_t st)
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot,
+                      uint32_t ticket, hipStream_t st)
 {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
-                       ranges, cursor, n_total, large_tiles, capacity, host_slot, ticket);
+                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,7 +669,7 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                        uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count,
                        const uint32_t* __restrict__ gate, Camera cam, uint32_t lastg, const Splat* __restrict__ splats,
                        const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
-                       uint32_t* __restrict__ n_contrib, int clamp_output, int long_sorted)
+                       uint32_t* __restrict__ n_contrib, int clamp_output, int long_sorted, Ckpt ck)
 {
     __shared__ uint64_t sh[SORT_CAP_SMALL];
     if (*gate) return;
@@ -699,8 +709,10 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     }
     if (FUSED) {
         mine = __builtin_amdgcn_readfirstlane(mine);
+        float4* ck_tile = ckpt_begin(ck, blockIdx.x);
         blend_forward_wave(cam, lastg, (int)(blockIdx.x % (uint32_t)cam.gx), (int)(blockIdx.x / (uint32_t)cam.gx), w, mine,
-                           act + (size_t)w * stride + s, splats, bg, out_color, final_T, n_contrib, clamp_output);
+                           act + (size_t)w * stride + s, splats, bg, out_color, final_T, n_contrib, clamp_output, ck_tile,
+                           ck.quad_nproc + blockIdx.x * 4u + (uint32_t)w);
     }
 }
 
@@ -815,10 +827,10 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
         if (fb)
             hipLaunchKernelGGL(tile_sort_small_kernel<true>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
                                n_total + 1, fb->cam, fb->lastg, fb->splats, fb->bg, fb->out_color, fb->final_T, fb->n_contrib, fb->clamp_output,
-                               long_tiles ? 1 : 0);
+                               long_tiles ? 1 : 0, fb->ck);
         else
             hipLaunchKernelGGL(tile_sort_small_kernel<false>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                               n_total + 1, Camera{}, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0, long_tiles ? 1 : 0);
+                               n_total + 1, Camera{}, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0, long_tiles ? 1 : 0, Ckpt{});
     }
 }
 

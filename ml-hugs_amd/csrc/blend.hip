@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256)
 blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ gate,
-                     int clamp_output, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_list_len)
+                     int clamp_output, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_list_len, Ckpt ck)
 {
     if (*(const_u32p)gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -49,22 +49,23 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
         const int tile = tile_list ? (int)((const_u32p)tile_list)[k] : (int)k;
         const v2u range = ((const_u2p)ranges)[tile];
         const uint32_t n = range.y > range.x ? ((const_u32p)act_count)[tile * NUM_LISTS + w] : 0u;
+        float4* ck_tile = ckpt_begin(ck, (uint32_t)tile);
         blend_forward_wave(cam, lastg, tile % cam.gx, tile / cam.gx, w, n, act + (size_t)w * act_stride + range.x, splats, bg, out_color,
-                           final_T, n_contrib, clamp_output);
+                           final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + (uint32_t)tile * 4u + (uint32_t)w);
     }
 }
 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
                           float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output,
-                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, hipStream_t st)
+                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, const Ckpt& ck, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;
     // (over the long-tile list the grid is still one workgroup per tile of the frame -- the host does not know how many are
     // long; workgroups beyond the list's length leave at once)
     hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1),
                        ranges, act, act_stride, act_count, splats, bg, out_color, final_T, n_contrib, gate, clamp_output ? 1 : 0,
-                       long_tiles, n_long_tiles);
+                       long_tiles, n_long_tiles, ck);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,13 +171,22 @@ __device__ __forceinline__ unsigned long long bwd_pixel(const SplatRec& s, uint3
 // NQ = 1: one wave per QUAD (a tile is one workgroup), walking the quad's own compacted list: four times the waves,
 // one reduction per (quad, entry) instead of per (tile, entry) -- more instructions in total, so it only pays when the
 // frame has too few tiles to occupy the SIMDs (a 512x512 human-only render has 1 024 tiles for 1 024 SIMDs).
-template <int NQ>
+// SEG (with NQ = 1): the depth-segmented form for sparse frames -- the wave walks only entries [lo, hi) of its quad's
+// list, starting from the forward blend's checkpoint behind entry hi - 1 (see blend_backward_segmented_kernel).
+struct BwdSegment {
+    uint32_t lo, hi;
+    const float4* start;      // (T, colour prefix) of the wave's 64 pixels behind entry hi - 1; nullptr: the quad's last segment
+    const float4* end_state;  // the state the forward wave ended with: its colour sums are the whole list's
+};
+
+template <int NQ, bool SEG = false>
 __device__ __forceinline__ void
 blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u range, const uint64_t* __restrict__ act,
                     size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats,
                     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                    const float* __restrict__ dL_dpix, float* __restrict__ grad_accum)
+                    const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, const BwdSegment seg = BwdSegment{})
 {
+    static_assert(!SEG || NQ == 1, "segments are per quad");
     const int lane = threadIdx.x & 63;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int list_id = NQ == 4 ? 4 : w;  // the "any quad" list, or this wave's quad's
@@ -201,6 +211,8 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
         ld_T[k] = final_T[pix], ld_n[k] = n_contrib[pix];
         ld_g[k][0] = dL_dpix[pix], ld_g[k][1] = dL_dpix[HW + pix], ld_g[k][2] = dL_dpix[2 * HW + pix];
     }
+    float4 ck_start = make_float4(0.f, 0.f, 0.f, 0.f), ck_end = ck_start;
+    if (SEG && seg.start) ck_start = seg.start[lane], ck_end = seg.end_state[lane];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
         const float Tf = in_img[k] ? ld_T[k] : 0.0f;
@@ -210,6 +222,14 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
         p[k].g1 = in_img[k] && (ld_n[k] >> 30 & 1u) ? ld_g[k][1] : 0.0f;
         p[k].g2 = in_img[k] && (ld_n[k] >> 31 & 1u) ? ld_g[k][2] : 0.0f;
         p[k].S = Tf * (bg0 * p[k].g0 + bg1 * p[k].g1 + bg2 * p[k].g2);
+        if (SEG && seg.start) {
+            // behind the segment: the transmittance the forward had there (|.|: its sign is the forward's "done" flag, and a
+            // pixel that was done takes none of this segment's entries) and everything composited behind it -- the whole
+            // pixel's colour sums minus the prefix up to the checkpoint, dotted with dL/dpixel, plus the background term
+            p[k].T = __builtin_fabsf(ck_start.x);
+            p[k].S = __builtin_fmaf(p[k].g0, ck_end.y - ck_start.y,
+                                    __builtin_fmaf(p[k].g1, ck_end.z - ck_start.z, __builtin_fmaf(p[k].g2, ck_end.w - ck_start.w, p[k].S)));
+        }
         p[k].last_contributor = in_img[k] ? (ld_n[k] & 0x0FFFFFFFu) : 0u;
         wmax = max(wmax, p[k].last_contributor);
     }
@@ -227,9 +247,10 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
 
     // entries of this tile that cover at least one quad (list 4), walked back to front; those beyond the deepest
     // position any pixel composited (pos1 > wmax) are skipped with a scalar branch
-    uint32_t n = ((const_u32p)act_count)[tile * NUM_LISTS + list_id];
+    uint32_t n = SEG ? seg.hi - seg.lo : ((const_u32p)act_count)[tile * NUM_LISTS + list_id];
     if (n == 0) return;
-    const uint64_t* first = act + (size_t)list_id * act_stride + range.x;
+    const uint64_t* first = act + (size_t)list_id * act_stride + range.x + (SEG ? seg.lo : 0u);
+    if (SEG && (uint32_t)(((const_u64p)first)[0] >> 32) > wmax) return;  // the whole segment lies behind every pixel's last entry
     // The walk starts at the deepest entry any pixel composited, not at the end of the list: where the pixels saturate
     // early (a dense human blob: lists of ~700 entries, pixels done after ~250) most of the list lies beyond wmax, and
     // stepping over it entry by entry -- record fetch, compare, branch -- cost a fifth of the kernel.  The list is in
@@ -327,14 +348,49 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     blend_backward_wave<NQ>(cam, lastg, tile, w, range, act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
+// Depth-segmented backward for SPARSE frames (a 512x512 human-only render, a person in front of an empty background): few
+// tiles, lists hundreds of entries deep, and blend_backward_kernel<1> lasts as long as its deepest quad's chain of
+// dependent entries while most SIMDs idle.  The forward blend left a checkpoint every CKPT_SEG list positions (blend_fwd.h);
+// here workgroup b takes checkpoint SLOT b = (tile, segment m), one wave per quad, and walks only entries
+// [m CKPT_SEG, (m + 1) CKPT_SEG) of the quad's list from the state the forward had behind them -- the chain is at most
+// CKPT_SEG entries long and the frame's (quad, entry) pairs spread over all SIMDs.  Same per-entry arithmetic, skip rules,
+// reduction and atomics as the one-wave-per-quad kernel.
+__global__ void __launch_bounds__(256)
+blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                                size_t act_stride, const Splat* __restrict__ splats, const float* __restrict__ bg,
+                                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, Ckpt ck)
+{
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x;  // (the grid is the frame's slot count, (N >> CKPT_SHIFT) + tiles)
+    const uint32_t tile = ((const_u32p)ck.slot_tile)[slot];
+    const uint32_t first_slot = ((const_u32p)ck.seg_first)[tile];
+    const uint32_t m = slot - first_slot;
+    const uint32_t walked = ((const_u32p)ck.quad_nproc)[tile * 4u + (uint32_t)w];  // entries the forward wave walked
+    const uint32_t segs = (walked + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT;
+    if (m >= segs) return;
+    const v2u range = ((const_u2p)ranges)[tile];
+    BwdSegment seg;
+    seg.lo = m << CKPT_SHIFT, seg.hi = min(walked, (m + 1u) << CKPT_SHIFT);
+    seg.start = m + 1u < segs ? ck.state + (size_t)(first_slot + m) * 256u + w * 64 : nullptr;
+    seg.end_state = ck.state + (size_t)(first_slot + segs - 1u) * 256u + w * 64;
+    blend_backward_wave<1, true>(cam, lastg, (int)tile, w, range, act, act_stride, nullptr, splats, bg, final_T, n_contrib, dL_dpix,
+                                 grad_accum, seg);
+}
+
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
-                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st)
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
+                           const Ckpt& ck, int64_t num_rendered, hipStream_t st)
 {
     const int num_tiles = cam.gx * cam.gy;
     static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
     const bool per_quad = force ? force[0] == '4' : sparse_frame;
-    if (per_quad)
+    if (sparse_frame && ck.state) {  // the forward left checkpoints (it does so exactly when the frame is sparse)
+        const uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;
+        hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act, act_stride,
+                           splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
+    } else if (per_quad)
         hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(num_tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                            act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
     else

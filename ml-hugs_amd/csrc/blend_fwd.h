@@ -76,11 +76,25 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
     last = upd ? pos1 : last;
 }
 
+// First slot of tile `tile` in the checkpoint buffer (nullptr: the frame leaves no checkpoints); the workgroup also
+// records which tile its slots belong to -- the backward's workgroups are dealt slots, not tiles (blend.hip).
+__device__ __forceinline__ float4* ckpt_begin(const Ckpt& ck, uint32_t tile)
+{
+    if (!ck.state || *(const_u32p)ck.sparse == 0u) return nullptr;
+    const uint32_t first = ((const_u32p)ck.seg_first)[tile], end = ((const_u32p)ck.seg_first)[tile + 1];
+    for (uint32_t k = first + threadIdx.x; k < end; k += blockDim.x) ck.slot_tile[k] = tile;
+    return ck.state + (size_t)first * 256u;
+}
+
 // One wave = the 64 pixels of quad `w` (0..3) of tile (tx, ty); walks `n` entries of the quad's compacted list.
+// ck_tile != nullptr: the tile's checkpoint slots -- slot k receives the wave's state (T with its "done" sign, colour
+// prefix) BEFORE list position (k + 1) * CKPT_SEG, the slot after the last full segment the state the wave ended with,
+// and *nproc_out the number of entries it walked.
 __device__ __forceinline__ void blend_forward_wave(const Camera& cam, uint32_t lastg, int tx, int ty, int w, uint32_t n,
                                                    const uint64_t* __restrict__ list, const Splat* __restrict__ splats,
                                                    const float* __restrict__ bg, float* __restrict__ out_color,
-                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int clamp_output)
+                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int clamp_output,
+                                                   float4* __restrict__ ck_tile = nullptr, uint32_t* __restrict__ nproc_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
@@ -90,6 +104,8 @@ __device__ __forceinline__ void blend_forward_wave(const Camera& cam, uint32_t l
 
     float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
+    uint32_t walked = 0;
+    float4* ck_mine = ck_tile ? ck_tile + w * 64 + lane : nullptr;
 
     if (n) {
         // Software pipeline, two entries per half-iteration, two register sets (A/B) so nothing is copied:
@@ -97,19 +113,27 @@ __device__ __forceinline__ void blend_forward_wave(const Camera& cam, uint32_t l
         v4u eA = load_pair(list, 0);
         SplatRec rA0 = load_rec(splats, eA.x, lastg), rA1 = load_rec(splats, eA.z, lastg);
         v4u eB = load_pair(list, 2);
+        walked = n;
         for (uint32_t j = 0; j < n; j += 4) {
+            if (ck_tile && j && (j & (uint32_t)(CKPT_SEG - 1)) == 0u) ck_mine[(size_t)((j >> CKPT_SHIFT) - 1u) * 256u] = make_float4(T, C0, C1, C2);
             const SplatRec rB0 = load_rec(splats, eB.x, lastg), rB1 = load_rec(splats, eB.z, lastg);
             const v4u eA2 = load_pair(list, j + 4);
             fwd_accumulate(rA0, eA.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 1 < n) fwd_accumulate(rA1, eA.w, pxf, pyf, T, C0, C1, C2, last);
-            if (j + 2 >= n || __ballot(T > 0.0f) == 0ull) break;
+            if (j + 2 >= n) break;
+            if (__ballot(T > 0.0f) == 0ull) { walked = j + 2; break; }
             rA0 = load_rec(splats, eA2.x, lastg), rA1 = load_rec(splats, eA2.z, lastg);
             const v4u eB2 = load_pair(list, j + 6);
             fwd_accumulate(rB0, eB.y, pxf, pyf, T, C0, C1, C2, last);
             if (j + 3 < n) fwd_accumulate(rB1, eB.w, pxf, pyf, T, C0, C1, C2, last);
-            if (__ballot(T > 0.0f) == 0ull) break;
+            if (__ballot(T > 0.0f) == 0ull) { walked = min(j + 4, n); break; }
             eA = eA2, eB = eB2;
         }
+    }
+    if (ck_tile) {
+        const uint32_t segs = (walked + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT;
+        if (segs >= 2u) ck_mine[(size_t)(segs - 1u) * 256u] = make_float4(T, C0, C1, C2);
+        if (lane == 0) *nproc_out = walked;
     }
     if (inside) {
         const size_t HW = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;

@@ -280,6 +280,7 @@ const char* hgs_stage_name(int32_t stage)
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return GeomLayout(P < 1 ? 1 : P, num_tiles_of(H, W)).total; }
 size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
+size_t hgs_ckpt_bytes(int64_t N, int32_t H, int32_t W) { return CkptLayout(N, num_tiles_of(H, W)).total; }
 
 size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int32_t W)
 {
@@ -307,6 +308,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (a.P == 0) return 0;  // nothing is launched: out_color keeps the caller's zeros (no background)
     if (!a.out_color || !a.radii) return fail(HGS_ERR_INVALID_ARGUMENT, "out_color and radii are required");
     const bool dbg = a.s.debug != 0;
+    // HGS_BWD_SEGMENTED=0: never leave checkpoints (backward then runs one wave per quad on sparse frames; A/B measurements)
+    static const bool seg_allowed = [] { const char* e = getenv("HGS_BWD_SEGMENTED"); return !(e && e[0] == '0'); }();
+    const bool want_ckpt = a.backward_checkpoints != 0 && seg_allowed;
 
     const int num_tiles = cam.gx * cam.gy;
     GeomLayout gl(a.P, num_tiles);
@@ -359,8 +363,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     { ProfScope ps(HGS_STAGE_SCAN, st);
       if (bin_mode == BIN_BY_CELL) launch_spatial_groups(a.P, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
       else if (bin_mode == BIN_NONE) launch_count(a.P, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, cap32,
-                       (unsigned long long*)slot.word, slot.ticket, st); }
+      launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
+                       want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
     tile_counters_clean(tc_index);  // the scan, which re-zeroes them, is enqueued
 
@@ -372,7 +376,19 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     static const bool fused = [] { const char* e = getenv("HGS_FUSED_SORT_BLEND"); return !(e && e[0] == '0'); }();
     float* final_T = (float*)(image + il.final_T);
     uint32_t* n_contrib = (uint32_t*)(image + il.n_contrib);
-    const FusedBlend fb{cam, (uint32_t)(a.P - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0};
+    FusedBlend fb{cam, (uint32_t)(a.P - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0, Ckpt{}};
+    // checkpoints for the depth-segmented backward: laid out for the same capacity as the binning buffer
+    bool known_dense = false;  // (set once N and the frame's flags are known: a dense frame needs no checkpoint buffer)
+    auto obtain_ckpt = [&](int64_t capacity) -> int {
+        if (!want_ckpt || known_dense) return HGS_OK;
+        CkptLayout cl(capacity, num_tiles);
+        char* ck = obtain(HGS_BUF_CKPT, cl.total);
+        if (!ck) return fail(HGS_ERR_ALLOC, "scratch allocation failed (checkpoints %zu B)", cl.total);
+        state->ckpt = ck, state->ckpt_bytes = cl.total;
+        fb.ck = Ckpt{(float4*)(ck + cl.state), (uint32_t*)(ck + cl.slot_tile), (const uint32_t*)(image + il.seg_first),
+                     (uint32_t*)(image + il.quad_nproc), n_total + 3};
+        return HGS_OK;
+    };
     // repair of a wrong "no long tiles" guess: the long tiles' own sort kernel, then the forward blend over the device-built
     // list of them (normally the long-tile sort runs in front of the small-tile kernel, which then blends every tile)
     auto enqueue_long_tiles = [&](const BinningLayout& bl, char* bin) -> int {
@@ -383,7 +399,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
           launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
-                               a.clamp_output != 0, large_tiles, n_total + 2, st); }
+                               a.clamp_output != 0, large_tiles, n_total + 2, fb.ck, st); }
         STAGE_CHECK(dbg, st, "blend_forward (long tiles)");
         return HGS_OK;
     };
@@ -393,6 +409,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         char* bin = obtain(HGS_BUF_BINNING, bl.total);
         if (!bin) return fail(HGS_ERR_ALLOC, "scratch allocation failed (binning %zu B)", bl.total);
         state->binning = bin, state->binning_bytes = bl.total, state->binning_capacity = capacity;
+        if (int rc = obtain_ckpt(capacity)) return rc;
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
@@ -406,7 +423,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
             // (when the long-tile sort was skipped, long tiles read as empty here: they are blended by the repair)
             { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
               launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
-                                   a.clamp_output != 0, nullptr, nullptr, st); }
+                                   a.clamp_output != 0, nullptr, nullptr, fb.ck, st); }
             STAGE_CHECK(dbg, st, "blend_forward");
         }
         return HGS_OK;
@@ -435,6 +452,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         // exact size known now (and whether there are long tiles); after a too-small guess the gated kernels above did
         // nothing, so the frame is simply enqueued again
         if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
+        known_dense = !sparse;
+        if (known_dense) state->ckpt = nullptr, state->ckpt_bytes = 0, fb.ck = Ckpt{};
         if (int rc = enqueue_frame(N, has_long)) return rc;
     } else if (has_long && !long_sort_done) {
         // guessed "no long tiles" wrongly: their lists read as empty so far -- sort and blend them now
@@ -486,6 +505,14 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     BinningLayout bl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered);
     if (a.state.geom_bytes < gl.total || a.state.image_bytes < il.total || a.state.binning_bytes < bl.total)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size");
+    Ckpt ck{};
+    if (a.state.ckpt) {
+        CkptLayout cl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered, cam.gx * cam.gy);
+        if (a.state.ckpt_bytes < cl.total) return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size (checkpoints)");
+        char* c = (char*)a.state.ckpt;
+        ck = Ckpt{(float4*)(c + cl.state), (uint32_t*)(c + cl.slot_tile), (const uint32_t*)((const char*)a.state.image + il.seg_first),
+                  (uint32_t*)((char*)a.state.image + il.quad_nproc), nullptr};
+    }
     const char* geom = (const char*)a.state.geom;
     const char* image = (const char*)a.state.image;
     const char* bin = (const char*)a.state.binning;
@@ -495,7 +522,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
       launch_blend_backward(cam, f.P, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
                             bl.act_stride, (const uint32_t*)(image + il.act_count), a.state.sparse_frame != 0, splats,
                             f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
-                            a.grad_accum, st); }
+                            a.grad_accum, ck, a.state.num_rendered, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");

@@ -117,8 +117,14 @@ struct GeomLayout {
 };
 constexpr int ACT_PAD = 16;
 constexpr int NUM_LISTS = 5;  // four per-quad lists + one "any quad" list per tile
+// Depth-segmented backward (blend.hip): on sparse frames the forward blend leaves a per-pixel checkpoint -- (T, colour
+// prefix) -- every CKPT_SEG positions of a quad's compacted list, so that a backward wave can start at any of them.
+// A checkpoint SLOT holds the 256 pixels of one tile (four quads x 64 lanes x float4 = 4 KB).  Tile t owns the slots
+// [seg_first[t], seg_first[t + 1]) with seg_first[t] = (start of the tile's list segment >> CKPT_SHIFT) + t: at least
+// ceil(list length / CKPT_SEG) of them, no prefix sum beyond the one the scan already does, (N >> CKPT_SHIFT) + T in all.
+constexpr int CKPT_SHIFT = 5, CKPT_SEG = 1 << CKPT_SHIFT;
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, act_count, cursor, large_tiles, n_total, total;
+    size_t final_T, n_contrib, ranges, act_count, cursor, large_tiles, n_total, seg_first, quad_nproc, total;
     ImageLayout(int H, int W) {
         size_t S = (size_t)H * W, T = (size_t)((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
         size_t o = 0;
@@ -129,6 +135,19 @@ struct ImageLayout {
         cursor = o;     o = align_up(o + 4 * T);   // start of each tile's segment (the fallback emit path advances it with atomics)
         large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
         n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles, [3] sparse-frame flag
+        seg_first = o;  o = align_up(o + 4 * (T + 1));  // first checkpoint slot of each tile; [T] = number of slots
+        quad_nproc = o; o = align_up(o + 16 * T);       // list entries the forward blend walked, per (tile, quad)
+        total = o;
+    }
+};
+struct CkptLayout {
+    size_t slot_tile, state, total;
+    size_t slots;
+    CkptLayout(int64_t N, int num_tiles) {
+        slots = (size_t)((N < 0 ? 0 : N) >> CKPT_SHIFT) + (size_t)num_tiles;
+        size_t o = 0;
+        slot_tile = o;  o = align_up(o + 4 * slots);      // which tile a slot belongs to (written by the tile's forward workgroup)
+        state = o;      o = align_up(o + 4096 * slots);   // float4 [slot][quad][lane]: (T, C0, C1, C2) before list position (k + 1) * CKPT_SEG
         total = o;
     }
 };
@@ -169,14 +188,20 @@ void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const 
                            uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
 // (re-zeroes tile_count, and cell_count if given, behind itself)
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
-                      uint32_t* n_total, uint32_t* large_tiles, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket,
-                      hipStream_t st);
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot,
+                      uint32_t ticket, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
                  const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 // fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
+// Checkpoints of the forward blend for the depth-segmented backward; state == nullptr: none.  They are written only when
+// the frame is sparse (*sparse != 0, decided by the tile scan), which is also when backward reads them.
+struct Ckpt {
+    float4* state; uint32_t* slot_tile; const uint32_t* seg_first; uint32_t* quad_nproc; const uint32_t* sparse;
+};
 struct FusedBlend {
     Camera cam; uint32_t lastg; const Splat* splats; const float* bg; float* out_color; float* final_T; uint32_t* n_contrib; int clamp_output;
+    Ckpt ck;
 };
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
@@ -185,10 +210,11 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
                           float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output,
-                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, hipStream_t st);
+                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, const Ckpt& ck, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
-                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum, hipStream_t st);
+                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
+                           const Ckpt& ck, int64_t num_rendered, hipStream_t st);
 
 }  // namespace hgs

@@ -22,10 +22,11 @@ using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-struct Hint { int64_t n; bool has_long; };
+struct Hint { int64_t n; bool has_long; bool sparse; };
 std::mutex g_mu;
 std::map<std::tuple<int, int64_t, int64_t, int64_t>, Hint> g_hints;   // (device, P, H, W) -> previous frame of this shape
 bool g_use_hint = true;
+bool g_use_ckpt = true;   // leave checkpoints for the depth-segmented backward on sparse frames (HGS_BWD_SEGMENTED=0: off)
 thread_local int64_t t_last_n = -1, t_last_capacity = -1;
 
 inline const float* fptr(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
@@ -125,6 +126,8 @@ public:
         {
             std::lock_guard<std::mutex> lk(g_mu);
             auto it = g_hints.find(key);
+            // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
+            a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse)) ? 1 : 0;
             if (g_use_hint && it != g_hints.end()) {
                 // + 12.5 % + 4096, rounded up to 256 Ki entries: frame after frame asks the caching allocator for the same size
                 a.binning_capacity_hint = (it->second.n + it->second.n / 8 + 4096 + 0x3FFFF) & ~(int64_t)0x3FFFF;
@@ -135,14 +138,16 @@ public:
         AllocCtx actx{&keep, bopts};
         Tensor scratch;
         if (P > 0) {
-            // pre-sized scratch, no allocation callbacks: geom | image | binning(hint)
+            // pre-sized scratch, no allocation callbacks: geom | image | binning(hint) [| checkpoints(hint)]
             const size_t g = align256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), im = align256(hgs_image_bytes((int32_t)H, (int32_t)W));
             const size_t b = a.binning_capacity_hint > 0 ? align256(hgs_binning_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
-            scratch = at::empty({(int64_t)(g + im + b)}, bopts);
+            const size_t ck = b && a.backward_checkpoints ? align256(hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
+            scratch = at::empty({(int64_t)(g + im + b + ck)}, bopts);
             char* base = (char*)scratch.data_ptr();
             a.scratch[HGS_BUF_GEOM] = base, a.scratch_bytes[HGS_BUF_GEOM] = g;
             a.scratch[HGS_BUF_IMAGE] = base + g, a.scratch_bytes[HGS_BUF_IMAGE] = im;
             if (b) a.scratch[HGS_BUF_BINNING] = base + g + im, a.scratch_bytes[HGS_BUF_BINNING] = b;
+            if (ck) a.scratch[HGS_BUF_CKPT] = base + g + im + b, a.scratch_bytes[HGS_BUF_CKPT] = ck;
         }
         int64_t n;
         {
@@ -153,7 +158,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(g_mu);
             if (g_hints.size() > 256) g_hints.clear();
-            g_hints[key] = Hint{n, bw.state.has_long_tiles != 0};
+            g_hints[key] = Hint{n, bw.state.has_long_tiles != 0, bw.state.sparse_frame != 0};
         }
         t_last_n = n, t_last_capacity = bw.state.binning_capacity;
 
@@ -163,7 +168,10 @@ public:
             ctx->save_for_backward({means3D, sh.defined() ? sh : Tensor(), colors.defined() ? colors : Tensor(),
                                     opac.defined() ? opac : Tensor(), scales.defined() ? scales : Tensor(),
                                     rot.defined() ? rot : Tensor(), cov.defined() ? cov : Tensor(), radii, bg, view, proj, campos,
-                                    scratch, keep.empty() ? Tensor() : keep.back(), slab});
+                                    scratch, slab});
+            // (buffers the allocation callback handed out -- the binning / checkpoint buffers of an unhinted or under-guessed
+            // frame -- stay alive with the node)
+            for (const Tensor& t : keep) ctx->saved_data["keep" + std::to_string(&t - keep.data())] = t;
             ctx->saved_data["H"] = H, ctx->saved_data["W"] = W, ctx->saved_data["tx"] = tanfovx, ctx->saved_data["ty"] = tanfovy;
             ctx->saved_data["mod"] = mod, ctx->saved_data["D"] = degree, ctx->saved_data["flags"] = (int64_t)((prefiltered ? 1 : 0) | (debug ? 2 : 0) | (clamp_output ? 4 : 0));
             ctx->saved_data["N"] = n, ctx->saved_data["cap"] = bw.state.binning_capacity;
@@ -171,6 +179,7 @@ public:
             ctx->saved_data["geom"] = (int64_t)(uintptr_t)bw.state.geom, ctx->saved_data["geom_b"] = (int64_t)bw.state.geom_bytes;
             ctx->saved_data["bin"] = (int64_t)(uintptr_t)bw.state.binning, ctx->saved_data["bin_b"] = (int64_t)bw.state.binning_bytes;
             ctx->saved_data["img"] = (int64_t)(uintptr_t)bw.state.image, ctx->saved_data["img_b"] = (int64_t)bw.state.image_bytes;
+            ctx->saved_data["ck"] = (int64_t)(uintptr_t)bw.state.ckpt, ctx->saved_data["ck_b"] = (int64_t)bw.state.ckpt_bytes;
             ctx->saved_data["fresh"] = true;
         }
         return {color, radii};
@@ -185,7 +194,7 @@ public:
         if (sv.empty()) return out;
         const Tensor &means3D = sv[0], &sh = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rot = sv[5], &cov = sv[6],
                      &radii = sv[7], &bg = sv[8], &view = sv[9], &proj = sv[10], &campos = sv[11];
-        Tensor slab = sv[14];
+        Tensor slab = sv[13];
         const int64_t P = means3D.size(0), H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
         if (P == 0) {   // nothing was rendered: empty gradients of the inputs' shapes
             out[0] = at::zeros_like(means3D), out[1] = at::zeros_like(means3D);
@@ -204,6 +213,7 @@ public:
         bw.state.geom = (void*)(uintptr_t)ctx->saved_data["geom"].toInt(), bw.state.geom_bytes = (size_t)ctx->saved_data["geom_b"].toInt();
         bw.state.binning = (void*)(uintptr_t)ctx->saved_data["bin"].toInt(), bw.state.binning_bytes = (size_t)ctx->saved_data["bin_b"].toInt();
         bw.state.image = (void*)(uintptr_t)ctx->saved_data["img"].toInt(), bw.state.image_bytes = (size_t)ctx->saved_data["img_b"].toInt();
+        bw.state.ckpt = (void*)(uintptr_t)ctx->saved_data["ck"].toInt(), bw.state.ckpt_bytes = (size_t)ctx->saved_data["ck_b"].toInt();
         bw.state.num_rendered = ctx->saved_data["N"].toInt(), bw.state.binning_capacity = ctx->saved_data["cap"].toInt();
         bw.state.sparse_frame = (int32_t)ctx->saved_data["sparse"].toInt(), bw.state.has_long_tiles = (int32_t)ctx->saved_data["long"].toInt();
         GradLayout gl(P, M);
@@ -256,10 +266,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize", &rasterize, "forward of the differentiable Gaussian rasterizer (C++ autograd node over the C ABI)");
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
     m.def("last_frame_info", [] { return std::make_pair(t_last_n, t_last_capacity); }, "(N, binning capacity) of this thread's last forward");
-    m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long) {
+    m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse) {
         std::lock_guard<std::mutex> lk(g_mu);
-        g_hints[std::make_tuple(dev, P, H, W)] = Hint{n, has_long};
-    });
+        g_hints[std::make_tuple(dev, P, H, W)] = Hint{n, has_long, sparse};
+    }, py::arg("dev"), py::arg("P"), py::arg("H"), py::arg("W"), py::arg("n"), py::arg("has_long"), py::arg("sparse") = true);
     m.def("clear_hints", [] { std::lock_guard<std::mutex> lk(g_mu); g_hints.clear(); });
     m.def("use_hints", [](bool on) { g_use_hint = on; });
+    m.def("use_checkpoints", [](bool on) { g_use_ckpt = on; });
 }

@@ -30,7 +30,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 5
+_ABI_VERSION = 6
 
 
 def library_path():
@@ -52,13 +52,14 @@ class _ForwardArgs(C.Structure):
                 ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
                 ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
-                ("defer_n", C.c_int32), ("reserved", C.c_int32), ("scratch", C.c_void_p * 3), ("scratch_bytes", C.c_size_t * 3)]
+                ("defer_n", C.c_int32), ("backward_checkpoints", C.c_int32), ("scratch", C.c_void_p * 4),
+                ("scratch_bytes", C.c_size_t * 4)]
 
 
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
-                ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
+                ("ckpt", C.c_void_p), ("ckpt_bytes", C.c_size_t), ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
                 ("has_long_tiles", C.c_int32), ("n_token", C.c_uint64)]
 
 
@@ -96,8 +97,9 @@ def _load():
     lib.hgs_mark_visible.restype = C.c_int32
     lib.hgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hgs_last_error.restype = C.c_char_p
-    for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_scratch_offset):
+    for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_ckpt_bytes, lib.hgs_scratch_offset):
         fn.restype = C.c_size_t
+    lib.hgs_ckpt_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_geom_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
@@ -219,10 +221,20 @@ _max_num_rendered = {}   # largest N seen per shape key: sizes the binning arena
 _DEFERRED_MIN_CAPACITY = 1 << 22
 
 
-def _remember(key, n, has_long):
+# Whether the last frame of a shape was SPARSE (few non-empty tiles): such frames get a checkpoint buffer when a backward
+# will follow (hgs_forward_args.backward_checkpoints); a shape without history is assumed sparse (the library then
+# allocates the buffer only if the frame turns out to be).
+_last_sparse = {}
+_USE_CKPT = os.environ.get("HGS_BWD_SEGMENTED", "1") != "0"
+
+
+def _remember(key, n, has_long, sparse=None):
     if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
         _last_num_rendered.clear()
         _max_num_rendered.clear()
+        _last_sparse.clear()
+    if sparse is not None:
+        _last_sparse[key] = bool(sparse)
     _last_num_rendered[key] = (n, has_long)
     _max_num_rendered[key] = max(n, _max_num_rendered.get(key, 0))
 
@@ -289,12 +301,13 @@ def _arena(dev, stream_id, nbytes):
     return t
 
 
-def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=None):
+def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=None, checkpoints=False):
     """Pre-sized scratch handed to the library through args.scratch (no allocation callbacks): one buffer holding geom |
-    image | binning(capacity).  Returns (buffer, (offsets))."""
+    image | binning(capacity) [| checkpoints(capacity)].  Returns (buffer, (offsets))."""
     g, im = _align(lib.hgs_geom_bytes(P, H, W)), _align(lib.hgs_image_bytes(H, W))
     b = _align(lib.hgs_binning_bytes(capacity, H, W)) if capacity > 0 else 0
-    total = g + im + b
+    ck = _align(lib.hgs_ckpt_bytes(capacity, H, W)) if (capacity > 0 and checkpoints) else 0
+    total = g + im + b + ck
     buf = _arena(dev, persistent_for_stream, total) if persistent_for_stream is not None else \
         torch.empty(total, dtype=torch.uint8, device=dev)
     base = buf.data_ptr()
@@ -304,6 +317,8 @@ def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=No
     args.scratch[2], args.scratch_bytes[2] = base_al + g, im
     if b:
         args.scratch[1], args.scratch_bytes[1] = base_al + g + im, b
+    if ck:
+        args.scratch[3], args.scratch_bytes[3] = base_al + g + im + b, ck
     return buf, (o, g, o + g, im, o + g + im, b)   # geom off/len, image off/len, binning off/len
 
 
@@ -352,6 +367,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
+        args.backward_checkpoints = 1 if (needs_grad and _USE_CKPT and _last_sparse.get(hint_key, True)) else 0
         prev_dev = torch.cuda.current_device()
         if prev_dev != dev.index:
             torch.cuda.set_device(dev)
@@ -361,7 +377,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if P > 0:
                 # pre-sized scratch, no allocation callbacks: per frame when backward will need it, else the stream's arena
                 scratch = _provide_scratch(args, lib, dev, P, H, W, int(args.binning_capacity_hint),
-                                           None if needs_grad else stream)
+                                           None if needs_grad else stream, bool(args.backward_checkpoints))
             n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), C.c_void_p(stream))
         finally:
             if prev_dev != dev.index:
@@ -373,7 +389,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(n)
         ctx.binning_capacity = int(state.binning_capacity)
         _last_frame_info = (ctx.num_rendered, ctx.binning_capacity)
-        _remember(hint_key, int(n), bool(state.has_long_tiles))
+        _remember(hint_key, int(n), bool(state.has_long_tiles), bool(state.sparse_frame))
         ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P, M)
         ctx.scratch, ctx.bufs = scratch, bufs   # kept alive for backward (and read by _debug_forward_state)
         empty = torch.empty(0, device=dev)
@@ -454,6 +470,7 @@ def _load_cpp():
     if mod.abi_version() != _ABI_VERSION:
         raise RuntimeError("_hgs_torch.so was built against another ABI version; rebuild it")
     mod.use_hints(_USE_HINT)
+    mod.use_checkpoints(_USE_CKPT)
     _cpp = mod
     return mod
 
@@ -511,7 +528,7 @@ class DeferredFrame:
             if n < 0:
                 _raise_last(lib, "rasterize_gaussians (deferred frame)")
         self.num_rendered = int(n)
-        _remember(self.key, int(n), bool(self.state.has_long_tiles))
+        _remember(self.key, int(n), bool(self.state.has_long_tiles), bool(self.state.sparse_frame))
         return self.num_rendered
 
 
@@ -564,7 +581,7 @@ def rasterize_deferred(means3D, opacities, raster_settings, shs=None, colors_pre
             _raise_last(lib, "rasterize_gaussians (deferred)")
         if seen is None:
             f.num_rendered = int(n)
-            _remember(f.key, int(n), bool(f.state.has_long_tiles))
+            _remember(f.key, int(n), bool(f.state.has_long_tiles), bool(f.state.sparse_frame))
     return f
 
 

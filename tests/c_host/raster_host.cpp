@@ -104,6 +104,8 @@ int main(int argc, char** argv)
     bw.dL_dscales = device_buffer<float>(3 * (size_t)P), bw.dL_drotations = device_buffer<float>(4 * (size_t)P);
     bw.dL_dout_color = to_device(dL);
 
+    // with a hint the host also offers the checkpoint buffer of the depth-segmented backward (small frames are sparse frames)
+    a.backward_checkpoints = use_hint ? 1 : 0;
     int64_t N = -1;
     for (int frame = 0; frame < (use_hint ? 2 : 1); ++frame) {   // second frame: capacity guessed from the first
         a.binning_capacity_hint = frame == 0 ? 0 : N + N / 8 + 4096;
@@ -112,8 +114,8 @@ int main(int argc, char** argv)
     }
     if (use_hint == 2) {
         const int64_t cap = N + N / 8 + 4096;
-        const size_t bytes[3] = {hgs_geom_bytes(P, H, W), hgs_binning_bytes(cap, H, W), hgs_image_bytes(H, W)};
-        for (int k = 0; k < 3; ++k) {
+        const size_t bytes[HGS_NUM_BUFS] = {hgs_geom_bytes(P, H, W), hgs_binning_bytes(cap, H, W), hgs_image_bytes(H, W), hgs_ckpt_bytes(cap, H, W)};
+        for (int k = 0; k < HGS_NUM_BUFS; ++k) {
             a.scratch[k] = alloc_cb(nullptr, k, bytes[k]), a.scratch_bytes[k] = bytes[k];
             if (!a.scratch[k]) return fprintf(stderr, "scratch allocation failed\n"), 2;
         }

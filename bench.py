@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--cluster", type=float, default=0.0, help="fraction of the Gaussians in a central blob (not the headline workload)")
     ap.add_argument("--spatial-order", action="store_true", help="store the Gaussians in 3-D Morton order (not the headline workload)")
+    ap.add_argument("--frames-per-rank", type=int, default=1,
+                    help="cameras each rank renders per step (frame f of rank r = camera r * K + f).  BASELINE configs[4] -- 8 frames x "
+                         "300k Gaussians over 8 GPUs -- is `--gpus 8 --gaussians 300000 --frames-per-rank 1`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-frames-in-flight figure")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
@@ -89,16 +92,46 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     log(f"[launcher] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}, backend {backend}")
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out0.decode().splitlines():   # the contract is ONE JSON line on stdout: library chatter goes to stderr
-        if line.startswith("{"):
+    # Watch ALL ranks (what torchrun does): the first one that fails takes the others down with it -- a rank that died in
+    # init would otherwise leave the rest in a collective until the process-group timeout -- and there is an overall deadline.
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("HGS_BENCH_DEADLINE_S", "3600"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = f"rank {r} exited with code {p.returncode}"
+        if failed is None and time.monotonic() > deadline:
+            failed = "deadline (HGS_BENCH_DEADLINE_S) passed"
+        time.sleep(0.05)
+    if failed is None:
+        bad = [r for r, p in enumerate(procs) if p.returncode != 0]
+        failed = f"rank {bad[0]} exited with code {procs[bad[0]].returncode}" if bad else None
+    if failed is not None:
+        log(f"[launcher] {failed}: stopping the other ranks")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    for line in (out0[0] if out0 else b"").decode().splitlines():   # the contract is ONE JSON line on stdout: library chatter goes to stderr
+        if line.startswith("{") and failed is None:
             print(line, flush=True)
         elif line.strip():
             log(line)
-    if any(codes):
+    if failed is not None or any(codes):
         log(f"[launcher] rank exit codes {codes}")
-        raise SystemExit(max(abs(c) for c in codes) or 1)
+        raise SystemExit(max([abs(c) for c in codes if c] + [1]))
 
 
 def launcher_selftest(args, rank, world):
@@ -106,8 +139,13 @@ def launcher_selftest(args, rank, world):
     import torch
     import torch.distributed as dist
     from hugs_amd import sharding
+    if os.environ.get("HGS_SELFTEST_FAIL_RANK") == str(rank):   # tests/test_bench_launcher.py: a rank that dies before the rendezvous
+        raise SystemExit(7)
+    if os.environ.get("HGS_SELFTEST_HANG_RANK") == str(rank):   # ... and one that never comes back (the launcher's deadline)
+        time.sleep(3600)
     if world > 1:
-        dist.init_process_group("gloo")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("HGS_BENCH_INIT_TIMEOUT_S", "120"))))
     ids = sharding.gather_frame_metrics([rank], [[float(rank), float(os.getpid())]], world, device=torch.device("cpu"))
     slowest = sharding.max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
     if rank == 0:
@@ -132,19 +170,32 @@ def host_cpu():
 
 
 def measured_copy_peak(torch, device, nbytes=1 << 30, reps=10):
-    """Device-to-device copy rate (read + write bytes / time) of this GPU, now: the practical HBM ceiling next to the
-    datasheet figure."""
+    """Device-to-device copy rates (read + write bytes / time) of this GPU, now -- the practical HBM ceiling next to the
+    datasheet figure: (the library's float4 grid-stride copy kernel -- the shape MI355X_MICROARCH.md measures 6.29 TB/s
+    with --, torch's Tensor.copy_)."""
+    import ctypes
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
     b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    e1.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)   # the events below are recorded on the same stream
+
+    def rate(copy):
+        for _ in range(3):
+            copy()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            copy()
+        e1.record()
+        e1.synchronize()
+        return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    def lib_copy():
+        if lib.hgs_copy_bandwidth(b.data_ptr(), a.data_ptr(), nbytes, stream) < 0:
+            raise RuntimeError(lib.hgs_last_error().decode())
+
+    return rate(lib_copy), rate(lambda: b.copy_(a))
 
 
 def main():
@@ -170,10 +221,12 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("HGS_BENCH_INIT_TIMEOUT_S", "300")))  # a dead sibling must not hang the rest
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     log(f"[rank {rank}] world_size {dist.get_world_size() if world > 1 else 1} ({backend if world > 1 else 'single process'}), "
         f"device {device} = {torch.cuda.get_device_name(device)}")
 
@@ -188,11 +241,18 @@ def main():
         from hugs_amd.spatial import morton_order
         order = morton_order(g["means3D"])
         g = {k: (v[order] if isinstance(v, np.ndarray) and v.shape[:1] == (P,) else v) for k, v in g.items()}
-    # frame r of the batch: the same scene seen from a slightly yawed camera (frame 0 = identity pose)
-    yaw = math.radians(1.5) * rank
-    w2c = np.eye(4)
-    w2c[0, 0], w2c[0, 2], w2c[2, 0], w2c[2, 2] = math.cos(yaw), math.sin(yaw), -math.sin(yaw), math.cos(yaw)
-    cam = syn.camera_from_w2c(w2c, cam0["fovx"], cam0["fovy"], H, W)
+    # frame k of the batch: the same scene seen from a slightly yawed camera (frame 0 = identity pose); rank r renders
+    # frames r * K .. r * K + K - 1 every step (hugs_amd.sharding: frames are independent, no data-path collective)
+    KF = max(1, args.frames_per_rank)
+
+    def camera_of(frame):
+        yaw = math.radians(1.5) * frame
+        w2c = np.eye(4)
+        w2c[0, 0], w2c[0, 2], w2c[2, 0], w2c[2, 2] = math.cos(yaw), math.sin(yaw), -math.sin(yaw), math.cos(yaw)
+        return syn.camera_from_w2c(w2c, cam0["fovx"], cam0["fovy"], H, W)
+
+    cams = [camera_of(rank * KF + f) for f in range(KF)]
+    cam = cams[0]
     dL = syn.pixel_grad(H, W)
 
     dev = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
@@ -201,21 +261,24 @@ def main():
         sharding.broadcast_gaussians([v.data for v in t.values()])  # replicas of rank 0's Gaussians (same seed anyway)
     means2D = torch.zeros(P, 3, device=device, requires_grad=True)
     dLd = dev(dL)
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5),
-        bg=torch.ones(3, device=device), scale_modifier=1.0, viewmatrix=dev(cam["world_view_transform"]),
-        projmatrix=dev(cam["full_proj_transform"]), sh_degree=D, campos=dev(cam["camera_center"]),
-        prefiltered=False, debug=False)
+    bg_white = torch.ones(3, device=device)
+    all_settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(c["fovx"] * 0.5), tanfovy=math.tan(c["fovy"] * 0.5),
+        bg=bg_white, scale_modifier=1.0, viewmatrix=dev(c["world_view_transform"]),
+        projmatrix=dev(c["full_proj_transform"]), sh_degree=D, campos=dev(c["camera_center"]),
+        prefiltered=False, debug=False) for c in cams]
+    settings = all_settings[0]
     leaves = list(t.values()) + [means2D]
 
     def step():
-        rast = GaussianRasterizer(raster_settings=settings)  # a new module per call, as the reference does
-        color, radii = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
-                            scales=t["scales"], rotations=t["rotations"])
-        if not args.forward_only:
-            color.backward(dLd)
-            for x in leaves:
-                x.grad = None
+        for st_ in all_settings:   # this rank's K frames
+            rast = GaussianRasterizer(raster_settings=st_)  # a new module per call, as the reference does
+            color, radii = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                                scales=t["scales"], rotations=t["rotations"])
+            if not args.forward_only:
+                color.backward(dLd)
+                for x in leaves:
+                    x.grad = None
         return color, radii
 
     def fence():
@@ -227,9 +290,11 @@ def main():
         step()
     # (forward-only: the forward blend runs fused with the tile sort, stage "sort" = tile_sort_small_kernel)
     dominant = "sort" if args.forward_only else "blend_backward"
-    # live HIP-event timing of the dominant kernel over the timed region, on every 8th launch (an event pair costs ~5 us of
-    # GPU time around the kernel it brackets: timing every launch took 2 % off the throughput it was measured beside)
-    profile_enable((dominant,), every_nth=8)
+    # live HIP-event timing of the dominant kernel over the timed region: on every 8th launch of a long run (an event pair
+    # costs ~5 us of GPU time around the kernel it brackets: timing every launch took 2 % off the throughput it was measured
+    # beside), on EVERY launch of a short one so that at least 16 launches are timed whenever --steps >= 16
+    every_nth = max(1, min(8, args.steps * KF // 16))
+    profile_enable((dominant,), every_nth=every_nth)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -239,6 +304,7 @@ def main():
     prof = profile_read()
     profile_enable(())
     coll_dev = device if backend == "nccl" else torch.device("cpu")  # where the tiny metric collectives run
+    own_elapsed = elapsed   # this rank's own clock over the bracket (a straggler shows in per_rank_fps)
     elapsed = sharding.max_over_ranks(elapsed, coll_dev)
 
     # exact integers of this frame (shared with the oracle): N and the visible count
@@ -249,8 +315,9 @@ def main():
         from diff_gaussian_rasterization import _debug_forward_state
         N = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
                                  scales=t["scales"].detach(), rotations=t["rotations"].detach())[2]["N"]
-    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv), float(device.index), 1.0]], world, device=coll_dev)
-    copy_peak = measured_copy_peak(torch, device) if rank == 0 else None
+    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv), float(device.index), 1.0, KF * args.steps / own_elapsed]],
+                                           world, device=coll_dev)
+    copy_peak, torch_copy_peak = measured_copy_peak(torch, device) if rank == 0 else (None, None)
 
     # per-stage breakdown in a separate, untimed pass (every stage bracketed by events)
     profile_enable()
@@ -291,24 +358,31 @@ def main():
     dom_ms = prof[dominant][0] / prof[dominant][1]
     dom_B = fwd_B + 28 * N if args.forward_only else bwd_B   # fused tile sort + forward blend: + keys in, list and compacted lists out
     achieved = dom_B / (dom_ms * 1e-3) / 1e9
-    fps = world * args.steps / elapsed
+    fps = world * KF * args.steps / elapsed
     out = {
         "metric": "rasterizer fwd+bwd FPS @1080p vs #Gaussians; achieved HBM GB/s vs peak",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks_seen": int(frames[:, 3].sum()), "rank_devices": [int(x) for x in frames[:, 2].tolist()],
-        "config": {"workload": f"configs[1]: {P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
+        "per_rank_fps": [round(float(x), 2) for x in frames[:, 4].tolist()],   # each rank's own clock: a straggler is visible here
+        "config": {"workload": f"{'configs[1]' if (P, KF) == (200_000, 1) else ('configs[4] (frame batch)' if P == 300_000 else 'sweep point')}: "
+                               f"{P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
                                f"{'forward only' if args.forward_only else 'forward+backward'} through "
-                               "GaussianRasterizer (drop-in API), one camera per GPU",
+                               f"GaussianRasterizer (drop-in API), {KF} camera(s) per GPU and step",
+                   "frames_per_rank": KF, "frames_per_step_all_ranks": world * KF,
                    "gaussians": P, "visible": Pv, "num_rendered_N": int(N), "tiles": T,
                    "N_per_frame_all_ranks": [int(x) for x in frames[:, 0].tolist()]},
         "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dominant], "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                      "peak_measured": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
-                     "peak_measured_how": "1 GiB device-to-device copy_ on this GPU in this run, (read + write bytes) / time",
+                     "peak_measured_how": "1 GiB device-to-device float4 grid-stride copy kernel (hgs_copy_bandwidth) on this GPU in "
+                                          "this run, (read + write bytes) / time; peak_torch_copy = the same with Tensor.copy_",
+                     "peak_torch_copy": round(torch_copy_peak, 1),
                      "traffic": None, "algorithmic_bytes_per_launch": int(dom_B),
-                     "avg_launch_ms": round(dom_ms, 4), "launches_timed": prof[dominant][1],
+                     "avg_launch_ms": round(dom_ms, 4), "launches_timed": prof[dominant][1], "timed_every_nth_launch": every_nth,
+                     "avg_launch_note": "HIP events on the launch stream around the kernel, inside the timed region; the event pair "
+                                        "itself adds ~1-2 % to the figure (rocprofv3's kernel trace in profiles/ is the event-free one)",
                      "note": "north_star's '>= 60 % of the HBM roofline' is structurally unreachable for the two blend kernels: "
                              "they do ~256 pixel-splat evaluations per 40-byte list entry and are VALU-issue bound (see "
                              "valu_issue.busy_frac) with HBM mostly idle; the per-Gaussian kernels (K1, K8) are the ones on the "
@@ -318,6 +392,8 @@ def main():
                         "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
         "stages_ms": stages,
+        "stages_ms_note": "separate untimed pass with an event pair around EVERY stage: each pair costs a few microseconds of GPU "
+                          "time, so the sum exceeds ms_per_step",
     }
     if fps_two_streams is not None:
         out["two_frames_in_flight"] = {"value": round(fps_two_streams, 2), "unit": "frames/s",

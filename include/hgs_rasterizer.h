@@ -251,6 +251,10 @@ int32_t hgs_profile_read(int32_t stage, double *total_ms, int64_t *launches);
 void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);
 
+/* Measurement aid: one float4 grid-stride device-to-device copy of `bytes` (a multiple of 16) on `stream` -- bench.py times
+ * it with events for `roofline.peak_measured`, the practical HBM ceiling of the GPU it runs on. */
+int32_t hgs_copy_bandwidth(void *dst, const void *src, size_t bytes, void *stream);
+
 /* Test/debug introspection: byte offsets of the named sub-arrays inside the scratch buffers.
  * Names: geom: "splats" (64-byte records), "tiles_touched"; binning: "list" (the sorted list, one u64 per entry:
  * (1-based position inside the tile << 32) | quad coverage mask << 28 | Gaussian index);

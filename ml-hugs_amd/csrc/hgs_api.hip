@@ -529,6 +529,23 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     return HGS_OK;
 }
 
+// Measurement aid (bench.py's `roofline.peak_measured`): a float4 grid-stride copy, the kernel shape the microarchitecture
+// guide measures the practical HBM ceiling with.  bytes must be a multiple of 16; src and dst 16-byte aligned.
+__global__ void __launch_bounds__(256) copy_bandwidth_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+
+int32_t hgs_copy_bandwidth(void* dst, const void* src, size_t bytes, void* stream)
+{
+    if (!dst || !src || (bytes & 15u) || (((uintptr_t)dst | (uintptr_t)src) & 15u)) return fail(HGS_ERR_INVALID_ARGUMENT, "bad arguments");
+    // 256 CUs x 8 workgroups of four waves: every SIMD holds eight waves of loads in flight
+    hipLaunchKernelGGL(copy_bandwidth_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float4*)dst, (const float4*)src, bytes / 16);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HGS_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(e));
+    return HGS_OK;
+}
+
 int32_t hgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present, void* stream)
 {
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(HGS_ERR_INVALID_ARGUMENT, "bad arguments");

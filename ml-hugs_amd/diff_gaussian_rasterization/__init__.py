@@ -104,6 +104,8 @@ def _load():
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+    lib.hgs_copy_bandwidth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.hgs_copy_bandwidth.restype = C.c_int32
     lib.hgs_profile_enable.argtypes = [C.c_uint32]
     lib.hgs_profile_enable.restype = None
     lib.hgs_profile_reset.restype = None

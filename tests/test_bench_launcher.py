@@ -36,3 +36,19 @@ def test_rccl_mode_refuses_more_ranks_than_gpus():
     quietly measuring fewer ranks."""
     r = run(["--gpus", "2"])
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_a_rank_that_dies_takes_the_others_down_promptly():
+    """the launcher used to wait on rank 0 only -- with rank 1 dead before the rendezvous, rank 0 sat in
+    init_process_group until the process-group timeout.  Now every rank is watched, as torchrun does."""
+    import time
+    t0 = time.monotonic()
+    r = run(["--gpus", "2", "--launcher-selftest"], {"HGS_SELFTEST_FAIL_RANK": "1", "HGS_BENCH_INIT_TIMEOUT_S": "600"}, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "rank 1 exited with code 7" in r.stderr and "stopping the other ranks" in r.stderr
+    assert time.monotonic() - t0 < 60.0
+
+
+def test_launcher_deadline():
+    r = run(["--gpus", "2", "--launcher-selftest"], {"HGS_SELFTEST_HANG_RANK": "1", "HGS_BENCH_DEADLINE_S": "8"}, timeout=120)
+    assert r.returncode != 0 and "deadline" in r.stderr and r.stdout.strip() == ""

@@ -62,4 +62,10 @@ def main(P=110_210, steps=200, warmup=20):
 
 
 if __name__ == "__main__":
-    main()
+    # HGS_BENCH_STEPS: short runs under the PMC passes of profiles/collect_workload.sh; an optional argument = P of the human
+    kw = {}
+    if os.environ.get("HGS_BENCH_STEPS"):
+        kw = {"steps": int(os.environ["HGS_BENCH_STEPS"]), "warmup": 3}
+    if len(sys.argv) > 1:
+        kw["P"] = int(sys.argv[1])
+    main(**kw)

@@ -70,4 +70,8 @@ def main(steps=100, warmup=15):
 
 
 if __name__ == "__main__":
-    main()
+    # HGS_BENCH_STEPS: short runs under the PMC passes of profiles/collect_workload.sh; an optional argument = P of the human
+    kw = {}
+    if os.environ.get("HGS_BENCH_STEPS"):
+        kw = {"steps": int(os.environ["HGS_BENCH_STEPS"]), "warmup": 3}
+    main(**kw)

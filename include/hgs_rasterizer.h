@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 6
+#define HGS_ABI_VERSION 7
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
@@ -71,6 +71,24 @@ typedef struct hgs_settings {
     int32_t debug;           /* !=0: synchronise + check after every stage */
 } hgs_settings;
 
+/* An optional SECOND set of Gaussians rendered together with the first: the reference's joint human + scene render
+ * concatenates five tensors per training step (/root/reference/hugs/renderer/gs_renderer.py:33-37: human first, scene
+ * second) and autograd splits their gradients again on the way back; with a second segment the two models' tensors are
+ * read -- and their gradients written -- in place.  Gaussian index = P + i for the i-th Gaussian of the segment, so every
+ * index-dependent result (sorted list, radii, dL/dmeans2D) is exactly what the concatenated call produces.  Same kinds
+ * of inputs as the first set (SHs or precomputed colours; scales + rotations or precomputed covariances); M may differ. */
+typedef struct hgs_segment {
+    int32_t P;                   /* 0: no second segment */
+    int32_t M;
+    const float *means3D;        /* [P,3] */
+    const float *shs;            /* [P,M,3] or NULL */
+    const float *colors_precomp; /* [P,3] or NULL */
+    const float *opacities;      /* [P] */
+    const float *scales;         /* [P,3] or NULL */
+    const float *rotations;      /* [P,4] or NULL */
+    const float *cov3D_precomp;  /* [P,6] or NULL */
+} hgs_segment;
+
 /* Inputs/outputs of the forward pass == kwargs of GaussianRasterizer.forward at
  * gs_renderer.py:144-152 plus the two outputs (rendered_image, radii). */
 typedef struct hgs_forward_args {
@@ -85,7 +103,7 @@ typedef struct hgs_forward_args {
     const float *rotations;      /* [P,4] (w,x,y,z), not normalised, or NULL */
     const float *cov3D_precomp;  /* [P,6] or NULL (exactly one of (scales,rotations) / cov3D_precomp) */
     float *out_color;            /* [3,H,W], written for every pixel when P > 0 */
-    int32_t *radii;              /* [P] */
+    int32_t *radii;              /* [P (+ seg2.P)] */
     /* Optional guess (entries) of N, the number of (tile, Gaussian) pairs -- e.g. last frame's N plus a margin; 0 =
      * none.  With a guess the binning buffer is allocated and the whole frame enqueued before N is known, so the GPU
      * never waits for the host; if the frame needs more than the guess, binning + blending are enqueued again with
@@ -122,6 +140,7 @@ typedef struct hgs_forward_args {
      * scratch_bytes[k] suffices, otherwise the allocation callback is asked as usual.  256-byte aligned device pointers. */
     void *scratch[4];
     size_t scratch_bytes[4];
+    hgs_segment seg2;            /* optional second set of Gaussians (all zero: none); scratch / hint sizes count P + seg2.P */
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -159,6 +178,15 @@ typedef struct hgs_backward_args {
     float *dL_dsh;              /* [P,M,3] or NULL */
     float *dL_dscales;          /* [P,3] */
     float *dL_drotations;       /* [P,4] */
+    /* With fwd.seg2: grad_accum and dL_dmeans2D cover all P + seg2.P Gaussians (one viewspace tensor, as the reference's
+     * joint render has); the seven per-input gradients of the second segment go to its own buffers: */
+    float *seg2_dL_dopacity;    /* [P2] */
+    float *seg2_dL_dcolors;     /* [P2,3] */
+    float *seg2_dL_dmeans3D;    /* [P2,3] */
+    float *seg2_dL_dcov3D;      /* [P2,6] */
+    float *seg2_dL_dsh;         /* [P2,M2,3] or NULL */
+    float *seg2_dL_dscales;     /* [P2,3] */
+    float *seg2_dL_drotations;  /* [P2,4] */
 } hgs_backward_args;
 
 int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);

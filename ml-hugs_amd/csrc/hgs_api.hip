@@ -207,8 +207,22 @@ int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
 int make_camera(const hgs_forward_args& a, Camera& cam)
 {
     const hgs_settings& s = a.s;
-    if (a.P < 0) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be >= 0");
-    if ((uint32_t)a.P > GID_MASK / 4u) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be < 2^26 (index packing / 32-bit record offsets)");
+    if (a.P < 0 || a.seg2.P < 0) return fail(HGS_ERR_INVALID_ARGUMENT, "P must be >= 0");
+    if ((uint64_t)a.P + (uint64_t)a.seg2.P > GID_MASK / 4u)
+        return fail(HGS_ERR_INVALID_ARGUMENT, "P must be < 2^26 (index packing / 32-bit record offsets)");
+    if (a.seg2.P > 0) {
+        // the second segment holds the same KINDS of inputs as the first (the kernels choose the array set per Gaussian)
+        const hgs_segment& b = a.seg2;
+        if (a.P == 0) return fail(HGS_ERR_INVALID_ARGUMENT, "a second segment needs a non-empty first one (pass the Gaussians as the first)");
+        if (!b.means3D || !b.opacities) return fail(HGS_ERR_INVALID_ARGUMENT, "seg2: means3D and opacities are required");
+        if ((b.shs != nullptr) != (a.shs != nullptr) || (b.colors_precomp != nullptr) != (a.colors_precomp != nullptr) ||
+            (b.scales != nullptr) != (a.scales != nullptr) || (b.rotations != nullptr) != (a.rotations != nullptr) ||
+            (b.cov3D_precomp != nullptr) != (a.cov3D_precomp != nullptr))
+            return fail(HGS_ERR_INVALID_ARGUMENT, "seg2 must provide the same kinds of inputs as the first segment");
+        if (b.shs && b.M < (s.sh_degree + 1) * (s.sh_degree + 1))
+            return fail(HGS_ERR_INVALID_ARGUMENT, "seg2.shs holds %d coefficients, degree %d needs %d", b.M, s.sh_degree,
+                        (s.sh_degree + 1) * (s.sh_degree + 1));
+    }
     if (s.image_height <= 0 || s.image_width <= 0) return fail(HGS_ERR_INVALID_ARGUMENT, "image size must be positive");
     if (a.P > 0 && !a.means3D) return fail(HGS_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
     if (!s.bg || !s.viewmatrix || !s.projmatrix || !s.campos)
@@ -313,7 +327,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const bool want_ckpt = a.backward_checkpoints != 0 && seg_allowed;
 
     const int num_tiles = cam.gx * cam.gy;
-    GeomLayout gl(a.P, num_tiles);
+    const int Ptot = a.P + a.seg2.P;  // Gaussian indices run over both segments
+    GeomLayout gl(Ptot, num_tiles);
     ImageLayout il(cam.H, cam.W);
     // caller-provided scratch when it suffices, else the allocation callback
     auto obtain = [&](int which, size_t bytes) -> char* {
@@ -330,7 +345,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     Splat* splats = (Splat*)(geom + gl.splats);
     uint32_t* tiles_touched = (uint32_t*)(geom + gl.tiles_touched);
     // the preprocess kernel counts pairs per tile itself when the tile array fits LDS (any frame up to ~7 Mpixel)
-    const int group = bin_group_for(a.P, num_tiles);
+    const int group = bin_group_for(Ptot, num_tiles);
     const int num_cells = num_cells_of(cam.gx, cam.gy);
     uint32_t* run_start = group ? (uint32_t*)(geom + gl.run_start) : nullptr;
     uint2* cell_slot = (uint2*)(geom + gl.cell_slot);
@@ -345,7 +360,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
     const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
     if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_index)) return rc;
-    int bin_mode = bin_mode_for(a.P, num_tiles, num_cells, group);
+    int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
     if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr)
         bin_mode = (e[0] == 'c' && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : e[0] == 'o' ? BIN_IN_ORDER : bin_mode;
@@ -361,8 +376,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
     { ProfScope ps(HGS_STAGE_SCAN, st);
-      if (bin_mode == BIN_BY_CELL) launch_spatial_groups(a.P, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
-      else if (bin_mode == BIN_NONE) launch_count(a.P, cam, splats, tile_count, st);
+      if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
+      else if (bin_mode == BIN_NONE) launch_count(Ptot, cam, splats, tile_count, st);
       launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
                        want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
@@ -376,7 +391,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     static const bool fused = [] { const char* e = getenv("HGS_FUSED_SORT_BLEND"); return !(e && e[0] == '0'); }();
     float* final_T = (float*)(image + il.final_T);
     uint32_t* n_contrib = (uint32_t*)(image + il.n_contrib);
-    FusedBlend fb{cam, (uint32_t)(a.P - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0, Ckpt{}};
+    FusedBlend fb{cam, (uint32_t)(Ptot - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0, Ckpt{}};
     // checkpoints for the depth-segmented backward: laid out for the same capacity as the binning buffer
     bool known_dense = false;  // (set once N and the frame's flags are known: a dense frame needs no checkpoint buffer)
     auto obtain_ckpt = [&](int64_t capacity) -> int {
@@ -398,7 +413,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
                            bl.act_stride, act_count, large_tiles, n_total, false, true, nullptr, st); }
         STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-          launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
+          launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
                                a.clamp_output != 0, large_tiles, n_total + 2, fb.ck, st); }
         STAGE_CHECK(dbg, st, "blend_forward (long tiles)");
         return HGS_OK;
@@ -413,7 +428,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(a.P, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
+        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(Ptot, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total,
@@ -422,7 +437,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         if (!fused) {
             // (when the long-tile sort was skipped, long tiles read as empty here: they are blended by the repair)
             { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-              launch_blend_forward(cam, a.P, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
+              launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
                                    a.clamp_output != 0, nullptr, nullptr, fb.ck, st); }
             STAGE_CHECK(dbg, st, "blend_forward");
         }
@@ -500,7 +515,11 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
         !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
         return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");
     const bool dbg = f.s.debug != 0;
-    GeomLayout gl(f.P, cam.gx * cam.gy);
+    const int Ptot = f.P + f.seg2.P;
+    if (f.seg2.P > 0 && (!a.seg2_dL_dopacity || !a.seg2_dL_dcolors || !a.seg2_dL_dmeans3D || !a.seg2_dL_dcov3D || !a.seg2_dL_dscales ||
+                         !a.seg2_dL_drotations || (f.seg2.shs && !a.seg2_dL_dsh)))
+        return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers of the second segment are required");
+    GeomLayout gl(Ptot, cam.gx * cam.gy);
     ImageLayout il(cam.H, cam.W);
     BinningLayout bl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered);
     if (a.state.geom_bytes < gl.total || a.state.image_bytes < il.total || a.state.binning_bytes < bl.total)
@@ -519,7 +538,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
-      launch_blend_backward(cam, f.P, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
+      launch_blend_backward(cam, Ptot, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
                             bl.act_stride, (const uint32_t*)(image + il.act_count), a.state.sparse_frame != 0, splats,
                             f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
                             a.grad_accum, ck, a.state.num_rendered, st); }

@@ -136,12 +136,22 @@ __device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __rest
 //   ONE returning atomic per touched tile on the global per-tile counters -- the value returned is where this group's run
 //   starts inside the tile's segment -- and leaves it in run_start[group][tile] for emit.
 // BIN_NONE: no binning work (very large tile counts: count_kernel / emit_kernel<false> on global atomics).
+// A second set of Gaussians behind the first (hgs_segment): Gaussian i >= P1 is element i - P1 of these arrays.  The
+// kernels pick the array set per thread -- a handful of selects -- and index it with the segment-local index.
+struct SecondInputs {
+    int P1, M;  // Gaussians in the first set (== P when there is no second one); SH coefficients stored per Gaussian of the second
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rots, *cov3D_precomp;
+};
+struct SecondGrads {
+    float *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dcov3D;
+};
+
 template <int MODE>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256
 __global__ void __launch_bounds__(MODE != BIN_NONE ? BIN_GROUP : 256)
-preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
-                  const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
-                  const float* __restrict__ scales, const float* __restrict__ rots,
-                  const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
+preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
+                  const float* __restrict__ colors_precomp_, const float* __restrict__ opacities_,
+                  const float* __restrict__ scales_, const float* __restrict__ rots_,
+                  const float* __restrict__ cov3D_precomp_, SecondInputs in2, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
                   uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
                   uint32_t* __restrict__ counters, uint2* __restrict__ cell_slot, uint32_t* __restrict__ run_start,
@@ -173,7 +183,18 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
 
     bool alive = false;
     if (i < P) {
-        const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+        // which set of input arrays this Gaussian lives in, and its index there
+        const bool second = i >= in2.P1;
+        const size_t j = (size_t)(second ? i - in2.P1 : i);
+        const float* means3D = second ? in2.means3D : means3D_;
+        const float* shs = second ? in2.shs : shs_;
+        const float* colors_precomp = second ? in2.colors_precomp : colors_precomp_;
+        const float* opacities = second ? in2.opacities : opacities_;
+        const float* scales = second ? in2.scales : scales_;
+        const float* rots = second ? in2.rots : rots_;
+        const float* cov3D_precomp = second ? in2.cov3D_precomp : cov3D_precomp_;
+        const int M = second ? in2.M : cam.M;
+        const float x = means3D[3 * j], y = means3D[3 * j + 1], z = means3D[3 * j + 2];
         float pv[3];
         pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
         pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
@@ -189,9 +210,9 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
             float S[6];
             if (cov3D_precomp) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * (size_t)i + k];
+                for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * j + k];
             } else {
-                cov3d_from_scale_rot(scales + 3 * (size_t)i, cam.mod, rots + 4 * (size_t)i, S);
+                cov3d_from_scale_rot(scales + 3 * j, cam.mod, rots + 4 * j, S);
             }
             Ewa e;
             ewa_project(pv, cam, V, S, e);
@@ -226,7 +247,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                     out.la = sqrtf(-out.ca);
                     out.lb = (-0.5f * out.cb) / out.la;
                     out.lc = sqrtf((0.5f * LOG2E) / e.c);
-                    out.log2_opacity = __log2f(opacities[i]);
+                    out.log2_opacity = __log2f(opacities[j]);
                     out.depth = pv[2];
                     out.radius = (int32_t)radf;
                     touched = (uint32_t)((maxx - minx) * (maxy - miny));
@@ -237,7 +258,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                         dx = dx / len, dy = dy / len, dz = dz / len;
                         float B[16];
                         sh_basis(cam.D, dx, dy, dz, B);
-                        const float* sh = shs + (size_t)i * cam.M * 3;
+                        const float* sh = shs + j * M * 3;
                         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
                         // the number of coefficients is a compile-time constant inside each case, so all their loads are
                         // issued before the first is waited for (a runtime trip count made it one round trip per coefficient)
@@ -251,8 +272,8 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
                         out.clamped = (acc0 < 0.0f ? 1u : 0u) | (acc1 < 0.0f ? 2u : 0u) | (acc2 < 0.0f ? 4u : 0u);
                         out.r = fmaxf(acc0, 0.0f), out.g = fmaxf(acc1, 0.0f), out.b = fmaxf(acc2, 0.0f);
                     } else {
-                        out.r = colors_precomp[3 * (size_t)i], out.g = colors_precomp[3 * (size_t)i + 1];
-                        out.b = colors_precomp[3 * (size_t)i + 2];
+                        out.r = colors_precomp[3 * j], out.g = colors_precomp[3 * j + 1];
+                        out.b = colors_precomp[3 * j + 2];
                     }
                 }
             }
@@ -314,17 +335,20 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D, const fl
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched, int mode,
                        uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, hipStream_t st)
 {
-#define HGS_K1_ARGS a.P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.s.viewmatrix, \
+    const int P = a.P + a.seg2.P;
+    const SecondInputs in2{a.P, a.seg2.M, a.seg2.means3D, a.seg2.shs, a.seg2.colors_precomp, a.seg2.opacities, a.seg2.scales,
+                           a.seg2.rotations, a.seg2.cov3D_precomp};
+#define HGS_K1_ARGS P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, in2, a.s.viewmatrix, \
                     a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii
     if (mode == BIN_BY_CELL)
-        hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((a.P + group - 1) / group), dim3(group),
+        hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((P + group - 1) / group), dim3(group),
                            2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy), st, HGS_K1_ARGS, counters, cell_slot, nullptr,
                            (float4*)a.grad_accum_to_zero);
     else if (mode == BIN_IN_ORDER)
-        hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((a.P + group - 1) / group), dim3(group),
+        hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((P + group - 1) / group), dim3(group),
                            sizeof(uint32_t) * cam.gx * cam.gy, st, HGS_K1_ARGS, counters, nullptr, run_start, (float4*)a.grad_accum_to_zero);
     else
-        hipLaunchKernelGGL(preprocess_kernel<BIN_NONE>, dim3((a.P + 255) / 256), dim3(256), 0, st, HGS_K1_ARGS, nullptr, nullptr,
+        hipLaunchKernelGGL(preprocess_kernel<BIN_NONE>, dim3((P + 255) / 256), dim3(256), 0, st, HGS_K1_ARGS, nullptr, nullptr,
                            nullptr, (float4*)a.grad_accum_to_zero);
 #undef HGS_K1_ARGS
 }
@@ -333,18 +357,36 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // K8+K9 fused: one thread per Gaussian, only radius > 0 does work; every output element is written here (zeros for
 // culled Gaussians and SH coefficients above the active degree), the caller pre-zeroes nothing.
 __global__ void __launch_bounds__(256)
-preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D, const float* __restrict__ shs,
-                           const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rots,
-                           const float* __restrict__ cov3D_precomp, const float* __restrict__ V,
+preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
+                           const float* __restrict__ opacities_, const float* __restrict__ scales_, const float* __restrict__ rots_,
+                           const float* __restrict__ cov3D_precomp_, SecondInputs in2, const float* __restrict__ V,
                            const float* __restrict__ F, const float* __restrict__ campos,
                            const Splat* __restrict__ splats, const float* __restrict__ grad_accum,
-                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
-                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D,
-                           float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-                           float* __restrict__ dL_dcov3D)
+                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity_,
+                           float* __restrict__ dL_dcolors_, float* __restrict__ dL_dmeans3D_,
+                           float* __restrict__ dL_dsh_, float* __restrict__ dL_dscale_, float* __restrict__ dL_drot_,
+                           float* __restrict__ dL_dcov3D_, SecondGrads out2)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    // the set of arrays (inputs and gradients) this Gaussian lives in, and its index there; the accumulator, the splat
+    // record and dL/dmean2D are indexed by the joint index i
+    const bool second = i >= in2.P1;
+    const size_t j = (size_t)(second ? i - in2.P1 : i);
+    const float* means3D = second ? in2.means3D : means3D_;
+    const float* shs = second ? in2.shs : shs_;
+    const float* opacities = second ? in2.opacities : opacities_;
+    const float* scales = second ? in2.scales : scales_;
+    const float* rots = second ? in2.rots : rots_;
+    const float* cov3D_precomp = second ? in2.cov3D_precomp : cov3D_precomp_;
+    float* dL_dopacity = second ? out2.dL_dopacity : dL_dopacity_;
+    float* dL_dcolors = second ? out2.dL_dcolors : dL_dcolors_;
+    float* dL_dmeans3D = second ? out2.dL_dmeans3D : dL_dmeans3D_;
+    float* dL_dsh = second ? out2.dL_dsh : dL_dsh_;
+    float* dL_dscale = second ? out2.dL_dscale : dL_dscale_;
+    float* dL_drot = second ? out2.dL_drot : dL_drot_;
+    float* dL_dcov3D = second ? out2.dL_dcov3D : dL_dcov3D_;
+    const int M = second ? in2.M : cam.M;
     // accumulator record written by the blend-backward atomics, raw moments of u = G dL/dalpha over the pixels:
     //   sum u dx, sum u dy, sum u dx^2, sum u dx dy | sum u dy^2, sum u, dL/dr, dL/dg | dL/db - - -
     // with u = opacity G dL/dalpha (the uncapped alpha times dL/dalpha).  Turned here, once per Gaussian, into
@@ -358,7 +400,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         const float4 hc = reinterpret_cast<const float4*>(splats + i)[3];   // the half-conic quarter of the record
         const bool live = __float_as_int(reinterpret_cast<const float4*>(splats + i)[2].z) > 0;  // else: record unset
         const float A = live ? hc.x * LN2 : 0.0f, B = live ? hc.y * LN2 : 0.0f, C = live ? hc.z * LN2 : 0.0f;
-        const float op = live ? opacities[i] : 0.0f;
+        const float op = live ? opacities[j] : 0.0f;
         const float sx = acc0.x, sy = acc0.y;
         acc0.x = (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);
         acc0.y = (0.5f * (float)cam.H) * (2.0f * C * sy + B * sx);
@@ -366,24 +408,24 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         acc1.y = op > 0.0f ? acc1.y / op : 0.0f;  // sum of G dL/dalpha
     }
     dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
-    dL_dopacity[i] = acc1.y;
-    dL_dcolors[3 * (size_t)i] = acc1.z, dL_dcolors[3 * (size_t)i + 1] = acc1.w, dL_dcolors[3 * (size_t)i + 2] = acc_b;
+    dL_dopacity[j] = acc1.y;
+    dL_dcolors[3 * j] = acc1.z, dL_dcolors[3 * j + 1] = acc1.w, dL_dcolors[3 * j + 2] = acc_b;
 
     const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
     if (__float_as_int(tail.z) <= 0) {
         // every output is fully written by this kernel (the caller does not pre-zero them)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = 0.0f, dL_dscale[3 * (size_t)i + k] = 0.0f;
-        reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * j + k] = 0.0f, dL_dscale[3 * j + k] = 0.0f;
+        reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = 0.0f;
         if (shs)
-            for (int k = 0; k < 3 * cam.M; ++k) dL_dsh[(size_t)i * cam.M * 3 + k] = 0.0f;
+            for (int k = 0; k < 3 * M; ++k) dL_dsh[j * M * 3 + k] = 0.0f;
         return;
     }
     const uint32_t clamped = __float_as_uint(tail.w);
 
-    const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+    const float x = means3D[3 * j], y = means3D[3 * j + 1], z = means3D[3 * j + 2];
     float pv[3];
     pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
     pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
@@ -391,9 +433,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
     float S[6];
     if (cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * (size_t)i + k];
+        for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * j + k];
     } else {
-        cov3d_from_scale_rot(scales + 3 * (size_t)i, cam.mod, rots + 4 * (size_t)i, S);
+        cov3d_from_scale_rot(scales + 3 * j, cam.mod, rots + 4 * j, S);
     }
     Ewa e;
     ewa_project(pv, cam, V, S, e);
@@ -415,7 +457,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         dS[4] = 2.0f * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2.0f * e.T11 * e.T12 * dL_dc;
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = dS[k];
 
     // dL/dT (2x3) -> dL/dJ -> dL/dt (view-space mean), with the frustum-clamp masks (A.6 quirk 2)
     float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
@@ -463,8 +505,8 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         float len = sqrtf(vx * vx + vy * vy + vz * vz);
         float X = vx / len, Y = vy / len, Z = vz / len;
         const int D = cam.D;
-        const float* sh = shs + (size_t)i * cam.M * 3;
-        float* dsh = dL_dsh + (size_t)i * cam.M * 3;
+        const float* sh = shs + j * M * 3;
+        float* dsh = dL_dsh + j * M * 3;
         float B[16];
         sh_basis(D, X, Y, Z, B);
         const int K = (D + 1) * (D + 1);
@@ -477,7 +519,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
             case 2: sh_backward_rows<9>(B, sh, dsh, dr0, dr1, dr2, shw); break;
             default: sh_backward_rows<16>(B, sh, dsh, dr0, dr1, dr2, shw); break;
         }
-        for (int k = 3 * K; k < 3 * cam.M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
+        for (int k = 3 * K; k < 3 * M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
 #define SHW(k) shw[k]
         if (D > 0) {
@@ -520,17 +562,15 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
         dm1 += (-vx * vy * ddx + (s2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
         dm2 += (-vx * vz * ddx - vy * vz * ddy + (s2 - vz * vz) * ddz) * inv32;
     }
-    dL_dmeans3D[3 * (size_t)i] = dm0;
-    dL_dmeans3D[3 * (size_t)i + 1] = dm1;
-    dL_dmeans3D[3 * (size_t)i + 2] = dm2;
+    dL_dmeans3D[3 * j] = dm0;
+    dL_dmeans3D[3 * j + 1] = dm1;
+    dL_dmeans3D[3 * j + 2] = dm2;
 
     // Sigma3D -> scale, quaternion (quaternion gradient w.r.t. the UN-normalised q)
     if (!cov3D_precomp) {
         const float mod = cam.mod;
-        const float r = rots[4 * (size_t)i], qx = rots[4 * (size_t)i + 1], qy = rots[4 * (size_t)i + 2],
-                    qz = rots[4 * (size_t)i + 3];
-        const float s[3] = {mod * scales[3 * (size_t)i], mod * scales[3 * (size_t)i + 1],
-                            mod * scales[3 * (size_t)i + 2]};
+        const float r = rots[4 * j], qx = rots[4 * j + 1], qy = rots[4 * j + 2], qz = rots[4 * j + 3];
+        const float s[3] = {mod * scales[3 * j], mod * scales[3 * j + 1], mod * scales[3 * j + 2]};
         const float R[3][3] = {
             {1.0f - 2.0f * (qy * qy + qz * qz), 2.0f * (qx * qy - r * qz), 2.0f * (qx * qz + r * qy)},
             {2.0f * (qx * qy + r * qz), 1.0f - 2.0f * (qx * qx + qz * qz), 2.0f * (qy * qz - r * qx)},
@@ -550,7 +590,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
                 dMc[ii] = 2.0f * acc;
             }
             float ds = R[0][jj] * dMc[0] + R[1][jj] * dMc[1] + R[2][jj] * dMc[2];
-            dL_dscale[3 * (size_t)i + jj] = mod * ds;
+            dL_dscale[3 * j + jj] = mod * ds;
 #pragma unroll
             for (int ii = 0; ii < 3; ++ii) dR[ii][jj] = s[jj] * dMc[ii];
         }
@@ -562,22 +602,27 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D,
                        r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
         dq.w = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] +
                        qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
-        reinterpret_cast<float4*>(dL_drot)[i] = dq;
+        reinterpret_cast<float4*>(dL_drot)[j] = dq;
     } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = 0.0f;
-        reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 3; ++k) dL_dscale[3 * j + k] = 0.0f;
+        reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st)
 {
     const hgs_forward_args& f = a.fwd;
-    int blocks = (f.P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, f.P, cam, f.means3D, f.shs,
-                       f.opacities, f.scales, f.rotations, f.cov3D_precomp, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
+    const int P = f.P + f.seg2.P;
+    int blocks = (P + 255) / 256;
+    const SecondInputs in2{f.P, f.seg2.M, f.seg2.means3D, f.seg2.shs, f.seg2.colors_precomp, f.seg2.opacities, f.seg2.scales,
+                           f.seg2.rotations, f.seg2.cov3D_precomp};
+    const SecondGrads out2{a.seg2_dL_dopacity, a.seg2_dL_dcolors, a.seg2_dL_dmeans3D, a.seg2_dL_dsh, a.seg2_dL_dscales,
+                           a.seg2_dL_drotations, a.seg2_dL_dcov3D};
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, P, cam, f.means3D, f.shs,
+                       f.opacities, f.scales, f.rotations, f.cov3D_precomp, in2, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
                        a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
-                       a.dL_drotations, a.dL_dcov3D);
+                       a.dL_drotations, a.dL_dcov3D, out2);
 }
 
 // K10

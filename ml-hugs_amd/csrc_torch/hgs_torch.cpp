@@ -50,24 +50,41 @@ void* alloc_cb(void* ctx, int, size_t bytes)
 
 void raise_last(const char* what) { TORCH_CHECK(false, what, ": ", hgs_last_error()); }
 
-// element offsets inside the gradient slab: accumulator [P,12], means2D, opacity, colors, means3D, cov3D, sh, scales, rotations
+// element offsets inside the gradient slab: accumulator [P + P2,12], means2D [P + P2,3]; opacity, colors, means3D, cov3D, sh,
+// scales, rotations of the first set; then of the second set (hgs_segment) in the same order
 struct GradLayout {
-    int64_t off[9], size[9], total;
-    GradLayout(int64_t P, int64_t M)
+    int64_t off[16], size[16], total;
+    GradLayout(int64_t P, int64_t M, int64_t P2, int64_t M2)
     {
-        const int64_t s[9] = {12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P};
+        const int64_t Pt = P + P2;
+        const int64_t s[16] = {12 * Pt, 3 * Pt, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P,
+                               P2, 3 * P2, 3 * P2, 6 * P2, 3 * M2 * P2, 3 * P2, 4 * P2};
         total = 0;
-        for (int k = 0; k < 9; ++k) size[k] = s[k], off[k] = total, total += (s[k] + 63) / 64 * 64;
+        for (int k = 0; k < 16; ++k) size[k] = s[k], off[k] = total, total += (s[k] + 63) / 64 * 64;
         if (total < 1) total = 1;
     }
 };
 
-void point_at_grads(hgs_backward_args& bw, float* base, const GradLayout& g, int64_t M)
+void point_at_grads(hgs_backward_args& bw, float* base, const GradLayout& g, int64_t M, int64_t M2)
 {
     bw.grad_accum = base + g.off[0], bw.dL_dmeans2D = base + g.off[1], bw.dL_dopacity = base + g.off[2];
     bw.dL_dcolors = base + g.off[3], bw.dL_dmeans3D = base + g.off[4], bw.dL_dcov3D = base + g.off[5];
     bw.dL_dsh = M ? base + g.off[6] : nullptr;
     bw.dL_dscales = base + g.off[7], bw.dL_drotations = base + g.off[8];
+    bw.seg2_dL_dopacity = base + g.off[9], bw.seg2_dL_dcolors = base + g.off[10], bw.seg2_dL_dmeans3D = base + g.off[11];
+    bw.seg2_dL_dcov3D = base + g.off[12], bw.seg2_dL_dsh = M2 ? base + g.off[13] : nullptr;
+    bw.seg2_dL_dscales = base + g.off[14], bw.seg2_dL_drotations = base + g.off[15];
+}
+
+void fill_segment(hgs_segment& g, const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac,
+                  const Tensor& scales, const Tensor& rot, const Tensor& cov)
+{
+    memset(&g, 0, sizeof g);
+    if (!means3D.defined() || means3D.numel() == 0) return;
+    g.P = (int32_t)means3D.size(0);
+    g.M = sh.defined() && sh.numel() ? (int32_t)sh.size(1) : 0;
+    g.means3D = fptr(means3D), g.shs = fptr(sh), g.colors_precomp = fptr(colors), g.opacities = fptr(opac);
+    g.scales = fptr(scales), g.rotations = fptr(rot), g.cov3D_precomp = fptr(cov);
 }
 
 void fill_forward(hgs_forward_args& a, const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac,
@@ -92,7 +109,9 @@ public:
     static variable_list forward(AutogradContext* ctx, Tensor means3D_, Tensor means2D, Tensor sh_, Tensor colors_,
                                  Tensor opac_, Tensor scales_, Tensor rot_, Tensor cov_, Tensor bg_, Tensor view_,
                                  Tensor proj_, Tensor campos_, int64_t H, int64_t W, double tanfovx, double tanfovy,
-                                 double mod, int64_t degree, bool prefiltered, bool debug, bool clamp_output, bool needs_grad)
+                                 double mod, int64_t degree, bool prefiltered, bool debug, bool clamp_output, bool needs_grad,
+                                 Tensor means3D_b_, Tensor sh_b_, Tensor colors_b_, Tensor opac_b_, Tensor scales_b_, Tensor rot_b_,
+                                 Tensor cov_b_)
     {
         TORCH_CHECK(means3D_.is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
         const auto dev = means3D_.device();
@@ -101,7 +120,13 @@ public:
         Tensor sh = f32c(sh_), colors = f32c(colors_), opac = f32c(opac_), scales = f32c(scales_), rot = f32c(rot_), cov = f32c(cov_);
         auto on_dev = [&](const Tensor& t) { return f32c(t.device() == dev ? t : t.to(dev)); };
         Tensor bg = on_dev(bg_), view = on_dev(view_), proj = on_dev(proj_), campos = on_dev(campos_);
-        const int64_t P = means3D.size(0);
+        // the optional second set of Gaussians (hgs_segment): rendered behind the first in index order, nothing concatenated
+        Tensor means3D_b = f32c(means3D_b_), sh_b = f32c(sh_b_), colors_b = f32c(colors_b_), opac_b = f32c(opac_b_),
+               scales_b = f32c(scales_b_), rot_b = f32c(rot_b_), cov_b = f32c(cov_b_);
+        const int64_t P1 = means3D.size(0), P2 = means3D_b.defined() ? means3D_b.size(0) : 0;
+        TORCH_CHECK(P2 == 0 || P1 > 0, "a second set of Gaussians needs a non-empty first one");
+        TORCH_CHECK(P2 == 0 || (means3D_b.dim() == 2 && means3D_b.size(1) == 3), "means3D must have dimensions (num_points, 3)");
+        const int64_t P = P1 + P2;
         const auto fopts = at::TensorOptions().dtype(at::kFloat).device(dev);
         const auto bopts = at::TensorOptions().dtype(at::kByte).device(dev);
         Tensor color = P == 0 ? at::zeros({3, H, W}, fopts) : at::empty({3, H, W}, fopts);
@@ -112,14 +137,15 @@ public:
         hgs_forward_args& a = bw.fwd;
         fill_forward(a, means3D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, tanfovx, tanfovy, mod, degree,
                      prefiltered, debug, clamp_output);
+        fill_segment(a.seg2, means3D_b, sh_b, colors_b, opac_b, scales_b, rot_b, cov_b);
         a.out_color = color.data_ptr<float>(), a.radii = P ? radii.data_ptr<int32_t>() : nullptr;
-        const int64_t M = a.M;
+        const int64_t M = a.M, M2 = a.seg2.M;
         // (needs_grad is decided by the caller: grad mode is off inside forward())
         Tensor slab;
         if (needs_grad && P > 0) {
-            GradLayout g(P, M);
+            GradLayout g(P1, M, P2, M2);
             slab = at::empty({g.total}, fopts);
-            point_at_grads(bw, slab.data_ptr<float>(), g, M);
+            point_at_grads(bw, slab.data_ptr<float>(), g, M, M2);
             a.grad_accum_to_zero = bw.grad_accum;
         }
         const auto key = std::make_tuple((int)dev.index(), P, H, W);
@@ -168,7 +194,10 @@ public:
             ctx->save_for_backward({means3D, sh.defined() ? sh : Tensor(), colors.defined() ? colors : Tensor(),
                                     opac.defined() ? opac : Tensor(), scales.defined() ? scales : Tensor(),
                                     rot.defined() ? rot : Tensor(), cov.defined() ? cov : Tensor(), radii, bg, view, proj, campos,
-                                    scratch, slab});
+                                    scratch, slab, means3D_b.defined() ? means3D_b : Tensor(), sh_b.defined() ? sh_b : Tensor(),
+                                    colors_b.defined() ? colors_b : Tensor(), opac_b.defined() ? opac_b : Tensor(),
+                                    scales_b.defined() ? scales_b : Tensor(), rot_b.defined() ? rot_b : Tensor(),
+                                    cov_b.defined() ? cov_b : Tensor()});
             // (buffers the allocation callback handed out -- the binning / checkpoint buffers of an unhinted or under-guessed
             // frame -- stay alive with the node)
             for (const Tensor& t : keep) ctx->saved_data["keep" + std::to_string(&t - keep.data())] = t;
@@ -187,7 +216,7 @@ public:
 
     static variable_list backward(AutogradContext* ctx, variable_list grads)
     {
-        variable_list out(22);
+        variable_list out(29);
         const Tensor& g_color = grads[0];
         if (!g_color.defined()) return out;   // colour did not take part in the loss
         const auto sv = ctx->get_saved_variables();
@@ -195,8 +224,11 @@ public:
         const Tensor &means3D = sv[0], &sh = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rot = sv[5], &cov = sv[6],
                      &radii = sv[7], &bg = sv[8], &view = sv[9], &proj = sv[10], &campos = sv[11];
         Tensor slab = sv[13];
-        const int64_t P = means3D.size(0), H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
-        if (P == 0) {   // nothing was rendered: empty gradients of the inputs' shapes
+        const Tensor &means3D_b = sv[14], &sh_b = sv[15], &colors_b = sv[16], &opac_b = sv[17], &scales_b = sv[18], &rot_b = sv[19],
+                     &cov_b = sv[20];
+        const int64_t P1 = means3D.size(0), P2 = means3D_b.defined() ? means3D_b.size(0) : 0;
+        const int64_t P = P1 + P2, H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+        if (P == 0) {   // nothing was rendered (so there is no second set either): empty gradients of the inputs' shapes
             out[0] = at::zeros_like(means3D), out[1] = at::zeros_like(means3D);
             for (int k = 1; k <= 6; ++k)
                 if (sv[k].defined()) out[k + 1] = at::zeros_like(sv[k]);
@@ -208,22 +240,23 @@ public:
         fill_forward(bw.fwd, means3D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, ctx->saved_data["tx"].toDouble(),
                      ctx->saved_data["ty"].toDouble(), ctx->saved_data["mod"].toDouble(), ctx->saved_data["D"].toInt(), flags & 1, flags & 2,
                      flags & 4);
+        fill_segment(bw.fwd.seg2, means3D_b, sh_b, colors_b, opac_b, scales_b, rot_b, cov_b);
         bw.fwd.radii = radii.data_ptr<int32_t>();
-        const int64_t M = bw.fwd.M;
+        const int64_t M = bw.fwd.M, M2 = bw.fwd.seg2.M;
         bw.state.geom = (void*)(uintptr_t)ctx->saved_data["geom"].toInt(), bw.state.geom_bytes = (size_t)ctx->saved_data["geom_b"].toInt();
         bw.state.binning = (void*)(uintptr_t)ctx->saved_data["bin"].toInt(), bw.state.binning_bytes = (size_t)ctx->saved_data["bin_b"].toInt();
         bw.state.image = (void*)(uintptr_t)ctx->saved_data["img"].toInt(), bw.state.image_bytes = (size_t)ctx->saved_data["img_b"].toInt();
         bw.state.ckpt = (void*)(uintptr_t)ctx->saved_data["ck"].toInt(), bw.state.ckpt_bytes = (size_t)ctx->saved_data["ck_b"].toInt();
         bw.state.num_rendered = ctx->saved_data["N"].toInt(), bw.state.binning_capacity = ctx->saved_data["cap"].toInt();
         bw.state.sparse_frame = (int32_t)ctx->saved_data["sparse"].toInt(), bw.state.has_long_tiles = (int32_t)ctx->saved_data["long"].toInt();
-        GradLayout gl(P, M);
+        GradLayout gl(P1, M, P2, M2);
         const auto dev = means3D.device();
         if (!ctx->saved_data["fresh"].toBool()) {   // a second backward (retain_graph): a fresh, zeroed slab
             slab = at::empty({gl.total}, means3D.options());
             slab.narrow(0, 0, std::max<int64_t>(gl.off[1], 1)).zero_();
         }
         ctx->saved_data["fresh"] = false;
-        point_at_grads(bw, slab.data_ptr<float>(), gl, M);
+        point_at_grads(bw, slab.data_ptr<float>(), gl, M, M2);
         Tensor g = f32c(g_color);
         bw.dL_dout_color = g.data_ptr<float>();
         int32_t rc;
@@ -233,14 +266,23 @@ public:
         }
         if (rc < 0) raise_last("rasterize_gaussians_backward");
         auto view_of = [&](int k, at::IntArrayRef shape) { return slab.narrow(0, gl.off[k], gl.size[k]).view(shape); };
-        out[0] = view_of(4, {P, 3});                                  // means3D
-        out[1] = view_of(1, {P, 3});                                  // means2D (the viewspace gradient sink)
-        if (sh.defined() && sh.numel()) out[2] = view_of(6, {P, M, 3});
-        if (colors.defined() && colors.numel()) out[3] = view_of(3, {P, 3});
-        out[4] = view_of(2, {P, 1});
-        if (scales.defined() && scales.numel()) out[5] = view_of(7, {P, 3});
-        if (rot.defined() && rot.numel()) out[6] = view_of(8, {P, 4});
-        if (cov.defined() && cov.numel()) out[7] = view_of(5, {P, 6});
+        out[0] = view_of(4, {P1, 3});                                 // means3D
+        out[1] = view_of(1, {P, 3});                                  // means2D (the viewspace gradient sink, both sets)
+        if (sh.defined() && sh.numel()) out[2] = view_of(6, {P1, M, 3});
+        if (colors.defined() && colors.numel()) out[3] = view_of(3, {P1, 3});
+        out[4] = view_of(2, {P1, 1});
+        if (scales.defined() && scales.numel()) out[5] = view_of(7, {P1, 3});
+        if (rot.defined() && rot.numel()) out[6] = view_of(8, {P1, 4});
+        if (cov.defined() && cov.numel()) out[7] = view_of(5, {P1, 6});
+        if (P2 > 0) {   // the second set's gradients, written in place by the library
+            out[22] = view_of(11, {P2, 3});
+            if (sh_b.defined() && sh_b.numel()) out[23] = view_of(13, {P2, M2, 3});
+            if (colors_b.defined() && colors_b.numel()) out[24] = view_of(10, {P2, 3});
+            out[25] = view_of(9, {P2, 1});
+            if (scales_b.defined() && scales_b.numel()) out[26] = view_of(14, {P2, 3});
+            if (rot_b.defined() && rot_b.numel()) out[27] = view_of(15, {P2, 4});
+            if (cov_b.defined() && cov_b.numel()) out[28] = view_of(12, {P2, 6});
+        }
         return out;
     }
 };
@@ -248,14 +290,20 @@ public:
 std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot,
                               Tensor cov, Tensor bg, Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W,
                               double tanfovx, double tanfovy, double mod, int64_t degree, bool prefiltered, bool debug,
-                              bool clamp_output)
+                              bool clamp_output, std::vector<Tensor> second)
 {
+    // `second`: nothing, or the second set's (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+    TORCH_CHECK(second.empty() || second.size() == 7, "the second set of Gaussians is a list of seven tensors");
+    if (second.empty()) second.assign(7, at::empty({0}, means3D.options()));
     bool needs_grad = false;
-    if (at::GradMode::is_enabled())
+    if (at::GradMode::is_enabled()) {
         for (const Tensor* t : {&means3D, &means2D, &sh, &colors, &opac, &scales, &rot, &cov})
             needs_grad = needs_grad || (t->defined() && t->requires_grad());
+        for (const Tensor& t : second) needs_grad = needs_grad || (t.defined() && t.requires_grad());
+    }
     auto r = Rasterize::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, tanfovx, tanfovy,
-                              mod, degree, prefiltered, debug, clamp_output, needs_grad);
+                              mod, degree, prefiltered, debug, clamp_output, needs_grad, second[0], second[1], second[2], second[3],
+                              second[4], second[5], second[6]);
     return {r[0], r[1]};
 }
 
@@ -263,7 +311,11 @@ std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor 
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
-    m.def("rasterize", &rasterize, "forward of the differentiable Gaussian rasterizer (C++ autograd node over the C ABI)");
+    m.def("rasterize", &rasterize, "forward of the differentiable Gaussian rasterizer (C++ autograd node over the C ABI)",
+          py::arg("means3D"), py::arg("means2D"), py::arg("sh"), py::arg("colors"), py::arg("opac"), py::arg("scales"), py::arg("rot"),
+          py::arg("cov"), py::arg("bg"), py::arg("view"), py::arg("proj"), py::arg("campos"), py::arg("H"), py::arg("W"),
+          py::arg("tanfovx"), py::arg("tanfovy"), py::arg("mod"), py::arg("degree"), py::arg("prefiltered"), py::arg("debug"),
+          py::arg("clamp_output"), py::arg("second") = std::vector<Tensor>());
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
     m.def("last_frame_info", [] { return std::make_pair(t_last_n, t_last_capacity); }, "(N, binning capacity) of this thread's last forward");
     m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse) {

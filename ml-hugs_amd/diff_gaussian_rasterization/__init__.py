@@ -30,7 +30,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 6
+_ABI_VERSION = 7
 
 
 def library_path():
@@ -46,6 +46,11 @@ class _Settings(C.Structure):
                 ("campos", C.c_void_p), ("prefiltered", C.c_int32), ("debug", C.c_int32)]
 
 
+class _Segment(C.Structure):
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
 class _ForwardArgs(C.Structure):
     _fields_ = [("s", _Settings), ("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
@@ -53,7 +58,7 @@ class _ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
                 ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
                 ("defer_n", C.c_int32), ("backward_checkpoints", C.c_int32), ("scratch", C.c_void_p * 4),
-                ("scratch_bytes", C.c_size_t * 4)]
+                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment)]
 
 
 class _ForwardState(C.Structure):
@@ -67,7 +72,10 @@ class _BackwardArgs(C.Structure):
     _fields_ = [("fwd", _ForwardArgs), ("state", _ForwardState), ("dL_dout_color", C.c_void_p),
                 ("grad_accum", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p)]
+                ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
+                ("seg2_dL_dopacity", C.c_void_p), ("seg2_dL_dcolors", C.c_void_p), ("seg2_dL_dmeans3D", C.c_void_p),
+                ("seg2_dL_dcov3D", C.c_void_p), ("seg2_dL_dsh", C.c_void_p), ("seg2_dL_dscales", C.c_void_p),
+                ("seg2_dL_drotations", C.c_void_p)]
 
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
@@ -252,12 +260,16 @@ def _capacity_hint(key):
 
 
 _GRAD_NAMES = ("grad_accum", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
-               "dL_drotations")
+               "dL_drotations", "seg2_dL_dopacity", "seg2_dL_dcolors", "seg2_dL_dmeans3D", "seg2_dL_dcov3D", "seg2_dL_dsh",
+               "seg2_dL_dscales", "seg2_dL_drotations")
 
 
-def _grad_layout(P, M):
-    """Element offsets of the [P,12] atomic accumulator and the eight gradient tensors inside one fp32 slab."""
-    sizes = (12 * P, 3 * P, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P)
+def _grad_layout(P, M, P2=0, M2=0):
+    """Element offsets of the [P + P2,12] atomic accumulator, the joint dL/dmeans2D and the seven gradient tensors of each
+    segment inside one fp32 slab."""
+    Pt = P + P2
+    sizes = (12 * Pt, 3 * Pt, P, 3 * P, 3 * P, 6 * P, 3 * M * P, 3 * P, 4 * P,
+             P2, 3 * P2, 3 * P2, 6 * P2, 3 * M2 * P2, 3 * P2, 4 * P2)
     offs, total = [], 0
     for n in sizes:
         offs.append(total)
@@ -265,22 +277,22 @@ def _grad_layout(P, M):
     return sizes, offs, max(total, 1)
 
 
-def _grad_slab(P, M, dev, zero, bw):
+def _grad_slab(P, M, dev, zero, bw, P2=0, M2=0):
     """One allocation for the accumulator (the only part that must be zero -- the library overwrites every other element;
     `zero=False` when forward is asked to zero it) and the gradient tensors; the backward argument block is pointed at
     it by address arithmetic, the tensor views are only made for what backward() returns."""
-    sizes, offs, total = _grad_layout(P, M)
+    sizes, offs, total = _grad_layout(P, M, P2, M2)
     slab = torch.empty(total, dtype=torch.float32, device=dev)
     if zero:
         slab[:max(offs[1], 1)].zero_()
     base = slab.data_ptr()
     for k, name in enumerate(_GRAD_NAMES):
-        setattr(bw, name, base + 4 * offs[k] if (sizes[k] or k != 6) else None)
+        setattr(bw, name, base + 4 * offs[k] if (sizes[k] or k not in (6, 13)) else None)
     return slab
 
 
-def _grad_view(slab, P, M, k, *shape):
-    sizes, offs, _ = _grad_layout(P, M)
+def _grad_view(slab, dims, k, *shape):
+    sizes, offs, _ = _grad_layout(*dims)
     return slab[offs[k]:offs[k] + sizes[k]].view(*shape)
 
 
@@ -324,10 +336,22 @@ def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=No
     return buf, (o, g, o + g, im, o + g + im, b)   # geom off/len, image off/len, binning off/len
 
 
+def _fill_segment(seg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp):
+    seg.P = int(means3D.shape[0])
+    seg.M = int(sh.shape[1]) if sh is not None else 0
+    seg.means3D, seg.shs, seg.colors_precomp = _ptr(means3D), _ptr(sh), _ptr(colors_precomp)
+    seg.opacities, seg.scales, seg.rotations, seg.cov3D_precomp = _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
+    """forward(means3D, means2D, sh, colors, opacities, scales, rotations, cov3Ds, settings, clamp_output
+               [, means3D_b, sh_b, colors_b, opacities_b, scales_b, rotations_b, cov3Ds_b])
+    The optional second set of Gaussians (hgs_segment: the joint human + scene render without torch.cat) is rendered
+    behind the first in index order; means2D then has P + P_b rows, as the reference's viewspace tensor of a joint render."""
+
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, clamp_output=False):
+                raster_settings, clamp_output=False, *second):
         lib = _load()
         _require_gpu(means3D, "means3D")
         dev = means3D.device
@@ -337,7 +361,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         sh, colors_precomp, opacities = _f32c(sh), _f32c(colors_precomp), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
-        P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+        P1, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+        sec = None
+        if second and second[0] is not None and second[0].numel():
+            if P1 == 0:
+                raise RuntimeError("a second set of Gaussians needs a non-empty first one")
+            sec = tuple(_f32c(x) for x in second)
+            if sec[0].ndim != 2 or sec[0].shape[1] != 3:
+                raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        P2 = sec[0].shape[0] if sec is not None else 0
+        P = P1 + P2
 
         # P == 0: nothing is launched and colour stays zero (no background) -- upstream behaviour
         color = torch.zeros(3, H, W, dtype=torch.float32, device=dev) if P == 0 else \
@@ -359,13 +392,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         bw = _BackwardArgs()
         args, state = bw.fwd, bw.state
         _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
+        if sec is not None:
+            _fill_segment(args.seg2, *sec)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
         args.clamp_output = 1 if clamp_output else 0
-        M = int(args.M)
+        M, M2 = int(args.M), int(args.seg2.M)
         needs_grad = P > 0 and any(ctx.needs_input_grad)
         slab = None
         if needs_grad:
-            slab = _grad_slab(P, M, dev, False, bw)
+            slab = _grad_slab(P1, M, dev, False, bw, P2, M2)
             args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
@@ -392,17 +427,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.binning_capacity = int(state.binning_capacity)
         _last_frame_info = (ctx.num_rendered, ctx.binning_capacity)
         _remember(hint_key, int(n), bool(state.has_long_tiles), bool(state.sparse_frame))
-        ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P, M)
+        ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P1, M, P2, M2)
         ctx.scratch, ctx.bufs = scratch, bufs   # kept alive for backward (and read by _debug_forward_state)
         empty = torch.empty(0, device=dev)
-        ctx.save_for_backward(means3D,
-                              sh if sh is not None else empty,
-                              colors_precomp if colors_precomp is not None else empty,
-                              opacities if opacities is not None else empty,
-                              scales if scales is not None else empty,
-                              rotations if rotations is not None else empty,
-                              cov3Ds_precomp if cov3Ds_precomp is not None else empty,
-                              radii)
+        e = lambda x: x if x is not None else empty
+        ctx.save_for_backward(means3D, e(sh), e(colors_precomp), e(opacities), e(scales), e(rotations), e(cov3Ds_precomp), radii,
+                              *([e(x) for x in sec] if sec is not None else []))
+        ctx.n_second_inputs = len(second)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zero-filled int32 "gradient" for radii
         return color, radii
@@ -411,15 +442,19 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         lib = _load()
         # the saved tensors are what `ctx.bw` points into: unpacking them also runs autograd's in-place-modification check
-        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, _radii = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, _radii = saved[:8]
+        sec = saved[8:]
         dev = means3D.device
-        P, M = ctx.dims
+        P1, M, P2, M2 = ctx.dims
+        P = P1 + P2
         bw, slab = ctx.bw, ctx.slab
+        none_second = (None,) * ctx.n_second_inputs
         if grad_out_color is None:  # colour did not take part in the loss
             ctx.slab = None
-            return (None,) * 10
+            return (None,) * 10 + none_second
         if slab is None:  # first use is prepared by forward; a second backward (retain_graph) gets a fresh slab
-            slab = _grad_slab(P, M, dev, True, bw)
+            slab = _grad_slab(P1, M, dev, True, bw, P2, M2)
         ctx.slab = None
 
         if P > 0:
@@ -436,17 +471,27 @@ class _RasterizeGaussians(torch.autograd.Function):
             if rc < 0:
                 _raise_last(lib, "rasterize_gaussians_backward")
 
-        v = lambda k, *shape: _grad_view(slab, P, M, k, *shape)
+        v = lambda k, *shape: _grad_view(slab, ctx.dims, k, *shape)
         # order of forward's inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-        # cov3Ds_precomp, raster_settings
-        return (v(4, P, 3), v(1, P, 3),
-                v(6, P, M, 3) if sh.numel() else None,
-                v(3, P, 3) if colors_precomp.numel() else None,
-                v(2, P, 1),
-                v(7, P, 3) if scales.numel() else None,
-                v(8, P, 4) if rotations.numel() else None,
-                v(5, P, 6) if cov3Ds_precomp.numel() else None,
-                None, None)
+        # cov3Ds_precomp, raster_settings, clamp_output [, the second set in the same order without means2D]
+        first = (v(4, P1, 3), v(1, P, 3),
+                 v(6, P1, M, 3) if sh.numel() else None,
+                 v(3, P1, 3) if colors_precomp.numel() else None,
+                 v(2, P1, 1),
+                 v(7, P1, 3) if scales.numel() else None,
+                 v(8, P1, 4) if rotations.numel() else None,
+                 v(5, P1, 6) if cov3Ds_precomp.numel() else None,
+                 None, None)
+        if not sec:
+            return first + none_second
+        _m3b, sh_b, col_b, _op_b, sc_b, rot_b, cov_b = sec
+        return first + (v(11, P2, 3),
+                        v(13, P2, M2, 3) if sh_b.numel() else None,
+                        v(10, P2, 3) if col_b.numel() else None,
+                        v(9, P2, 1),
+                        v(14, P2, 3) if sc_b.numel() else None,
+                        v(15, P2, 4) if rot_b.numel() else None,
+                        v(12, P2, 6) if cov_b.numel() else None)
 
 
 # The same binding as a C++ autograd node (ml-hugs_amd/csrc_torch/hgs_torch.cpp -> lib/_hgs_torch.so): identical library
@@ -485,20 +530,30 @@ def last_frame_info():
     return _last_frame_info
 
 
+_SECOND_KEYS = ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp")
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, clamp_output=False):
+                        raster_settings, clamp_output=False, second=None):
+    """`second`: optional dict with the keys of _SECOND_KEYS (missing / None = absent) -- a second model's Gaussians
+    rendered together with the first without concatenating anything (hgs_segment); means2D must then have
+    len(means3D) + len(second["means3D"]) rows."""
     global _last_frame_info
+    sec = ()
+    if second is not None and second.get("means3D") is not None and second["means3D"].numel():
+        empty = torch.Tensor([])
+        sec = tuple(second.get(k) if second.get(k) is not None else empty for k in _SECOND_KEYS)
     cpp = _load_cpp()
     if cpp is not None:
         rs = raster_settings
         color, radii = cpp.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
                                      rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
                                      float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
-                                     bool(rs.prefiltered), bool(rs.debug), bool(clamp_output))
+                                     bool(rs.prefiltered), bool(rs.debug), bool(clamp_output), list(sec))
         _last_frame_info = cpp.last_frame_info()
         return color, radii
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, clamp_output)
+                                     cov3Ds_precomp, raster_settings, clamp_output, *sec)
 
 
 class DeferredFrame:
@@ -610,9 +665,12 @@ class GaussianRasterizer(nn.Module):
         return present
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, clamp_output=False):
-        """`clamp_output` is the one addition to upstream's signature: True fuses the `torch.clamp(image, 0, 1)` that
-        the reference's render() applies right after this call (gs_renderer.py:153), forward and backward."""
+                cov3D_precomp=None, clamp_output=False, second=None):
+        """Two additions to upstream's signature: `clamp_output` -- True fuses the `torch.clamp(image, 0, 1)` that the
+        reference's render() applies right after this call (gs_renderer.py:153), forward and backward -- and `second`, a
+        dict (means3D, opacities, shs | colors_precomp, scales + rotations | cov3D_precomp) with a second model's Gaussians,
+        rendered behind the first in index order exactly as if the tensors had been concatenated (gs_renderer.py:33-37)
+        but read, and their gradients written, in place."""
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -631,7 +689,7 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = empty
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings, clamp_output)
+                                   cov3D_precomp, raster_settings, clamp_output, second)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -9,9 +9,13 @@ the behaviours the trainer relies on:
   * tanfov is computed on the host in double precision                           (:116-117)
   * `feats.ndim == 2` selects precomputed colours, otherwise SH                  (:119-123)
   * prefiltered=False, debug=False; image clamped to [0,1]; visibility = radii>0 (:137-138,153,159)
-  * joint mode concatenates human first, scene second, takes the active SH degree from the human
+  * joint mode renders human first, scene second, takes the active SH degree from the human
     model, optionally renders the human alone on its own background, and slices radii/visibility
     per model                                                                    (:32-52,68-98)
+The one structural difference: the reference concatenates the two models' five tensors per step (:33-37) and autograd
+splits the gradients again; here the scene's tensors travel as the rasterizer's SECOND SEGMENT (hgs_segment), read and
+differentiated in place -- Gaussian indices, radii, viewspace_points and every value are those of the concatenated call
+(HGS_JOINT_CONCAT=1 keeps the reference's torch.cat for A/B runs).
 """
 import math
 import os
@@ -23,8 +27,23 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 _FIELDS = (("shs", "feats"), ("xyz", "means3D"), ("opacity", "opacity"), ("scales", "scales"), ("rotq", "rotations"))
 
 
-def _gather(human_gs_out, scene_gs_out, render_mode):
-    if render_mode == "human_scene":
+_JOINT_CONCAT = os.environ.get("HGS_JOINT_CONCAT", "0") == "1"
+
+
+def _two_segments(human_gs_out, scene_gs_out):
+    """Can the joint render pass the scene as the rasterizer's second segment?  (Both models non-empty and holding the same
+    kind of features; otherwise -- and with HGS_JOINT_CONCAT=1 -- the tensors are concatenated as the reference does.)"""
+    h, sc = human_gs_out, scene_gs_out
+    return (not _JOINT_CONCAT and h["xyz"].shape[0] > 0 and sc["xyz"].shape[0] > 0 and h["shs"].dim() == sc["shs"].dim()
+            and h["xyz"].device == sc["xyz"].device)
+
+
+def _gather(human_gs_out, scene_gs_out, render_mode, concat=True):
+    if render_mode == "human_scene" and not concat:
+        out = {dst: human_gs_out[src] for src, dst in _FIELDS}
+        out["second"] = {dst: scene_gs_out[src] for src, dst in _FIELDS}
+        out["active_sh_degree"] = human_gs_out["active_sh_degree"]
+    elif render_mode == "human_scene":
         out = {dst: torch.cat([human_gs_out[src], scene_gs_out[src]], dim=0) for src, dst in _FIELDS}
         out["active_sh_degree"] = human_gs_out["active_sh_degree"]
     elif render_mode == "human":
@@ -53,7 +72,8 @@ def _side_stream(device):
 
 def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_color=None, scaling_modifier=1.0,
                        render_mode="human_scene", render_human_separate=False):
-    g = _gather(human_gs_out, scene_gs_out, render_mode)
+    g = _gather(human_gs_out, scene_gs_out, render_mode,
+                concat=not (render_mode == "human_scene" and _two_segments(human_gs_out, scene_gs_out)))
     separate = render_human_separate and render_mode == "human_scene"
     human_pkg = None
 
@@ -80,7 +100,7 @@ def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_colo
                     t.record_stream(side)
     pkg = render(means3D=g["means3D"], feats=g["feats"], opacity=g["opacity"], scales=g["scales"],
                  rotations=g["rotations"], data=data, scaling_modifier=scaling_modifier, bg_color=bg_color,
-                 active_sh_degree=g["active_sh_degree"])
+                 active_sh_degree=g["active_sh_degree"], second=g.get("second"))
 
     if separate:
         if human_pkg is None:
@@ -110,13 +130,19 @@ def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_colo
 
 
 def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.0, bg_color=None,
-           active_sh_degree=0):
+           active_sh_degree=0, second=None):
+    """`second` (not in the reference's signature): a dict {means3D, feats, opacity, scales, rotations} with a second model's
+    Gaussians, rendered behind the first in index order -- what the reference gets by concatenating (:33-37)."""
     device = means3D.device
     if bg_color is None:
         bg_color = torch.zeros(3, dtype=torch.float32, device=device)
 
     # gradient sink for dL/d(screen-space mean): non-leaf, so it must retain its grad explicitly
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
+    if second is None:
+        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
+    else:   # one row per Gaussian of both models, as the reference's zeros_like of the concatenated means
+        screenspace_points = torch.zeros(means3D.shape[0] + second["means3D"].shape[0], 3, dtype=means3D.dtype,
+                                         requires_grad=True, device=device) + 0
     try:
         screenspace_points.retain_grad()
     except Exception:
@@ -137,6 +163,9 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
         debug=False,
     )
     is_rgb = feats.dim() == 2
+    if second is not None:
+        second = {"means3D": second["means3D"], "opacities": second["opacity"], "scales": second["scales"],
+                  "rotations": second["rotations"], ("colors_precomp" if is_rgb else "shs"): second["feats"]}
     image, radii = GaussianRasterizer(raster_settings=settings)(
         means3D=means3D,
         means2D=screenspace_points,
@@ -146,6 +175,7 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
         scales=scales,
         rotations=rotations,
         clamp_output=True,   # the reference's torch.clamp(rendered_image, 0.0, 1.0) (:153), fused into the blend kernels
+        **({} if second is None else {"second": second}),   # (a one-model call carries exactly the reference's kwargs + the clamp)
     )
     return {
         "render": image,

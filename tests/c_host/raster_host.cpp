@@ -103,9 +103,23 @@ int main(int argc, char** argv)
     bw.dL_dcov3D = device_buffer<float>(6 * (size_t)P), bw.dL_dsh = device_buffer<float>(3 * (size_t)M * P);
     bw.dL_dscales = device_buffer<float>(3 * (size_t)P), bw.dL_drotations = device_buffer<float>(4 * (size_t)P);
     bw.dL_dout_color = to_device(dL);
+    if (use_hint == 3) {
+        // the two-segment form (hgs_segment): the same Gaussians handed over as a first set of P1 and a second set of P - P1.
+        // Here both live in one allocation, so the second set's inputs and gradients are simply the tails of the arrays --
+        // and everything written out below must equal the one-set run.
+        const size_t P1 = (size_t)(2 * P) / 5;
+        a.P = (int32_t)P1;
+        hgs_segment& b = a.seg2;
+        b.P = P - (int32_t)P1, b.M = M;
+        b.means3D = a.means3D + 3 * P1, b.shs = a.shs + 3 * (size_t)M * P1, b.opacities = a.opacities + P1;
+        b.scales = a.scales + 3 * P1, b.rotations = a.rotations + 4 * P1;
+        bw.seg2_dL_dopacity = bw.dL_dopacity + P1, bw.seg2_dL_dcolors = bw.dL_dcolors + 3 * P1, bw.seg2_dL_dmeans3D = bw.dL_dmeans3D + 3 * P1;
+        bw.seg2_dL_dcov3D = bw.dL_dcov3D + 6 * P1, bw.seg2_dL_dsh = bw.dL_dsh + 3 * (size_t)M * P1;
+        bw.seg2_dL_dscales = bw.dL_dscales + 3 * P1, bw.seg2_dL_drotations = bw.dL_drotations + 4 * P1;
+    }
 
     // with a hint the host also offers the checkpoint buffer of the depth-segmented backward (small frames are sparse frames)
-    a.backward_checkpoints = use_hint ? 1 : 0;
+    a.backward_checkpoints = use_hint ? 1 : 0;   // (mode 3 too)
     int64_t N = -1;
     for (int frame = 0; frame < (use_hint ? 2 : 1); ++frame) {   // second frame: capacity guessed from the first
         a.binning_capacity_hint = frame == 0 ? 0 : N + N / 8 + 4096;

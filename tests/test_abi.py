@@ -41,6 +41,9 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(hgs_settings), sizeof(hgs_forward_args), sizeof(hgs_forward_state), sizeof(hgs_backward_args));
   printf("%zu %zu %zu %zu\n", offsetof(hgs_forward_args, P), offsetof(hgs_forward_args, means3D), offsetof(hgs_forward_args, radii), offsetof(hgs_settings, campos));
   printf("%zu %zu %zu %zu\n", offsetof(hgs_backward_args, state), offsetof(hgs_backward_args, dL_dout_color), offsetof(hgs_backward_args, grad_accum), offsetof(hgs_backward_args, dL_drotations));
+  /* ABI v6 / v7: the checkpoint buffer and the second segment */
+  printf("%zu %zu %zu %zu\n", sizeof(hgs_segment), offsetof(hgs_forward_args, backward_checkpoints), offsetof(hgs_forward_args, scratch_bytes), offsetof(hgs_forward_args, seg2));
+  printf("%zu %zu %zu %zu\n", offsetof(hgs_segment, cov3D_precomp), offsetof(hgs_forward_state, ckpt), offsetof(hgs_forward_state, n_token), offsetof(hgs_backward_args, seg2_dL_drotations));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
@@ -50,7 +53,10 @@ int main(void) {
     S, F, St, B = dgr._Settings, dgr._ForwardArgs, dgr._ForwardState, dgr._BackwardArgs
     assert v[:4] == [C.sizeof(S), C.sizeof(F), C.sizeof(St), C.sizeof(B)]
     assert v[4:8] == [F.P.offset, F.means3D.offset, F.radii.offset, S.campos.offset]
-    assert v[8:] == [B.state.offset, B.dL_dout_color.offset, B.grad_accum.offset, B.dL_drotations.offset]
+    assert v[8:12] == [B.state.offset, B.dL_dout_color.offset, B.grad_accum.offset, B.dL_drotations.offset]
+    Sg = dgr._Segment
+    assert v[12:16] == [C.sizeof(Sg), F.backward_checkpoints.offset, F.scratch_bytes.offset, F.seg2.offset]
+    assert v[16:] == [Sg.cov3D_precomp.offset, St.ckpt.offset, St.n_token.offset, B.seg2_dL_drotations.offset]
 
 
 def test_scratch_size_queries_and_offsets():

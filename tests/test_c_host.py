@@ -29,7 +29,7 @@ def test_host_builds_against_the_header_and_library():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_hint", [0, 1, 2])   # 2: plus deferred frames in caller-provided scratch
+@pytest.mark.parametrize("use_hint", [0, 1, 2, 3])   # 2: plus deferred frames in caller-provided scratch; 3: the two-segment form
 def test_c_host_matches_the_oracle(use_hint, device, tmp_path):
     sc = make_scene(**CASES["basic_d3"])
     inp = oracle_inputs(sc)

@@ -169,12 +169,16 @@ def test_c3_lbs_posed_human_through_the_rasterizer(P, device):
         assert rel_l2(t.grad.cpu().numpy().reshape(ref[k].shape), ref[k]) <= 2 * GRAD_REL_TOL, k
 
 
+@pytest.mark.parametrize("joint", ["second_segment", "concat"])
 @pytest.mark.parametrize("n_human,n_scene", [(30_000, 100_000), (110_210, 200_000)])
-def test_c4_joint_human_scene_1080p(n_human, n_scene, device):
+def test_c4_joint_human_scene_1080p(n_human, n_scene, joint, device, monkeypatch):
     """(110 210, 200 000) is the full BASELINE configs[3] size (SMPL subdivided twice, hugs_human.yaml:28 + the 200k scene;
     what tools/bench_c4.py times): both renders through render_human_scene with the side stream on, the sparse-frame
-    backward on the human-only render, radii exact, images and every gradient against the oracle."""
-    from hugs_amd.renderer import render_human_scene
+    backward on the human-only render, radii exact, images and every gradient against the oracle.  The joint render goes
+    through the two-segment form of the C ABI (the scene as hgs_segment: nothing concatenated, gradients written in place)
+    and, "concat", through the reference's own torch.cat form."""
+    from hugs_amd.renderer import gs_renderer, render_human_scene
+    monkeypatch.setattr(gs_renderer, "_JOINT_CONCAT", joint == "concat")
     H, W = 1080, 1920
     cam0 = syn.pinhole_camera(H, W)
     hm = human_gaussians(n_human, seed=7)

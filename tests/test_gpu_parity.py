@@ -809,3 +809,63 @@ def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):
     assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
     assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
     check_image(color.cpu().numpy(), ref["color"], "36k tiles")
+
+
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_second_segment_equals_the_concatenated_call(name, binding, device, monkeypatch):
+    """hgs_segment (ABI v7): the Gaussians split at an arbitrary index into a first set and a `second` one, handed over
+    without concatenation, render the SAME frame as the one-set call -- image and radii bit for bit (same Gaussian indices,
+    same sorted list) -- and every gradient lands in its own model's tensor, equal to the slice of the one-set gradient up
+    to the summation order of the float atomics.  What it replaces: the five torch.cat of
+    /root/reference/hugs/renderer/gs_renderer.py:33-37 and autograd's split of their gradients.  The second set's SH
+    tensor is stored with a different number of coefficients where the degree allows it (M may differ per segment)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = make_scene(**CASES[name])
+    P = sc["means3D"].shape[0]
+    if P < 2:
+        pytest.skip("nothing to split")
+    cut = max(1, (2 * P) // 5)
+    t, color, radii = run_gpu(sc, device)
+    dL = to_dev(sc["dL_dpix"], device)
+    color.backward(dL)
+
+    keys = ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
+    a = {k: (to_dev(sc[k][:cut], device, True) if sc[k] is not None else None) for k in keys}
+    b = {k: (to_dev(sc[k][cut:], device, True) if sc[k] is not None else None) for k in keys}
+    K = (sc["D"] + 1) ** 2
+    if sc["shs"] is not None and K < sc["M"]:   # the second model stores only the coefficients the degree uses
+        b["shs"] = to_dev(sc["shs"][cut:, :K], device, True)
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+    c2, r2 = GaussianRasterizer(gpu_settings(sc, device))(
+        means3D=a["means3D"], means2D=means2D, opacities=a["opacities"], shs=a["shs"], colors_precomp=a["colors_precomp"],
+        scales=a["scales"], rotations=a["rotations"], cov3D_precomp=a["cov3D_precomp"],
+        second={k: v for k, v in b.items() if v is not None})
+    assert torch.equal(r2, radii) and torch.equal(c2, color)
+    c2.backward(dL)
+    assert rel_l2(means2D.grad.cpu().numpy(), t["means2D"].grad.cpu().numpy()) <= 1e-5
+    for k in keys:
+        if t[k] is None:
+            continue
+        full = t[k].grad.cpu().numpy()
+        assert rel_l2(a[k].grad.cpu().numpy(), full[:cut]) <= 1e-5, k
+        second_ref = full[cut:, :K] if (k == "shs" and K < sc["M"]) else full[cut:]
+        assert rel_l2(b[k].grad.cpu().numpy(), second_ref) <= 1e-5, k
+
+
+def test_second_segment_argument_errors(device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(**CASES["basic_d3"])
+    t = gpu_tensors(sc, device)
+    rast = GaussianRasterizer(gpu_settings(sc, device))
+    kw = dict(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    # a second set of another KIND (precomputed colours behind SHs) is refused by the library, not rendered wrongly
+    bad = {"means3D": t["means3D"], "opacities": t["opacities"], "colors_precomp": t["means3D"], "scales": t["scales"],
+           "rotations": t["rotations"]}
+    with pytest.raises(RuntimeError, match="same kinds of inputs"):
+        rast(**kw, second=bad)
+    with pytest.raises(RuntimeError, match="coefficients"):   # too few SH coefficients for the active degree
+        rast(**kw, second={"means3D": t["means3D"], "opacities": t["opacities"], "shs": t["shs"][:, :4].contiguous(),
+                           "scales": t["scales"], "rotations": t["rotations"]})

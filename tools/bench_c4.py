@@ -45,7 +45,8 @@ def main(steps=100, warmup=15):
     def step():
         pkg = render_human_scene(data, human, scene, bg_color=bg, human_bg_color=hbg, render_mode="human_scene",
                                  render_human_separate=True)
-        ((pkg["render"] * w1).sum() + (pkg["human_img"] * w2).sum()).backward()
+        # fixed dL/dimage for both renders, handed to autograd directly (as bench.py does): no stand-in loss kernels in the timing
+        torch.autograd.backward([pkg["render"], pkg["human_img"]], [w1, w2])
         for x in leaves:
             x.grad = None
 
@@ -66,6 +67,7 @@ def main(steps=100, warmup=15):
     profile_enable(())
     print(json.dumps({"stages_ms_both_renders": stages, "workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
                       "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
+                      "joint_render": "torch.cat (reference form)" if os.environ.get("HGS_JOINT_CONCAT", "0") == "1" else "second segment (no concatenation)",
                       "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1)}))
 
 

@@ -171,7 +171,7 @@ def host_cpu():
 
 def measured_copy_peak(torch, device, nbytes=1 << 30, reps=10):
     """Device-to-device copy rates (read + write bytes / time) of this GPU, now -- the practical HBM ceiling next to the
-    datasheet figure: (the library's float4 grid-stride copy kernel -- the shape MI355X_MICROARCH.md measures 6.29 TB/s
+    datasheet figure: (the library's float4-per-thread copy kernel -- the shape MI355X_MICROARCH.md measures 6.29 TB/s
     with --, torch's Tensor.copy_)."""
     import ctypes
     import diff_gaussian_rasterization as dgr
@@ -376,7 +376,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dominant], "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                      "peak_measured": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
-                     "peak_measured_how": "1 GiB device-to-device float4 grid-stride copy kernel (hgs_copy_bandwidth) on this GPU in "
+                     "peak_measured_how": "1 GiB device-to-device float4-per-thread copy kernel (hgs_copy_bandwidth) on this GPU in "
                                           "this run, (read + write bytes) / time; peak_torch_copy = the same with Tensor.copy_",
                      "peak_torch_copy": round(torch_copy_peak, 1),
                      "traffic": None, "algorithmic_bytes_per_launch": int(dom_B),

@@ -279,7 +279,7 @@ int32_t hgs_profile_read(int32_t stage, double *total_ms, int64_t *launches);
 void hgs_profile_reset(void);
 const char *hgs_stage_name(int32_t stage);
 
-/* Measurement aid: one float4 grid-stride device-to-device copy of `bytes` (a multiple of 16) on `stream` -- bench.py times
+/* Measurement aid: one float4-per-thread device-to-device copy of `bytes` (a multiple of 16) on `stream` -- bench.py times
  * it with events for `roofline.peak_measured`, the practical HBM ceiling of the GPU it runs on. */
 int32_t hgs_copy_bandwidth(void *dst, const void *src, size_t bytes, void *stream);
 

@@ -548,18 +548,24 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     return HGS_OK;
 }
 
-// Measurement aid (bench.py's `roofline.peak_measured`): a float4 grid-stride copy, the kernel shape the microarchitecture
-// guide measures the practical HBM ceiling with.  bytes must be a multiple of 16; src and dst 16-byte aligned.
+// Measurement aid (bench.py's `roofline.peak_measured`): a float4 copy, one element per thread -- the kernel shape the
+// microarchitecture guide measures the practical HBM ceiling with (6.29 TB/s there; 6.23-6.26 on this pool's boxes,
+// tools/microbench/copy_bw.hip: a grid-stride loop over the same data reaches only 4.5-5.7 TB/s, whatever its grid and
+// unrolling -- every thread then walks its own far-apart stream).  bytes must be a multiple of 16; 16-byte aligned pointers.
 __global__ void __launch_bounds__(256) copy_bandwidth_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n)
 {
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 int32_t hgs_copy_bandwidth(void* dst, const void* src, size_t bytes, void* stream)
 {
     if (!dst || !src || (bytes & 15u) || (((uintptr_t)dst | (uintptr_t)src) & 15u)) return fail(HGS_ERR_INVALID_ARGUMENT, "bad arguments");
-    // 256 CUs x 8 workgroups of four waves: every SIMD holds eight waves of loads in flight
-    hipLaunchKernelGGL(copy_bandwidth_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float4*)dst, (const float4*)src, bytes / 16);
+    const size_t n = bytes / 16;
+    if (n == 0) return HGS_OK;
+    if ((n + 255) / 256 > 0x7FFFFFFFull) return fail(HGS_ERR_INVALID_ARGUMENT, "too large for one launch");
+    hipLaunchKernelGGL(copy_bandwidth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)dst,
+                       (const float4*)src, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(HGS_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(e));
     return HGS_OK;

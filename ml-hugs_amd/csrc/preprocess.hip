@@ -5,6 +5,8 @@
 // This translation unit is compiled with -ffp-contract=off: radius, tile rectangle, tiles_touched and
 // the depth bits are integer functions of fp32 arithmetic and must round exactly as written (they are
 // compared bit-for-bit against the CPU oracle).  Division and sqrt are IEEE (correctly rounded).
+#include <cstdlib>
+
 #include "hgs_common.h"
 #include "binning_walk.h"
 
@@ -97,7 +99,7 @@ __device__ __forceinline__ void ewa_project(const float* pv, const Camera& cam, 
 }
 
 template <int K>
-__device__ __forceinline__ void sh_backward_rows(const float (&B)[16], const float* __restrict__ sh, float* __restrict__ dsh,
+__device__ __forceinline__ void sh_backward_rows(const float (&B)[16], const float* sh, float* dsh,  // (sh may BE dsh: an LDS row)
                                                  float dr0, float dr1, float dr2, float (&shw)[16])
 {
     float c[K][3];
@@ -356,6 +358,16 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // ------------------------------------------------------------------------------------------------
 // K8+K9 fused: one thread per Gaussian, only radius > 0 does work; every output element is written here (zeros for
 // culled Gaussians and SH coefficients above the active degree), the caller pre-zeroes nothing.
+//
+// The SH rows -- 192 bytes per Gaussian on the [P,16,3] layout the HUGS models keep -- are moved by the WAVE, not by the
+// thread: a thread reading or writing its own row makes every load / store instruction touch 64 different cache lines,
+// one dword each, and the kernel ran on the address path instead of on HBM (WRITE_SIZE 1.32x the algorithmic bytes).
+// Here a wave's 64 rows are one contiguous 12 KB block: it is written (and, with coop_mode bit 1, read) with float4
+// accesses that are whole lines, staged through LDS -- a row per lane with an odd stride of 3 K + 1 dwords (K = coefficients of the
+// active degree; conflict-free) -- and the coefficients above the active degree (180 of every 192 bytes at degree 0)
+// are written as zeros straight from registers.  Waves whose rows are not one block of one array (M != 16, a wave that
+// straddles the two segments) keep the per-thread path.
+constexpr int SH_ROW_F4 = 12;  // float4 per row at M = 16
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                            const float* __restrict__ opacities_, const float* __restrict__ scales_, const float* __restrict__ rots_,
@@ -365,10 +377,42 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity_,
                            float* __restrict__ dL_dcolors_, float* __restrict__ dL_dmeans3D_,
                            float* __restrict__ dL_dsh_, float* __restrict__ dL_dscale_, float* __restrict__ dL_drot_,
-                           float* __restrict__ dL_dcov3D_, SecondGrads out2)
+                           float* __restrict__ dL_dcov3D_, SecondGrads out2, int coop_mode)
 {
+    extern __shared__ float sh_stage[];  // [waves][64][3 K + 1]
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int lane = threadIdx.x & 63;
+    // ---- wave-level view of the SH rows (all values wave-uniform) ----
+    const int wave_first = __builtin_amdgcn_readfirstlane(i - lane);   // joint index of lane 0's Gaussian
+    if (wave_first >= P) return;
+    const int Kact = (cam.D + 1) * (cam.D + 1), row_stride = 3 * Kact + 1;
+    const bool wave_second = wave_first >= in2.P1;
+    const int seg_end = wave_second ? P : in2.P1;                       // one past the last Gaussian of the wave's segment
+    const int rows = min(64, seg_end - wave_first);                     // rows of the wave that lie in its segment
+    // coop_mode: bit 0 = the wave stores the dL/dsh rows, bit 1 = it also loads the SH rows (else every thread its own)
+    const bool coop = (coop_mode & 1) && shs_ != nullptr && (wave_second ? in2.M : cam.M) == 16 && wave_first + rows >= min(wave_first + 64, P);
+    const bool coop_load = coop && (coop_mode & 2) && cam.D > 0;
+    float* stage = sh_stage + (size_t)(threadIdx.x >> 6) * 64 * row_stride;
+    const size_t wave_row0 = (size_t)(wave_second ? wave_first - in2.P1 : wave_first);
+    if (coop_load) {
+        // the wave's rows, whole lines at a time, into LDS (only the coefficients of the active degree are kept)
+        const float4* src = reinterpret_cast<const float4*>((wave_second ? in2.shs : shs_) + wave_row0 * 48);
+#pragma unroll
+        for (int it = 0; it < SH_ROW_F4; ++it) {
+            const int idx = it * 64 + lane, row = idx / SH_ROW_F4, e = (idx - row * SH_ROW_F4) * 4;
+            if (row < rows && e < 3 * Kact) {
+                const float4 v = src[idx];
+                float* d = stage + row * row_stride + e;
+                d[0] = v.x;
+                if (e + 1 < 3 * Kact) d[1] = v.y;
+                if (e + 2 < 3 * Kact) d[2] = v.z;
+                if (e + 3 < 3 * Kact) d[3] = v.w;
+            }
+        }
+    }
+    // (from here on a thread without a Gaussian only takes part in the wave's row stores)
+    const bool has = i < P;
+    if (!has) i = P - 1;
     // the set of arrays (inputs and gradients) this Gaussian lives in, and its index there; the accumulator, the splat
     // record and dL/dmean2D are indexed by the joint index i
     const bool second = i >= in2.P1;
@@ -407,22 +451,29 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
         acc0.z = -0.5f * acc0.z, acc0.w = -0.5f * acc0.w, acc1.x = -0.5f * acc1.x;
         acc1.y = op > 0.0f ? acc1.y / op : 0.0f;  // sum of G dL/dalpha
     }
-    dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
-    dL_dopacity[j] = acc1.y;
-    dL_dcolors[3 * j] = acc1.z, dL_dcolors[3 * j + 1] = acc1.w, dL_dcolors[3 * j + 2] = acc_b;
+    if (has) {
+        dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+        dL_dopacity[j] = acc1.y;
+        dL_dcolors[3 * j] = acc1.z, dL_dcolors[3 * j + 1] = acc1.w, dL_dcolors[3 * j + 2] = acc_b;
+    }
 
     const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
-    if (__float_as_int(tail.z) <= 0) {
+    const bool live = has && __float_as_int(tail.z) > 0;
+    float* my_row = stage + lane * row_stride;  // this Gaussian's row of the wave's LDS stage (coop)
+    if (has && !live) {
         // every output is fully written by this kernel (the caller does not pre-zero them)
 #pragma unroll
         for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * j + k] = 0.0f, dL_dscale[3 * j + k] = 0.0f;
         reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = 0.0f;
-        if (shs)
+        if (shs && !coop)
             for (int k = 0; k < 3 * M; ++k) dL_dsh[j * M * 3 + k] = 0.0f;
-        return;
     }
+    if (coop && !live)
+        for (int k = 0; k < 3 * Kact; ++k) my_row[k] = 0.0f;
+    // (no early return: every lane takes part in the wave's row stores at the end)
+    auto per_gaussian = [&]() {
     const uint32_t clamped = __float_as_uint(tail.w);
 
     const float x = means3D[3 * j], y = means3D[3 * j + 1], z = means3D[3 * j + 2];
@@ -505,21 +556,32 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
         float len = sqrtf(vx * vx + vy * vy + vz * vz);
         float X = vx / len, Y = vy / len, Z = vz / len;
         const int D = cam.D;
-        const float* sh = shs + j * M * 3;
-        float* dsh = dL_dsh + j * M * 3;
         float B[16];
         sh_basis(D, X, Y, Z, B);
         const int K = (D + 1) * (D + 1);
         // shw[k] = sh[k] . dL/dcolour for the direction gradient, and dL/dsh[k] = B[k] dL/dcolour: the coefficient count
         // is a compile-time constant inside each case, so all loads are in flight together (see sh_dot)
         float shw[16];
-        switch (D) {
-            case 0: sh_backward_rows<1>(B, sh, dsh, dr0, dr1, dr2, shw); break;
-            case 1: sh_backward_rows<4>(B, sh, dsh, dr0, dr1, dr2, shw); break;
-            case 2: sh_backward_rows<9>(B, sh, dsh, dr0, dr1, dr2, shw); break;
-            default: sh_backward_rows<16>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+        if (coop) {
+            // rows through the wave's LDS stage: read from it (degree 0: the three floats straight from memory), written to it
+            const float* sh_in = coop_load ? my_row : shs + j * M * 3;
+            switch (D) {
+                case 0: sh_backward_rows<1>(B, shs + j * M * 3, my_row, dr0, dr1, dr2, shw); break;
+                case 1: sh_backward_rows<4>(B, sh_in, my_row, dr0, dr1, dr2, shw); break;
+                case 2: sh_backward_rows<9>(B, sh_in, my_row, dr0, dr1, dr2, shw); break;
+                default: sh_backward_rows<16>(B, sh_in, my_row, dr0, dr1, dr2, shw); break;
+            }
+        } else {
+            const float* sh = shs + j * M * 3;
+            float* dsh = dL_dsh + j * M * 3;
+            switch (D) {
+                case 0: sh_backward_rows<1>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+                case 1: sh_backward_rows<4>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+                case 2: sh_backward_rows<9>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+                default: sh_backward_rows<16>(B, sh, dsh, dr0, dr1, dr2, shw); break;
+            }
+            for (int k = 3 * K; k < 3 * M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         }
-        for (int k = 3 * K; k < 3 * M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
 #define SHW(k) shw[k]
         if (D > 0) {
@@ -608,6 +670,26 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
         for (int k = 0; k < 3; ++k) dL_dscale[3 * j + k] = 0.0f;
         reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    };  // per_gaussian
+    if (live) per_gaussian();
+
+    if (coop) {
+        // the wave's 64 rows of dL/dsh leave as whole lines: the staged coefficients of the active degree, zeros above it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4* dst = reinterpret_cast<float4*>((wave_second ? out2.dL_dsh : dL_dsh_) + wave_row0 * 48);
+#pragma unroll
+        for (int it = 0; it < SH_ROW_F4; ++it) {
+            const int idx = it * 64 + lane, row = idx / SH_ROW_F4, e = (idx - row * SH_ROW_F4) * 4;
+            if (row < rows) {
+                const float* r = stage + row * row_stride + e;
+                float4 v;
+                v.x = e < 3 * Kact ? r[0] : 0.0f, v.y = e + 1 < 3 * Kact ? r[1] : 0.0f;
+                v.z = e + 2 < 3 * Kact ? r[2] : 0.0f, v.w = e + 3 < 3 * Kact ? r[3] : 0.0f;
+                dst[idx] = v;
+            }
+        }
+    }
 }
 
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st)
@@ -619,10 +701,16 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
                            f.seg2.rotations, f.seg2.cov3D_precomp};
     const SecondGrads out2{a.seg2_dL_dopacity, a.seg2_dL_dcolors, a.seg2_dL_dmeans3D, a.seg2_dL_dsh, a.seg2_dL_dscales,
                            a.seg2_dL_drotations, a.seg2_dL_dcov3D};
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, st, P, cam, f.means3D, f.shs,
+    static const int forced = [] { const char* e = getenv("HGS_K8_COOP"); return e ? atoi(e) : -1; }();   // measurement override
+    // default: the wave STORES the rows; loading them through LDS as well was measured slower at every degree (C2, degree 3:
+    // 37.0 us per-thread / 32.0 store only / 39.4 load + store; degree 1: 38.3 / 25.5 / 27.9 -- the round trip through LDS
+    // sits in front of the whole per-Gaussian computation)
+    const int coop_mode = forced >= 0 ? forced : 1;
+    const size_t stage_bytes = (f.shs && coop_mode) ? (size_t)256 * (3 * (cam.D + 1) * (cam.D + 1) + 1) * sizeof(float) : 0;  // [4 waves][64 rows][3 K + 1]
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), stage_bytes, st, P, cam, f.means3D, f.shs,
                        f.opacities, f.scales, f.rotations, f.cov3D_precomp, in2, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
                        a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
-                       a.dL_drotations, a.dL_dcov3D, out2);
+                       a.dL_drotations, a.dL_dcov3D, out2, coop_mode);
 }
 
 // K10

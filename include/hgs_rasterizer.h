@@ -45,7 +45,10 @@ enum {
     HGS_ERR_HIP = -3,
     HGS_ERR_NO_DEVICE = -4,
     HGS_PENDING = -5,        /* hgs_forward_poll: the frame's tile scan has not run yet */
-    HGS_ERR_OVERFLOW = -6    /* hgs_forward_poll: a deferred frame needed more binning entries than it was given */
+    HGS_ERR_OVERFLOW = -6,   /* hgs_forward_poll: a deferred frame needed more binning entries than it was given; forward /
+                                poll: the frame has 2^32 - 16 or more (tile, Gaussian) pairs -- more than list positions can address */
+    HGS_ERR_EXPIRED = -7     /* hgs_forward_poll: the frame's result slot has been handed to a later frame (more than 1 024 forwards
+                                were issued before this deferred frame was polled): its N is lost, run the frame again */
 };
 
 /* Returns a device pointer to at least `bytes` bytes, 256-byte aligned, or NULL. */
@@ -290,6 +293,11 @@ int32_t hgs_copy_bandwidth(void *dst, const void *src, size_t bytes, void *strea
  * pass dL/dout_color, all set unless clamp_output clipped them), "ranges". Returns (size_t)-1 for an unknown name. */
 size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int32_t image_height,
                           int32_t image_width);
+
+/* Test/debug introspection of the library's own (host-side) state: "tile_counter_entries" (per-stream counter arrays it
+ * currently keeps), "tile_counter_max_entries" (the bound beyond which idle streams' arrays are dropped), "slot_ring"
+ * (result slots: forwards after which an unpolled deferred frame expires).  -1 for an unknown name. */
+int64_t hgs_debug_stat(const char *name);
 
 #ifdef __cplusplus
 }

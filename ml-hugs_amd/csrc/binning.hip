@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
+constexpr uint32_t N_TOO_MANY = 0xFFFFFFF0u;  // pair counts from here on are reported as "too many" (32-bit list positions)
 
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
@@ -58,7 +59,8 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t n_large, n_nonempty;
-    if (threadIdx.x == 0) n_large = 0, n_nonempty = 0;
+    __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
+    if (threadIdx.x == 0) n_large = 0, n_nonempty = 0, total64 = 0ull;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
     for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
@@ -87,9 +89,13 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         if (lane == 63) wsum[w] = inc;
         // non-empty tiles of the wave (for the sparse-frame decision)
         uint32_t ne = nonempty;
+        unsigned long long m64 = mine;  // (eight counts below 2^26 each: `mine` itself cannot wrap)
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ne += (uint32_t)__shfl_xor((int)ne, d, 64);
-        if (lane == 0 && ne) atomicAdd(&n_nonempty, ne);
+        for (int d = 32; d >= 1; d >>= 1) {
+            ne += (uint32_t)__shfl_xor((int)ne, d, 64);
+            m64 += (unsigned long long)__shfl_xor((long long)m64, d, 64);
+        }
+        if (lane == 0 && ne) atomicAdd(&n_nonempty, ne), atomicAdd(&total64, m64);
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
@@ -135,7 +141,10 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        n_total[0] = carry, n_total[1] = carry > capacity ? 1u : 0u, n_total[2] = n_large;
+        // more pairs than 32-bit positions can address (N_TOO_MANY and above are reserved): the gate closes whatever the
+        // capacity, and the host is told N = 0xFFFFFFFF, which it turns into HGS_ERR_OVERFLOW
+        if (total64 >= (unsigned long long)N_TOO_MANY) carry = 0xFFFFFFFFu;
+        n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u, n_total[2] = n_large;
         if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
         // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
         // the backward blend then splits long tiles over four waves

@@ -3,7 +3,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "hgs_common.h"
@@ -122,24 +124,44 @@ HostSlot host_slot()
     return {g_slot_base + 8 * (next % SLOT_RING), next, next % SLOT_RING};
 }
 
+// What the slot says about ticket `mine`: 1 = it carries it (N and flags are there), 0 = not yet (it still holds an older
+// frame's word, or nothing), -1 = EXPIRED: it carries a LATER ticket -- the ring went all the way round (SLOT_RING forwards)
+// before this frame was looked at, and its N is gone.  Tickets are 30-bit serial numbers: "later" = ahead by less than 2^29.
+int slot_state(unsigned long long v, uint32_t mine)
+{
+    const uint32_t t = (uint32_t)(v >> 32) & 0x3FFFFFFFu;
+    if (t == mine) return 1;
+    if (t == 0) return 0;
+    return (((t - mine) & 0x3FFFFFFFu) < 0x20000000u) ? -1 : 0;
+}
+
+int expired()
+{
+    return fail(HGS_ERR_EXPIRED, "the deferred frame's result slot was reused by a later frame (more than %u forwards since): run it again", SLOT_RING);
+}
+
 // Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
 // (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
 int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out, bool* long_out)
 {
     for (unsigned spins = 1;; ++spins) {
         const unsigned long long v = *hs.word;
-        if (((uint32_t)(v >> 32) & 0x3FFFFFFFu) == hs.ticket) {
+        const int state = slot_state(v, hs.ticket);
+        if (state > 0) {
             *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0, *long_out = ((v >> 62) & 1u) != 0;
             return HGS_OK;
         }
+        if (state < 0) return expired();
         if ((spins & 0x3FFF) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess) {
                 const unsigned long long v2 = *hs.word;
-                if (((uint32_t)(v2 >> 32) & 0x3FFFFFFFu) == hs.ticket) {
+                const int state2 = slot_state(v2, hs.ticket);
+                if (state2 > 0) {
                     *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0, *long_out = ((v2 >> 62) & 1u) != 0;
                     return HGS_OK;
                 }
+                if (state2 < 0) return expired();
                 return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
             }
             if (q != hipErrorNotReady) return fail(HGS_ERR_HIP, "HIP error while waiting for tile_scan: %s", hipGetErrorString(q));
@@ -151,50 +173,111 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
 // Per-tile pair counters: one small device array per (device, stream), ZERO between frames -- the preprocess kernel adds
 // into it and tile_scan_kernel, its only reader, zeroes what it read.  (A frame cannot zero them itself: the adds of the
 // preprocess kernel's workgroups must not race with a fill by another workgroup of the same kernel; a memset node in
-// front of every frame is a launch this design does without.)  An entry is re-zeroed before use if the previous call on
-// its stream ended between the preprocess kernel and the scan (an error return).
+// front of every frame is a launch this design does without.)
+//  * An entry is LEASED from the moment a forward call picks it until that call has enqueued the scan (or gives up): a second
+//    host thread issuing frames on the same stream waits at the lease, so its preprocess kernel can never add into counters
+//    the first one's scan has not consumed yet.  A call that ends between the two kernels leaves the entry marked dirty and
+//    the next lease zeroes it first.
+//  * The table is a hash map, and bounded: beyond TC_MAX_ENTRIES, entries of streams that are idle (or gone) are dropped and
+//    their arrays freed.  An array that has become too small (a larger frame on the same stream) is freed after the
+//    stream has drained -- growth is rare, one synchronisation then is cheap.
 struct TileCounters {
-    int dev; hipStream_t st; uint32_t* buf; size_t tiles; bool dirty;
+    uint32_t* buf = nullptr; size_t tiles = 0; bool dirty = true;
+    std::mutex lease;
 };
+struct TcKey {
+    int dev; hipStream_t st;
+    bool operator==(const TcKey& o) const { return dev == o.dev && st == o.st; }
+};
+struct TcHash {
+    size_t operator()(const TcKey& k) const { return std::hash<const void*>()((const void*)k.st) * 31u + (size_t)k.dev; }
+};
+constexpr size_t TC_MAX_ENTRIES = 64;
 std::mutex g_tc_mu;
-std::vector<TileCounters> g_tc;
+std::unordered_map<TcKey, std::unique_ptr<TileCounters>, TcHash> g_tc;
 
-int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, size_t* index)
+// RAII lease of a stream's counters (see above)
+struct TileCounterLease {
+    TileCounters* e = nullptr;
+    bool scan_enqueued = false;
+    void release()
+    {
+        if (!e) return;
+        e->dirty = !scan_enqueued;
+        e->lease.unlock();
+        e = nullptr;
+    }
+    ~TileCounterLease() { release(); }
+};
+
+int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, TileCounterLease* lease)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_tc_mu);
-    size_t k = 0;
-    for (; k < g_tc.size(); ++k)
-        if (g_tc[k].dev == dev && g_tc[k].st == st) break;
-    if (k == g_tc.size()) g_tc.push_back({dev, st, nullptr, 0, true});
-    TileCounters& e = g_tc[k];
+    TileCounters* e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_tc_mu);
+        auto it = g_tc.find(TcKey{dev, st});
+        if (it == g_tc.end()) {
+            if (g_tc.size() >= TC_MAX_ENTRIES) {
+                // drop what is not in use: entries nobody holds whose stream has nothing pending (or no longer exists)
+                for (auto k = g_tc.begin(); k != g_tc.end();) {
+                    TileCounters* c = k->second.get();
+                    bool drop = false;
+                    if (k->first.dev == dev && c->lease.try_lock()) {
+                        drop = hipStreamQuery(k->first.st) != hipErrorNotReady;
+                        (void)hipGetLastError();  // (a destroyed stream's handle is an error here, not later)
+                        c->lease.unlock();
+                    }
+                    if (drop) {
+                        if (c->buf) (void)hipFree(c->buf);
+                        k = g_tc.erase(k);
+                    } else
+                        ++k;
+                }
+            }
+            it = g_tc.emplace(TcKey{dev, st}, std::make_unique<TileCounters>()).first;
+        }
+        e = it->second.get();
+    }
+    e->lease.lock();  // (outside the table lock: another thread may be between its preprocess kernel and its scan)
+    lease->e = e;
     const size_t want = (tiles + 7) / 8 * 8;  // the scan reads whole groups of eight
-    if (e.tiles < want) {
-        // (the old, smaller array is left to the stream's earlier frames; it is a few KB)
-        if (hipMalloc((void**)&e.buf, want * sizeof(uint32_t)) != hipSuccess) return fail(HGS_ERR_ALLOC, "tile counter allocation failed");
-        e.tiles = want, e.dirty = true;
+    if (e->tiles < want) {
+        if (e->buf) {
+            // earlier frames of this stream may still be using the smaller array
+            const hipError_t er = hipStreamSynchronize(st);
+            if (er != hipSuccess) return fail(HGS_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(er));
+            (void)hipFree(e->buf);
+            e->buf = nullptr, e->tiles = 0;
+        }
+        if (hipMalloc((void**)&e->buf, want * sizeof(uint32_t)) != hipSuccess) {
+            e->buf = nullptr;
+            return fail(HGS_ERR_ALLOC, "tile counter allocation failed");
+        }
+        e->tiles = want, e->dirty = true;
     }
-    if (e.dirty) {
-        const hipError_t er = hipMemsetAsync(e.buf, 0, e.tiles * sizeof(uint32_t), st);
+    if (e->dirty) {
+        const hipError_t er = hipMemsetAsync(e->buf, 0, e->tiles * sizeof(uint32_t), st);
         if (er != hipSuccess) return fail(HGS_ERR_HIP, "hipMemsetAsync(tile counters): %s", hipGetErrorString(er));
+        e->dirty = false;
     }
-    e.dirty = true;  // until this call has enqueued the scan
-    *out = e.buf, *index = k;
+    *out = e->buf;
     return HGS_OK;
 }
-void tile_counters_clean(size_t index)
-{
-    std::lock_guard<std::mutex> lk(g_tc_mu);
-    g_tc[index].dirty = false;
-}
 
-bool slot_ready(const HostSlot& hs, uint32_t* n_out, bool* sparse_out, bool* long_out)
+// 1: N and flags read; 0: not there yet; -1: expired
+int slot_ready(const HostSlot& hs, uint32_t* n_out, bool* sparse_out, bool* long_out)
 {
     const unsigned long long v = *hs.word;
-    if (((uint32_t)(v >> 32) & 0x3FFFFFFFu) != hs.ticket) return false;
-    *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0, *long_out = ((v >> 62) & 1u) != 0;
-    return true;
+    const int state = slot_state(v, hs.ticket);
+    if (state > 0) *n_out = (uint32_t)v, *sparse_out = (v >> 63) != 0, *long_out = ((v >> 62) & 1u) != 0;
+    return state;
+}
+
+int too_many_pairs()
+{
+    return fail(HGS_ERR_OVERFLOW, "the frame has 2^32 - 16 or more (tile, Gaussian) pairs: more than 32-bit list positions can address");
 }
 
 int bits_for(uint32_t n)  // number of bits needed to represent values in [0, n)
@@ -296,6 +379,18 @@ size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
 size_t hgs_ckpt_bytes(int64_t N, int32_t H, int32_t W) { return CkptLayout(N, num_tiles_of(H, W)).total; }
 
+int64_t hgs_debug_stat(const char* name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "tile_counter_entries")) {
+        std::lock_guard<std::mutex> lk(g_tc_mu);
+        return (int64_t)g_tc.size();
+    }
+    if (!strcmp(name, "tile_counter_max_entries")) return (int64_t)TC_MAX_ENTRIES;
+    if (!strcmp(name, "slot_ring")) return (int64_t)SLOT_RING;
+    return -1;
+}
+
 size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int32_t W)
 {
     GeomLayout g(P < 1 ? 1 : P, num_tiles_of(H, W));
@@ -356,10 +451,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t* n_total = (uint32_t*)(image + il.n_total);
     uint32_t* large_tiles = (uint32_t*)(image + il.large_tiles);
     uint32_t* tile_count = nullptr;
-    size_t tc_index = 0;
+    TileCounterLease tc_lease;  // held until the scan is enqueued (or this call gives up)
     // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
     const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
-    if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_index)) return rc;
+    if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_lease)) return rc;
     int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
     if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr)
@@ -381,7 +476,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
       launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
                        want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
     STAGE_CHECK(dbg, st, "tile_scan");
-    tile_counters_clean(tc_index);  // the scan, which re-zeroes them, is enqueued
+    // the scan, which re-zeroes the counters, is enqueued: the next frame on this stream may have them
+    tc_lease.scan_enqueued = true;
+    tc_lease.release();
 
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
     const uint32_t* gate = n_total + 1;
@@ -459,6 +556,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t n32 = 0;
     bool sparse = false, has_long = false;
     if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long)) return rc;
+    if (n32 == 0xFFFFFFFFu) return too_many_pairs();  // (every kernel behind the scan was gated off)
     const int64_t N = (int64_t)n32;
     state->num_rendered = N;
     state->sparse_frame = sparse ? 1 : 0;
@@ -486,10 +584,13 @@ int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
     const HostSlot hs{g_slot_base + 8 * index, ticket, index};
     uint32_t n32 = 0;
     bool sparse = false, has_long = false;
-    if (!slot_ready(hs, &n32, &sparse, &has_long)) {
+    const int ready = slot_ready(hs, &n32, &sparse, &has_long);
+    if (ready < 0) return expired();
+    if (ready == 0) {
         if (!block) return HGS_PENDING;
         if (int rc = wait_for_slot(hs, (hipStream_t)stream, &n32, &sparse, &has_long)) return rc;
     }
+    if (n32 == 0xFFFFFFFFu) return too_many_pairs();
     state->sparse_frame = sparse ? 1 : 0, state->has_long_tiles = has_long ? 1 : 0;
     if ((int64_t)n32 > state->binning_capacity)
         return fail(HGS_ERR_OVERFLOW, "deferred frame needed %u binning entries but was given %lld: its output is invalid, run it again",

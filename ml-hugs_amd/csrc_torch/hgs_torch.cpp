@@ -28,6 +28,30 @@ std::map<std::tuple<int, int64_t, int64_t, int64_t>, Hint> g_hints;   // (device
 bool g_use_hint = true;
 bool g_use_ckpt = true;   // leave checkpoints for the depth-segmented backward on sparse frames (HGS_BWD_SEGMENTED=0: off)
 thread_local int64_t t_last_n = -1, t_last_capacity = -1;
+thread_local bool t_last_long = false, t_last_sparse = false;
+
+// + 12.5 % + 4096, rounded up to 1/16 of the next power of two (at least 64 Ki entries): the same number as
+// diff_gaussian_rasterization._round_capacity -- frame after frame asks the caching allocator for the same size
+int64_t round_capacity(int64_t n)
+{
+    const int64_t want = n + n / 8 + 4096;
+    int64_t p2 = 1;
+    while (p2 < want) p2 <<= 1;
+    const int64_t granule = std::max<int64_t>(1 << 16, p2 >> 4);
+    return (want + granule - 1) / granule * granule;
+}
+
+// Scratch of frames that need no backward (the reference's validation / animation / canonical loops run under no_grad,
+// gs_trainer.py:448-684): one persistent arena per (device, stream) instead of an allocation per frame -- work on a stream
+// is ordered, so the next frame on that stream may overwrite it.  (The Python binding keeps the same policy: _arena.)
+std::map<std::pair<int, void*>, Tensor> g_arenas;
+Tensor arena_for(int dev, void* stream, size_t bytes, const at::TensorOptions& bopts)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Tensor& t = g_arenas[{dev, stream}];
+    if (!t.defined() || (size_t)t.numel() < bytes) t = at::empty({(int64_t)(bytes + bytes / 4 + 4096)}, bopts);
+    return t;
+}
 
 inline const float* fptr(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 
@@ -155,8 +179,7 @@ public:
             // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
             a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse)) ? 1 : 0;
             if (g_use_hint && it != g_hints.end()) {
-                // + 12.5 % + 4096, rounded up to 256 Ki entries: frame after frame asks the caching allocator for the same size
-                a.binning_capacity_hint = (it->second.n + it->second.n / 8 + 4096 + 0x3FFFF) & ~(int64_t)0x3FFFF;
+                a.binning_capacity_hint = round_capacity(it->second.n);
                 a.expect_no_long_tiles = it->second.has_long ? 0 : 1;
             }
         }
@@ -168,7 +191,9 @@ public:
             const size_t g = align256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), im = align256(hgs_image_bytes((int32_t)H, (int32_t)W));
             const size_t b = a.binning_capacity_hint > 0 ? align256(hgs_binning_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
             const size_t ck = b && a.backward_checkpoints ? align256(hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
-            scratch = at::empty({(int64_t)(g + im + b + ck)}, bopts);
+            // per frame when backward will need it, else the stream's arena
+            scratch = needs_grad ? at::empty({(int64_t)(g + im + b + ck)}, bopts)
+                                 : arena_for((int)dev.index(), (void*)c10::hip::getCurrentHIPStream(dev.index()).stream(), g + im + b + ck, bopts);
             char* base = (char*)scratch.data_ptr();
             a.scratch[HGS_BUF_GEOM] = base, a.scratch_bytes[HGS_BUF_GEOM] = g;
             a.scratch[HGS_BUF_IMAGE] = base + g, a.scratch_bytes[HGS_BUF_IMAGE] = im;
@@ -187,6 +212,7 @@ public:
             g_hints[key] = Hint{n, bw.state.has_long_tiles != 0, bw.state.sparse_frame != 0};
         }
         t_last_n = n, t_last_capacity = bw.state.binning_capacity;
+        t_last_long = bw.state.has_long_tiles != 0, t_last_sparse = bw.state.sparse_frame != 0;
 
         ctx->mark_non_differentiable({radii});
         if (needs_grad) {
@@ -317,7 +343,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("tanfovx"), py::arg("tanfovy"), py::arg("mod"), py::arg("degree"), py::arg("prefiltered"), py::arg("debug"),
           py::arg("clamp_output"), py::arg("second") = std::vector<Tensor>());
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
-    m.def("last_frame_info", [] { return std::make_pair(t_last_n, t_last_capacity); }, "(N, binning capacity) of this thread's last forward");
+    m.def("last_frame_info", [] { return std::make_tuple(t_last_n, t_last_capacity, t_last_long, t_last_sparse); },
+          "(N, binning capacity, has long tiles, sparse) of this thread's last forward");
     m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse) {
         std::lock_guard<std::mutex> lk(g_mu);
         g_hints[std::make_tuple(dev, P, H, W)] = Hint{n, has_long, sparse};

@@ -112,6 +112,8 @@ def _load():
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.hgs_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+    lib.hgs_debug_stat.argtypes = [C.c_char_p]
+    lib.hgs_debug_stat.restype = C.c_int64
     lib.hgs_copy_bandwidth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.hgs_copy_bandwidth.restype = C.c_int32
     lib.hgs_profile_enable.argtypes = [C.c_uint32]
@@ -228,7 +230,14 @@ _USE_HINT = os.environ.get("HGS_BINNING_HINT", "1") != "0"
 
 
 _max_num_rendered = {}   # largest N seen per shape key: sizes the binning arena of deferred frames
-_DEFERRED_MIN_CAPACITY = 1 << 22
+_DEFERRED_MIN_CAPACITY = 1 << 22   # ceiling of the floor below
+
+
+def _deferred_capacity(seen, H, W):
+    """Binning capacity of a deferred frame: 4x the largest N its shape has shown, and no less than 256 entries per tile
+    (a 1080p frame: 2 Mi entries, a 512x512 one: 256 Ki -- the floor scales with the image instead of being 4 Mi flat)."""
+    tiles = ((H + 15) // 16) * ((W + 15) // 16)
+    return max(4 * seen + 4096, min(_DEFERRED_MIN_CAPACITY, max(1 << 16, 256 * tiles)))
 
 
 # Whether the last frame of a shape was SPARSE (few non-empty tiles): such frames get a checkpoint buffer when a backward
@@ -238,13 +247,15 @@ _last_sparse = {}
 _USE_CKPT = os.environ.get("HGS_BWD_SEGMENTED", "1") != "0"
 
 
-def _remember(key, n, has_long, sparse=None):
+def _remember(key, n, has_long, sparse=None, to_cpp=True):
     if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
         _last_num_rendered.clear()
         _max_num_rendered.clear()
         _last_sparse.clear()
     if sparse is not None:
         _last_sparse[key] = bool(sparse)
+    if to_cpp and _cpp is not None:   # ... and what the Python paths learnt, the C++ node uses
+        _cpp.set_hint(key[0], key[1], key[2], key[3], n, has_long, _last_sparse.get(key, True))
     _last_num_rendered[key] = (n, has_long)
     _max_num_rendered[key] = max(n, _max_num_rendered.get(key, 0))
 
@@ -255,8 +266,17 @@ def _capacity_hint(key):
     if prev is None:
         return 0, 0
     n, had_long = prev
-    # + 12.5 % + 4096, rounded up to 256 Ki entries: frame after frame asks the caching allocator for the same size
-    return (n + n // 8 + 4096 + 0x3FFFF) & ~0x3FFFF, 0 if had_long else 1
+    return _round_capacity(n), 0 if had_long else 1
+
+
+def _round_capacity(n):
+    """+ 12.5 % + 4096, rounded up to a granule PROPORTIONAL to the size (1/16 of the next power of two, at least 64 Ki
+    entries): frame after frame asks the caching allocator for the same size, and a small frame (the 6 890-Gaussian SMPL
+    template at 512x512) no longer carries the 256 Ki-entry granule -- 16.8 MB of binning scratch -- of a 1080p scene.
+    (The C++ binding computes the same number: csrc_torch/hgs_torch.cpp round_capacity.)"""
+    want = n + n // 8 + 4096
+    granule = max(1 << 16, (1 << max(want - 1, 1).bit_length()) >> 4)
+    return (want + granule - 1) // granule * granule
 
 
 _GRAD_NAMES = ("grad_accum", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
@@ -550,7 +570,10 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
                                      float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
                                      bool(rs.prefiltered), bool(rs.debug), bool(clamp_output), list(sec))
-        _last_frame_info = cpp.last_frame_info()
+        n, cap, has_long, sparse = cpp.last_frame_info()
+        _last_frame_info = (n, cap)
+        if radii.numel():   # one hint table for both bindings: what the C++ node learnt, the Python paths (deferred frames) use
+            _remember((means3D.device.index, radii.numel(), int(rs.image_height), int(rs.image_width)), n, has_long, sparse, to_cpp=False)
         return color, radii
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, clamp_output, *sec)
@@ -569,7 +592,9 @@ class DeferredFrame:
         dev = self.color.device
         with torch.cuda.device(dev):
             n = lib.hgs_forward_poll(C.byref(self.state), 1, C.c_void_p(self.stream.cuda_stream))
-            if n == -6:   # HGS_ERR_OVERFLOW: the gated kernels did nothing -- run the frame again, waiting for N this time
+            # HGS_ERR_OVERFLOW: the gated kernels did nothing; HGS_ERR_EXPIRED: the frame ran but its N was lost to a later
+            # frame (more than 1 024 forwards before this resolve) -- either way run the frame again, waiting for N this time
+            if n in (-6, -7) and b"2^32" not in lib.hgs_last_error():
                 self.args.defer_n, self.args.binning_capacity_hint = 0, 0
                 bufs = []
 
@@ -628,7 +653,7 @@ def rasterize_deferred(means3D, opacities, raster_settings, shs=None, colors_pre
             if seen is None:    # nothing known about this shape yet: an ordinary frame that waits for N
                 f.keep["scratch"] = _provide_scratch(f.args, lib, dev, P, H, W, 0, f.stream.cuda_stream)
             else:
-                cap = max(4 * seen + 4096, _DEFERRED_MIN_CAPACITY)
+                cap = _deferred_capacity(seen, H, W)
                 f.args.binning_capacity_hint, f.args.defer_n = cap, 1
                 f.keep["scratch"] = _provide_scratch(f.args, lib, dev, P, H, W, cap, f.stream.cuda_stream)
             n = lib.hgs_rasterize_forward(C.byref(f.args), _ALLOC_FN(_alloc), None, C.byref(f.state),

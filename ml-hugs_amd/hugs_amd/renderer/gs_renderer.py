@@ -219,6 +219,9 @@ def _render_deferred(means3D, feats, opacity, scales, rotations, data, scaling_m
                               scales=scales, rotations=rotations, clamp_output=True)
 
 
+_MAX_PENDING = 256   # deferred frames in flight before the oldest is resolved (the library's result-slot ring has 1 024 entries)
+
+
 def render_batch(frames, num_streams=2):
     """Forward-only (no autograd graph) rendering of independent frames, pipelined.
 
@@ -228,8 +231,14 @@ def render_batch(frames, num_streams=2):
     every frame -- {"render", "viewspace_points", "visibility_filter", "radii"} -- valid on the caller's stream."""
     out, pending = [], []
     main = side = None
+    resolved = 0
     with torch.no_grad():
         for i, fr in enumerate(frames):
+            # a sliding window: a long frame loop (animation, canonical renders) never has more than _MAX_PENDING unresolved
+            # frames -- their result slots in the library are a ring, and an unresolved frame pins its scratch arena's turn
+            while len(pending) - resolved >= _MAX_PENDING:
+                pending[resolved][0].resolve()
+                resolved += 1
             device = fr["means3D"].device
             if main is None:
                 main = torch.cuda.current_stream(device)

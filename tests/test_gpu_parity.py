@@ -234,7 +234,9 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     t1, c1, r1 = run_gpu(sc, device)
     cap = c1.grad_fn.binning_capacity
     assert c1.grad_fn.num_rendered == n
-    assert cap == (n if guess != "ample" else (n + n // 8 + 4096 + 0x3FFFF) & ~0x3FFFF)
+    assert cap == (n if guess != "ample" else dgr._round_capacity(n)) and cap >= n
+    # a granule proportional to the size: the C2 frame keeps its 256 Ki-entry granule, the SMPL template at 512x512 gets 64 Ki
+    assert dgr._round_capacity(1_914_449) == 9 << 18 and dgr._round_capacity(60_000) == 2 << 16
     c1.backward(to_dev(sc["dL_dpix"], device))
     torch.cuda.synchronize()
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
@@ -869,3 +871,123 @@ def test_second_segment_argument_errors(device):
     with pytest.raises(RuntimeError, match="coefficients"):   # too few SH coefficients for the active degree
         rast(**kw, second={"means3D": t["means3D"], "opacities": t["opacities"], "shs": t["shs"][:, :4].contiguous(),
                            "scales": t["scales"], "rotations": t["rotations"]})
+
+
+# ---------------------------------------------------------------------------------------------
+# robustness of the host side of the library
+def test_more_pairs_than_32_bit_positions_is_an_error_not_a_wrap(device):
+    """Sum of tiles touched >= 2^32 - 16: the 32-bit scan would wrap silently (P < 2^26 is checked, N was not).  The scan
+    now also counts in 64 bits, closes the gate and reports N = 0xFFFFFFFF, which forward turns into HGS_ERR_OVERFLOW
+    before anything is allocated for the list.  530 000 splats that each cover all 8 160 tiles of a 1080p frame: 4.3e9 pairs."""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from hugs_amd import synthetic as syn
+    H, W, P = 1080, 1920, 530_000
+    cam = syn.pinhole_camera(H, W)
+    rng = np.random.default_rng(0)
+    means = np.concatenate([rng.uniform(-0.5, 0.5, (P, 2)), rng.uniform(4.0, 6.0, (P, 1))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
+    settings = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"] / 2), math.tan(cam["fovy"] / 2), torch.ones(3, device=device), 1.0,
+                                             t(cam["world_view_transform"]), t(cam["full_proj_transform"]), 0, t(cam["camera_center"]),
+                                             False, False)
+    with torch.no_grad(), pytest.raises(RuntimeError, match=r"2\^32"):
+        GaussianRasterizer(settings)(means3D=t(means), means2D=torch.zeros(P, 3, device=device), opacities=torch.full((P, 1), 0.5, device=device),
+                                     colors_precomp=torch.rand(P, 3, device=device), scales=torch.full((P, 3), 40.0, device=device),
+                                     rotations=t(np.tile([1.0, 0, 0, 0], (P, 1))))
+    torch.cuda.synchronize()
+    # ... and the stream, its counters and the library are fine afterwards
+    sc = make_scene(**CASES["basic_d3"])
+    _, color, _ = run_gpu(sc, device)
+    check_image(color.detach().cpu().numpy(), ho.forward(oracle_inputs(sc))["color"], "after the overflow")
+
+
+def test_deferred_frame_whose_result_slot_was_recycled(device, monkeypatch):
+    """The library publishes every frame's N through a ring of 1 024 pinned slots.  A deferred frame polled only after more
+    than 1 024 later forwards finds a LATER frame's word in its slot: that is now a defined HGS_ERR_EXPIRED (it used to end
+    as "stream went idle without publishing", and a non-blocking poll said HGS_PENDING forever), and resolve() runs the
+    frame again.  render_batch itself never lets it come to that (it resolves in a sliding window)."""
+    import ctypes as C
+    import copy
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd.renderer import gs_renderer
+    _force_ctypes_binding(monkeypatch)
+    lib = dgr._load()
+    ring = lib.hgs_debug_stat(b"slot_ring")
+    assert ring == 1024
+    sc = make_scene(P=500, H=64, W=96, seed=71, D=1, sigma_px=5.0)
+    fr = _orbit_frames(sc, device, 1)[0]
+    with torch.no_grad():
+        want = gs_renderer.render(**fr)
+        first = gs_renderer._render_deferred(fr["means3D"], fr["feats"], fr["opacity"], fr["scales"], fr["rotations"], fr["data"], 1.0,
+                                             fr["bg_color"], fr["active_sh_degree"])
+        assert first.num_rendered is None                                   # really deferred
+        later = [gs_renderer._render_deferred(fr["means3D"], fr["feats"], fr["opacity"], fr["scales"], fr["rotations"], fr["data"], 1.0,
+                                              fr["bg_color"], fr["active_sh_degree"]) for _ in range(ring + 76)]
+        torch.cuda.synchronize()
+        st = dgr._ForwardState.from_buffer_copy(first.state)
+        assert lib.hgs_forward_poll(C.byref(st), 0, None) == -7 and b"result slot" in lib.hgs_last_error()   # HGS_ERR_EXPIRED, also when blocking:
+        assert lib.hgs_forward_poll(C.byref(st), 1, C.c_void_p(first.stream.cuda_stream)) == -7
+        assert later[-1].resolve() > 0                                     # a recent frame's slot is intact
+        n = first.resolve()                                                 # runs the frame again
+        torch.cuda.synchronize()
+        assert n == later[-1].resolve() and torch.equal(first.color, want["render"]) and torch.equal(first.radii, want["radii"])
+    # the sliding window of render_batch: 1 100 frames in one call, every one of them valid
+    monkeypatch.setattr(gs_renderer, "_MAX_PENDING", 64)
+    out = gs_renderer.render_batch((fr for _ in range(ring + 76)), num_streams=2)
+    torch.cuda.synchronize()
+    assert len(out) == ring + 76 and all(torch.equal(o["render"], want["render"]) for o in out[::97] + out[-3:])
+
+
+def test_two_host_threads_on_one_stream_do_not_share_counters_mid_frame(device, monkeypatch):
+    """the per-tile counters live in one array per (device, stream); a forward holds a lease on it from its
+    preprocess kernel to its scan, so a second host thread issuing frames on the same stream cannot add into counters
+    the first frame's scan has not consumed.  Two threads x 150 frames of two different scenes on the default stream:
+    every image equals its scene's serial render bit for bit."""
+    import threading
+    _force_ctypes_binding(monkeypatch)      # (the ctypes call releases the GIL: the two threads really overlap in the library)
+    from hugs_amd.renderer import render
+    scs = [make_scene(P=4000, H=128, W=192, seed=81, D=1, sigma_px=5.0), make_scene(P=2500, H=96, W=160, seed=82, D=0, sigma_px=7.0)]
+    frames = [_orbit_frames(sc, device, 1)[0] for sc in scs]
+    with torch.no_grad():
+        want = [render(**fr)["render"].clone() for fr in frames]
+    torch.cuda.synchronize()
+    bad, errors = [], []
+
+    def worker(k):
+        try:
+            with torch.no_grad():
+                for it in range(150):
+                    img = render(**frames[k])["render"]
+                    if not torch.equal(img, want[k]):
+                        bad.append((k, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    assert not errors and not bad, (errors[:2], bad[:5])
+
+
+def test_tile_counter_table_is_bounded(device):
+    """One counter array per (device, stream) used to be kept forever and searched linearly; now a hash map that drops
+    idle streams' arrays beyond its bound (densification / many side streams churn through streams and shapes)."""
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd.renderer import render
+    lib = dgr._load()
+    bound = lib.hgs_debug_stat(b"tile_counter_max_entries")
+    sc = make_scene(P=300, H=64, W=64, seed=83, D=0)
+    fr = _orbit_frames(sc, device, 1)[0]
+    with torch.no_grad():
+        want = render(**fr)["render"]
+        streams = [torch.cuda.Stream(device) for _ in range(bound + 40)]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(s):
+                img = render(**fr)["render"]
+            s.synchronize()
+            assert torch.equal(img, want)
+    assert 0 < lib.hgs_debug_stat(b"tile_counter_entries") <= bound

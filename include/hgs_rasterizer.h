@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 7
+#define HGS_ABI_VERSION 8
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
@@ -190,7 +190,15 @@ typedef struct hgs_backward_args {
     float *seg2_dL_dsh;         /* [P2,M2,3] or NULL */
     float *seg2_dL_dscales;     /* [P2,3] */
     float *seg2_dL_drotations;  /* [P2,4] */
+    uint32_t flags;             /* HGS_BWD_* bits */
+    uint32_t reserved;
 } hgs_backward_args;
+
+/* hgs_backward_args.flags.  dL/dscales is, by default, the true derivative -- it carries settings.scale_modifier, the factor
+ * between the stored scale and the one the covariance is built from.  The published CUDA kernel omits that factor; with this
+ * bit the library does too.  (Every gradient-enabled call of the reference passes scale_modifier 1.0, where the two agree:
+ * /root/reference/hugs/renderer/gs_renderer.py:26,103.) */
+#define HGS_BWD_UPSTREAM_SCALE_GRAD 1u
 
 int32_t hgs_rasterize_backward(const hgs_backward_args *args, void *stream);
 

@@ -332,6 +332,7 @@ int make_camera(const hgs_forward_args& a, Camera& cam)
     cam.fy = (float)cam.H / (2.0f * s.tanfovy);
     cam.mod = s.scale_modifier;
     cam.D = s.sh_degree, cam.M = a.M;
+    cam.scale_grad_factor = s.scale_modifier;
     return HGS_OK;
 }
 
@@ -607,6 +608,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     hipStream_t st = (hipStream_t)stream;
     Camera cam;
     if (int rc = make_camera(f, cam)) return rc;
+    if (a.flags & HGS_BWD_UPSTREAM_SCALE_GRAD) cam.scale_grad_factor = 1.0f;
     if (f.P == 0) return HGS_OK;
     if (!a.state.geom || !a.state.image || !a.state.binning)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state is missing");

@@ -51,6 +51,7 @@ struct Camera {  // small by-value kernel argument
     int W, H, gx, gy;
     float tanfovx, tanfovy, fx, fy, mod;
     int D, M;
+    float scale_grad_factor;  // backward: mod (the true dL/dscale) or 1 (HGS_BWD_UPSTREAM_SCALE_GRAD)
 };
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }

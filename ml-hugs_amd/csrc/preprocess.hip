@@ -652,7 +652,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
                 dMc[ii] = 2.0f * acc;
             }
             float ds = R[0][jj] * dMc[0] + R[1][jj] * dMc[1] + R[2][jj] * dMc[2];
-            dL_dscale[3 * j + jj] = mod * ds;
+            dL_dscale[3 * j + jj] = cam.scale_grad_factor * ds;
 #pragma unroll
             for (int ii = 0; ii < 3; ++ii) dR[ii][jj] = s[jj] * dMc[ii];
         }

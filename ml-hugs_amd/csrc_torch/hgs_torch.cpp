@@ -26,6 +26,7 @@ struct Hint { int64_t n; bool has_long; bool sparse; };
 std::mutex g_mu;
 std::map<std::tuple<int, int64_t, int64_t, int64_t>, Hint> g_hints;   // (device, P, H, W) -> previous frame of this shape
 bool g_use_hint = true;
+bool g_upstream_scale_grad = false;   // HGS_BWD_UPSTREAM_SCALE_GRAD on every backward (set_upstream_scale_grad)
 bool g_use_ckpt = true;   // leave checkpoints for the depth-segmented backward on sparse frames (HGS_BWD_SEGMENTED=0: off)
 thread_local int64_t t_last_n = -1, t_last_capacity = -1;
 thread_local bool t_last_long = false, t_last_sparse = false;
@@ -285,6 +286,7 @@ public:
         point_at_grads(bw, slab.data_ptr<float>(), gl, M, M2);
         Tensor g = f32c(g_color);
         bw.dL_dout_color = g.data_ptr<float>();
+        bw.flags = g_upstream_scale_grad ? HGS_BWD_UPSTREAM_SCALE_GRAD : 0u;
         int32_t rc;
         {
             c10::DeviceGuard guard(dev);
@@ -352,4 +354,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("clear_hints", [] { std::lock_guard<std::mutex> lk(g_mu); g_hints.clear(); });
     m.def("use_hints", [](bool on) { g_use_hint = on; });
     m.def("use_checkpoints", [](bool on) { g_use_ckpt = on; });
+    m.def("set_upstream_scale_grad", [](bool on) { g_upstream_scale_grad = on; });
 }

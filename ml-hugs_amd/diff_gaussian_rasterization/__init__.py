@@ -25,12 +25,12 @@ import torch
 import torch.nn as nn
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_deferred", "DeferredFrame",
-           "library_path"]
+           "library_path", "set_upstream_scale_grad"]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 7
+_ABI_VERSION = 8
 
 
 def library_path():
@@ -75,10 +75,22 @@ class _BackwardArgs(C.Structure):
                 ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
                 ("seg2_dL_dopacity", C.c_void_p), ("seg2_dL_dcolors", C.c_void_p), ("seg2_dL_dmeans3D", C.c_void_p),
                 ("seg2_dL_dcov3D", C.c_void_p), ("seg2_dL_dsh", C.c_void_p), ("seg2_dL_dscales", C.c_void_p),
-                ("seg2_dL_drotations", C.c_void_p)]
+                ("seg2_dL_drotations", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+HGS_BWD_UPSTREAM_SCALE_GRAD = 1
+# dL/dscales: the true derivative (includes settings.scale_modifier) by default; True reproduces the published kernel, which
+# omits the factor (both bindings; HGS_UPSTREAM_SCALE_GRAD=1 in the environment, or set_upstream_scale_grad()).  The two
+# agree wherever the reference differentiates: it renders with scale_modifier 1.0 (gs_renderer.py:26,103).
+_UPSTREAM_SCALE_GRAD = os.environ.get("HGS_UPSTREAM_SCALE_GRAD", "0") == "1"
+
+
+def set_upstream_scale_grad(on):
+    global _UPSTREAM_SCALE_GRAD
+    _UPSTREAM_SCALE_GRAD = bool(on)
+    if _cpp is not None:
+        _cpp.set_upstream_scale_grad(bool(on))
 _lib = None
 
 
@@ -480,6 +492,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P > 0:
             grad_out_color = _f32c(grad_out_color)
             bw.dL_dout_color = grad_out_color.data_ptr()
+            bw.flags = HGS_BWD_UPSTREAM_SCALE_GRAD if _UPSTREAM_SCALE_GRAD else 0
             prev_dev = torch.cuda.current_device()
             if prev_dev != dev.index:
                 torch.cuda.set_device(dev)
@@ -538,6 +551,7 @@ def _load_cpp():
         raise RuntimeError("_hgs_torch.so was built against another ABI version; rebuild it")
     mod.use_hints(_USE_HINT)
     mod.use_checkpoints(_USE_CKPT)
+    mod.set_upstream_scale_grad(_UPSTREAM_SCALE_GRAD)
     _cpp = mod
     return mod
 

@@ -32,6 +32,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+static int g_upstream_scale_grad = 0; /* see oracle_preprocess_backward */
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -621,7 +623,9 @@ void oracle_preprocess_backward(int P, int M, int D, int H, int W, real tanfovx,
                 }
             for (int jj = 0; jj < 3; ++jj) {
                 real ds = R[0][jj] * dM[0][jj] + R[1][jj] * dM[1][jj] + R[2][jj] * dM[2][jj];
-                dL_dscale[3 * i + jj] = mod * ds;
+                /* the true derivative carries the scale modifier; the published kernel omits the factor (SURVEY.md A.5 note):
+                 * oracle_set_upstream_scale_grad(1) reproduces that convention */
+                dL_dscale[3 * i + jj] = (g_upstream_scale_grad ? (real)1 : mod) * ds;
                 for (int ii = 0; ii < 3; ++ii) dR[ii][jj] = s[jj] * dM[ii][jj];
             }
             dL_drot[4 * i + 0] = R_(2) * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
@@ -640,6 +644,8 @@ void oracle_mark_visible(int P, const real *means3D, const real *V, uint8_t *pre
         present[i] = z > R_(0.2);
     }
 }
+
+void oracle_set_upstream_scale_grad(int on) { g_upstream_scale_grad = on; }
 
 void oracle_set_threads(int n)
 {

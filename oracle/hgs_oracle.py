@@ -53,6 +53,13 @@ def set_threads(n, dtype=np.float32):
     _lib(dtype).oracle_set_threads(int(n))
 
 
+def set_upstream_scale_grad(on):
+    """True: dL/dscale WITHOUT the scale_modifier factor, as the published kernel computes it (the library's
+    HGS_BWD_UPSTREAM_SCALE_GRAD switch); False (default): the true derivative."""
+    for d in (np.float32, np.float64):
+        _lib(d).oracle_set_upstream_scale_grad(int(bool(on)))
+
+
 class Inputs:
     """Plain container of rasterizer inputs (numpy). Shapes as SURVEY.md 8a."""
 

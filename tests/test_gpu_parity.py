@@ -991,3 +991,32 @@ def test_tile_counter_table_is_bounded(device):
             s.synchronize()
             assert torch.equal(img, want)
     assert 0 < lib.hgs_debug_stat(b"tile_counter_entries") <= bound
+
+
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+@pytest.mark.parametrize("upstream", [False, True])
+def test_scale_gradient_convention_switch(upstream, binding, device, monkeypatch):
+    """dL/dscales at scale_modifier 0.7 in both conventions: the true derivative (default: x modifier) and the published
+    kernel's (HGS_BWD_UPSTREAM_SCALE_GRAD: the factor omitted) -- library and oracle take the same switch; every other
+    gradient is untouched by it.  The reference only differentiates at modifier 1.0 (gs_renderer.py:26,103), where the two agree."""
+    import diff_gaussian_rasterization as dgr
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = make_scene(P=300, H=96, W=128, seed=31, D=2, scale_modifier=0.7)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    g_true = ho.backward(inp, ref, sc["dL_dpix"])
+    try:
+        ho.set_upstream_scale_grad(upstream)
+        dgr.set_upstream_scale_grad(upstream)
+        g_ref = ho.backward(inp, ref, sc["dL_dpix"])
+        t, color, _ = run_gpu(sc, device)
+        color.backward(to_dev(sc["dL_dpix"], device))
+    finally:
+        ho.set_upstream_scale_grad(False)
+        dgr.set_upstream_scale_grad(False)
+    assert rel_l2(g_ref["scales"] * (0.7 if upstream else 1.0), g_true["scales"]) <= 1e-6   # the two conventions differ by exactly the modifier
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_l2(t[k].grad.cpu().numpy().reshape(g_ref[k].shape), g_ref[k]) <= GRAD_REL_TOL, k
+    if upstream:
+        assert rel_l2(t["scales"].grad.cpu().numpy(), g_true["scales"]) > 0.2               # and the switch really did something

@@ -184,3 +184,21 @@ def test_analytic_backward_equals_finite_differences_of_the_forward_fp64(name):
         assert err <= 2e-6, (name, k, float(err))
         checked += int(usable.sum())
     assert checked >= 250
+
+
+def test_upstream_scale_gradient_switch_of_the_oracle():
+    """oracle_set_upstream_scale_grad: dL/dscale without the scale_modifier factor (the published kernel's convention; the
+    library's HGS_BWD_UPSTREAM_SCALE_GRAD) = the true derivative / modifier, nothing else changes."""
+    sc = make_scene(P=40, H=40, W=56, seed=17, D=1, scale_modifier=0.7, with_culled=False)
+    inp = oracle_inputs(sc, np.float64)
+    f = ho.forward(inp)
+    g0 = ho.backward(inp, f, sc["dL_dpix"])
+    try:
+        ho.set_upstream_scale_grad(True)
+        g1 = ho.backward(inp, f, sc["dL_dpix"])
+    finally:
+        ho.set_upstream_scale_grad(False)
+    assert np.abs(g0["scales"]).max() > 0
+    np.testing.assert_allclose(g1["scales"] * 0.7, g0["scales"], rtol=1e-12, atol=0)
+    for k in ("means3D", "opacities", "shs", "rotations", "means2D"):
+        assert np.array_equal(g0[k], g1[k]), k

@@ -119,7 +119,7 @@ typedef struct hgs_forward_args {
      * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
      * its autograd backward, without the five elementwise passes over the image they cost. */
     int32_t clamp_output;
-    /* !=0: the caller expects no tile with more than 2048 entries (its previous frame of this shape had none, see
+    /* !=0: the caller expects no long tile -- a list of more than 2048 entries, 1024 on a sparse frame -- (its previous frame of this shape had none, see
      * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
      * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
     int32_t expect_no_long_tiles;
@@ -155,7 +155,7 @@ typedef struct hgs_forward_state {
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
-    int32_t has_long_tiles;   /* !=0: some tile list is longer than 2048 entries (feeds the next frame's expect_no_long_tiles) */
+    int32_t has_long_tiles;   /* !=0: some tile list is long -- more than 2048 entries, on a sparse frame more than 1024 (feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
 } hgs_forward_state;
 

@@ -12,6 +12,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 
 #include "hgs_rasterizer.h"
@@ -45,11 +46,13 @@ int64_t round_capacity(int64_t n)
 // Scratch of frames that need no backward (the reference's validation / animation / canonical loops run under no_grad,
 // gs_trainer.py:448-684): one persistent arena per (device, stream) instead of an allocation per frame -- work on a stream
 // is ordered, so the next frame on that stream may overwrite it.  (The Python binding keeps the same policy: _arena.)
-std::map<std::pair<int, void*>, Tensor> g_arenas;
+// Keyed by the host thread too: two threads issuing frames on one stream interleave their enqueues, and the second frame's
+// first kernel would overwrite scratch the first frame's later kernels have yet to read.
+std::map<std::tuple<int, void*, std::thread::id>, Tensor> g_arenas;
 Tensor arena_for(int dev, void* stream, size_t bytes, const at::TensorOptions& bopts)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    Tensor& t = g_arenas[{dev, stream}];
+    Tensor& t = g_arenas[std::make_tuple(dev, stream, std::this_thread::get_id())];
     if (!t.defined() || (size_t)t.numel() < bytes) t = at::empty({(int64_t)(bytes + bytes / 4 + 4096)}, bopts);
     return t;
 }

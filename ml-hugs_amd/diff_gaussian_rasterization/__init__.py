@@ -19,6 +19,7 @@ on the GPU this module raises.  PyTorch is used only for device memory, streams 
 """
 import ctypes as C
 import os
+import threading
 from typing import NamedTuple
 
 import torch
@@ -339,7 +340,9 @@ _arenas = {}
 
 
 def _arena(dev, stream_id, nbytes):
-    key = (dev.index, stream_id)
+    # (per host thread as well: two threads issuing frames on ONE stream interleave their enqueues, and the second frame's
+    #  first kernel would overwrite scratch the first frame's later kernels have yet to read)
+    key = (dev.index, stream_id, threading.get_ident())
     t = _arenas.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)

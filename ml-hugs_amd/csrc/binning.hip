@@ -50,11 +50,8 @@ constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the
 // On SPARSE frames (few non-empty tiles, deep lists: a human-only render) the one-workgroup-per-tile kernel below has the CUs
 // mostly idle and lasts as long as its longest tile's sort: there, lists from LONG_MIN_SPARSE entries on already go to the
 // long-tile kernel (1 024 threads and a bucket sort instead of a 256-thread bitonic network).
-#ifndef HGS_AB_LONG_MIN
-#define HGS_AB_LONG_MIN 1024
-#endif
-constexpr int LONG_MIN_SPARSE = HGS_AB_LONG_MIN;
-__device__ __forceinline__ uint32_t long_tile_threshold(uint32_t sparse) { return sparse ? (uint32_t)LONG_MIN_SPARSE : (uint32_t)SORT_CAP_SMALL; }
+constexpr int LONG_MIN_SPARSE = 1024;
+constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
 constexpr uint32_t N_TOO_MANY = 0xFFFFFFF0u;  // pair counts from here on are reported as "too many" (32-bit list positions)
@@ -163,7 +160,10 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
         n_total[3] = sparse;
         // (sparse << 63 | has-long-tiles << 62 | 30-bit ticket << 32 | N)
-        const uint32_t any_long = (sparse ? n_large : n_large_dense) ? 1u : 0u;  // ... by this frame's threshold
+        // this frame's long-tile threshold (n_total[4]): read by both sort kernels
+        const uint32_t threshold = (sparse && n_large >= LONG_MIN_SPARSE_TILES) ? (uint32_t)LONG_MIN_SPARSE : (uint32_t)SORT_CAP_SMALL;
+        n_total[4] = threshold;
+        const uint32_t any_long = (threshold == (uint32_t)LONG_MIN_SPARSE ? n_large : n_large_dense) ? 1u : 0u;
         const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)any_long << 30);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -609,6 +609,97 @@ __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_
     bitonic_phases<E, NT, NT * E>(key, sh, (lane ^ 16u) << 2, (lane ^ 32u) << 2);
 }
 
+// BUCKET SORT of one tile's keys by a workgroup of NT threads (E keys per thread, n <= E NT): the keys are dealt to E NT
+// buckets by a monotone function of their depth bits (linear between the tile's nearest and farthest depth), an exclusive
+// scan of the bucket sizes places the buckets, the keys are scattered into their buckets in LDS, and the key at every
+// position then ranks itself among the handful of keys of its own bucket by the full 64-bit key (depth, then Gaussian
+// index): a histogram pass, a scan, a scatter and a short ranking loop instead of a bitonic network of log^2 steps
+// (4 096 keys on 1 024 threads: 31 us -> ~6 us; 512 keys on 256 threads: ~900 -> ~150 instructions per thread).
+// In: key[e] = element e NT + tid (~0 beyond n).  Out: thread's e-th key `key[e]` is now the one that was scattered to LDS
+// position e NT + tid and pos[e] its FINAL position in the sorted order (only for e NT + tid < n).  Returns false -- keys
+// untouched -- when the depths pile up in one bucket (more than BUCKET_MAX keys in it, e.g. all depths equal): the caller
+// takes the bitonic network.  sh_keys: E NT keys of LDS; bstart: E NT + 1 words; red: 3 NT / 64 words.
+constexpr uint32_t BUCKET_MAX = 48;
+template <int E, uint32_t NT>
+__device__ __forceinline__ bool bucket_sort(uint64_t (&key)[E], uint32_t (&pos)[E], uint32_t n, uint64_t* sh_keys, uint32_t* bstart,
+                                            uint32_t* red)
+{
+    constexpr uint32_t NB = (uint32_t)E * NT, NW = NT / 64u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * NT + tid;
+        if (i < n) dmin = min(dmin, (uint32_t)(key[e] >> 32)), dmax = max(dmax, (uint32_t)(key[e] >> 32));
+        bstart[i] = 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
+    }
+    if (lane == 0) red[w] = dmin, red[NW + w] = dmax;
+    if (tid == 0) bstart[NB] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < NW; ++k) dmin = min(dmin, red[k]), dmax = max(dmax, red[NW + k]);
+    // bucket of a key: monotone in its depth bits (unsigned -> float conversion, a positive factor and the truncation are all
+    // monotone), so bucket order never contradicts key order; what it does to ties is the ranking's business
+    const float scale = (float)NB / ((float)(dmax - dmin) + 1.0f);
+    auto bucket_of = [&](uint64_t k) { return min((uint32_t)((float)((uint32_t)(k >> 32) - dmin) * scale), NB - 1u); };
+    uint32_t slot[E], bkt[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * NT + tid;
+        bkt[e] = i < n ? bucket_of(key[e]) : 0u;
+        slot[e] = i < n ? atomicAdd(&bstart[bkt[e]], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the NB bucket sizes (E consecutive buckets per thread) and the largest bucket
+    uint32_t cnt[E], mine = 0, biggest = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) cnt[e] = bstart[tid * E + e], mine += cnt[e], biggest = max(biggest, cnt[e]);
+    const uint32_t incl = wave_inclusive_scan(mine);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, d, 64));
+    if (lane == 63) red[w] = incl;  // (every thread passed the barrier above after reading the min / max partials)
+    if (lane == 0) red[2 * NW + w] = biggest;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < NW; ++k) {
+        if (k < w) before += red[k];
+        biggest = max(biggest, red[2 * NW + k]);
+    }
+    if (biggest > BUCKET_MAX) {  // (workgroup-uniform)
+        __syncthreads();         // nobody still reads `red` / `bstart` when the caller reuses the memory
+        return false;
+    }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int e = 0; e < E; ++e) bstart[tid * E + e] = run, run += cnt[e];
+    if (tid == NT - 1u) bstart[NB] = run;  // == n
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if ((uint32_t)e * NT + tid < n) sh_keys[bstart[bkt[e]] + slot[e]] = key[e];
+    __syncthreads();
+    // position i holds some key of bucket b: its final position is the bucket's start plus its rank inside the bucket
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * NT + tid;
+        pos[e] = i;
+        if (i < n) {
+            const uint64_t k = sh_keys[i];
+            const uint32_t b = bucket_of(k), lo = bstart[b], hi = bstart[b + 1];
+            uint32_t rank = 0;
+            for (uint32_t j = lo; j < hi; ++j) rank += sh_keys[j] < k ? 1u : 0u;
+            key[e] = k, pos[e] = lo + rank;
+        }
+    }
+    return true;
+}
+
 // Appends up to 256 consecutive sorted entries of a tile (one per thread, `valid` when it exists) to the tile's
 // NUM_LISTS compacted lists: list q < 4 keeps the entries covering quad q, list 4 those covering any quad.  List q
 // of a tile lives at act[q * stride + s ...] (same offsets as the tile's segment of the sorted list, so no global
@@ -658,7 +749,29 @@ __device__ __forceinline__ uint32_t tile_sort_small(uint32_t tile, uint32_t s, u
         const uint32_t i = (uint32_t)e * 256u + threadIdx.x;
         key[e] = i < n ? keys[s + i] : ~0ull;
     }
-    bitonic_in_registers<E>(key, sh);
+    // 257 .. 1024 entries: the bucket sort (its keys and bucket array share the 16 KB the network's LDS steps use); the
+    // bitonic network for up to 256 entries (one key per thread: 36 cheap steps), for 1025 .. 2048 (no room for the
+    // buckets), and whenever the tile's depths pile up in one bucket
+    bool sorted = false;  // (workgroup-uniform)
+    if constexpr (E == 2 || E == 4) {
+        uint32_t pos[E];
+        uint32_t* bstart = reinterpret_cast<uint32_t*>(sh + E * 256);
+        if (bucket_sort<E, 256u>(key, pos, n, sh, bstart, bstart + E * 256 + 4)) {
+            __syncthreads();  // every thread has ranked its keys: the bucketed copy may be overwritten
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((uint32_t)e * 256u + threadIdx.x < n) sh[pos[e]] = key[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)e * 256u + threadIdx.x;
+                key[e] = i < n ? sh[i] : ~0ull;
+            }
+            __syncthreads();  // (the compaction below reuses sh)
+            sorted = true;
+        }
+    }
+    if (!sorted) bitonic_in_registers<E>(key, sh);
     uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -702,7 +815,7 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     if (n == 0) {
         if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
         if (!FUSED) return;
-    } else if (n > long_tile_threshold(gate[2])) {  // (gate points at n_total[1]: [3] is the sparse-frame flag)
+    } else if (n > gate[3]) {  // (gate points at n_total[1]: n_total[4] is this frame's long-tile threshold)
         // a long tile: sorted by tile_sort_large_kernel, which ran BEFORE this kernel (long_sorted) -- then only the blend is
         // left to do here -- or whose launch was skipped on the caller's guess that the frame has none: the tile's lists
         // read as empty and its pixels stay unwritten until the caller has repaired the guess (hgs_api.hip)
@@ -738,15 +851,10 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     }
 }
 
-// Long tiles (more than SORT_CAP_SMALL entries; from LONG_MIN_SPARSE on sparse frames), up to CAP entries: a BUCKET SORT in
-// LDS -- the keys are dealt to CAP buckets by a monotone function of their depth bits (linear between the tile's nearest and
-// farthest depth), an exclusive scan of the bucket sizes places the buckets, and every key then ranks itself among the handful
-// of keys of its own bucket by the full 64-bit key: one histogram pass, one scan, one scatter and one short ranking loop
-// instead of the 78-step bitonic network (1 024 threads, 4 096 keys: 31 us -> ~6 us).  A tile whose depths pile up in one
-// bucket (more than BUCKET_MAX keys, e.g. all depths equal) takes the bitonic network in registers instead; beyond CAP
-// entries: chunks sorted in LDS + brute-force ranking through global scratch (slow, but only for absurdly dense tiles).
+// Long tiles (more than SORT_CAP_SMALL entries; from LONG_MIN_SPARSE on sparse frames), up to CAP entries: bucket_sort
+// above with 1 024 threads (the bitonic network in registers when the depths pile up in one bucket); beyond CAP entries:
+// chunks sorted in LDS + brute-force ranking through global scratch (slow, but only for absurdly dense tiles).
 constexpr int SORT_LARGE_THREADS = 1024;  // a long tile is one workgroup's job: make it a big one
-constexpr uint32_t BUCKET_MAX = 48;
 template <int CAP>
 __global__ void __launch_bounds__(SORT_LARGE_THREADS)
 tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
@@ -758,7 +866,7 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     __shared__ uint32_t bucket_start[CAP + 1];  // bucket sizes, then (in place) their exclusive scan
     __shared__ uint32_t red[3 * (SORT_LARGE_THREADS / 64)];
     if (n_total[1]) return;  // gate
-    const uint32_t threshold = long_tile_threshold(n_total[3]);
+    const uint32_t threshold = n_total[4];
     // a fixed, small grid walks the (usually empty) list of long-tile candidates that tile_scan_kernel made
     for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
     const uint32_t tile = large_tiles[li];
@@ -799,85 +907,21 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                 if (i < n) list[s + i] = list_entry(key[e], i + 1u);
             }
         };
-        // ---- bucket sort ----
+        // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket) ----
         constexpr int E = CAP / SORT_LARGE_THREADS;
-        constexpr uint32_t NW = SORT_LARGE_THREADS / 64;
-        const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
         uint64_t key[E];
-        uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+        uint32_t pos[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + tid;
+            const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
             key[e] = i < n ? keys[s + i] : ~0ull;
-            if (i < n) dmin = min(dmin, (uint32_t)(key[e] >> 32)), dmax = max(dmax, (uint32_t)(key[e] >> 32));
-            bucket_start[(uint32_t)e * SORT_LARGE_THREADS + tid] = 0u;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
-            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
-        }
-        if (lane == 0) red[w] = dmin, red[NW + w] = dmax;
-        if (tid == 0) bucket_start[CAP] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < NW; ++k) dmin = min(dmin, red[k]), dmax = max(dmax, red[NW + k]);
-        // bucket of a key: monotone in its depth bits (unsigned -> float conversion, a positive factor and the truncation
-        // are all monotone), so bucket order never contradicts key order; what it does to ties is the ranking's business
-        const float scale = (float)CAP / ((float)(dmax - dmin) + 1.0f);
-        auto bucket_of = [&](uint64_t k) { return min((uint32_t)((float)((uint32_t)(k >> 32) - dmin) * scale), (uint32_t)CAP - 1u); };
-        uint32_t slot[E], bkt[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + tid;
-            bkt[e] = i < n ? bucket_of(key[e]) : 0u;
-            slot[e] = i < n ? atomicAdd(&bucket_start[bkt[e]], 1u) : 0u;
-        }
-        __syncthreads();
-        // exclusive scan of the CAP bucket sizes (E consecutive buckets per thread) and the largest bucket
-        uint32_t cnt[E], mine = 0, biggest = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) cnt[e] = bucket_start[tid * E + e], mine += cnt[e], biggest = max(biggest, cnt[e]);
-        const uint32_t incl = wave_inclusive_scan(mine);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, d, 64));
-        __syncthreads();  // (everyone has read the min / max partials)
-        if (lane == 63) red[w] = incl;
-        if (lane == 0) red[2 * NW + w] = biggest;
-        __syncthreads();
-        uint32_t before = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < NW; ++k) {
-            if (k < w) before += red[k];
-            biggest = max(biggest, red[2 * NW + k]);
-        }
-        if (biggest <= BUCKET_MAX) {  // (workgroup-uniform)
-            uint32_t run = before + incl - mine;
-#pragma unroll
-            for (int e = 0; e < E; ++e) bucket_start[tid * E + e] = run, run += cnt[e];
-            if (tid == SORT_LARGE_THREADS - 1) bucket_start[CAP] = run;  // == n
-            __syncthreads();
+        if (bucket_sort<E, SORT_LARGE_THREADS>(key, pos, n, sh, bucket_start, red)) {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if ((uint32_t)e * SORT_LARGE_THREADS + tid < n) sh[bucket_start[bkt[e]] + slot[e]] = key[e];
-            __syncthreads();
-            // position i holds some key of bucket b: its final position is the bucket's start plus its rank inside the bucket
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + tid;
-                if (i < n) {
-                    const uint64_t k = sh[i];
-                    const uint32_t b = bucket_of(k), lo = bucket_start[b], hi = bucket_start[b + 1];
-                    uint32_t rank = 0;
-                    for (uint32_t j = lo; j < hi; ++j) rank += sh[j] < k ? 1u : 0u;
-                    list[s + lo + rank] = list_entry(k, lo + rank + 1u);
-                }
-            }
-        } else {
-            __syncthreads();  // (bucket_start / red are not touched again before the next tile)
-            if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
-            else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
-        }
+                if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < n) list[s + pos[e]] = list_entry(key[e], pos[e] + 1u);
+        } else if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
+        else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
     } else {
         // Longer than LDS: sort CAP-sized chunks in LDS into `scratch`, then every key finds its final position as its
         // index in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are

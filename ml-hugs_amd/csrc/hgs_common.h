@@ -135,7 +135,7 @@ struct ImageLayout {
         act_count = o;  o = align_up(o + 4 * T * NUM_LISTS);   // entries in each tile's compacted lists
         cursor = o;     o = align_up(o + 4 * T);   // start of each tile's segment (the fallback emit path advances it with atomics)
         large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
-        n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of large tiles, [3] sparse-frame flag
+        n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of long-tile candidates, [3] sparse-frame flag, [4] long-tile threshold
         seg_first = o;  o = align_up(o + 4 * (T + 1));  // first checkpoint slot of each tile; [T] = number of slots
         quad_nproc = o; o = align_up(o + 16 * T);       // list entries the forward blend walked, per (tile, quad)
         total = o;

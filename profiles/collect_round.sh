@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything under profiles/ for one round tag, in one gpurun call:
+#   gpurun --timeout 2400 -- 'bash profiles/collect_round.sh r3c'      then: cp gpurun_out/<tag>*/<tag>* profiles/
+# = collect.sh (the bench workload: kernel stats, timeline, PMC traffic + VALU passes, the bench line) plus
+# collect_workload.sh for the side workloads (C3 both sizes, C4 with the two renders concurrent and serial), the FPS
+# sweep, the forward-only loops and the two soaks.
+set -u
+TAG=${1:?tag}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT"
+bash profiles/collect.sh $TAG > /dev/null 2>&1
+bash profiles/collect_workload.sh ${TAG}_c3_110210 tools/bench_c3.py > /dev/null 2>&1
+bash profiles/collect_workload.sh ${TAG}_c3_6890 tools/bench_c3.py 6890 > /dev/null 2>&1
+bash profiles/collect_workload.sh ${TAG}_c4 tools/bench_c4.py > /dev/null 2>&1
+HGS_CONCURRENT_RENDERS=0 bash profiles/collect_workload.sh ${TAG}_c4_serial tools/bench_c4.py > /dev/null 2>&1
+OUT=$ROOT/gpurun_out/$TAG
+python3 tools/sweep.py > "$OUT/${TAG}_sweep.json" 2> "$OUT/sweep.err"
+python3 tools/bench_fwd.py > "$OUT/${TAG}_fwd.jsonl" 2> "$OUT/fwd.err"
+SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
+python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1
+rm -rf "$ROOT"/gpurun_out/${TAG}*/trace "$ROOT"/gpurun_out/${TAG}*/pmc_*
+tail -n 3 "$OUT/${TAG}_soak.txt" "$OUT/${TAG}_soak_churn.txt"
+cat "$OUT/${TAG}_bench.json"

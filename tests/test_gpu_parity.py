@@ -1020,3 +1020,43 @@ def test_scale_gradient_convention_switch(upstream, binding, device, monkeypatch
         assert rel_l2(t[k].grad.cpu().numpy().reshape(g_ref[k].shape), g_ref[k]) <= GRAD_REL_TOL, k
     if upstream:
         assert rel_l2(t["scales"].grad.cpu().numpy(), g_true["scales"]) > 0.2               # and the switch really did something
+
+
+@pytest.mark.parametrize("P,lo,hi,depths", [
+    (500, 257, 512, "spread"),        # bucket sort in the small-tile kernel, two keys per thread
+    (1300, 513, 1024, "spread"),      # ... four keys per thread
+    (1300, 513, 1024, "ties"),        # a third of the Gaussians share three exact depths: ranked by index inside their buckets
+    (900, 257, 1024, "equal"),        # every depth equal: one bucket -- the fallback to the bitonic network
+    (40000, 1025, 8192, "spread"),    # >= 16 lists beyond 1024 entries on a sparse frame: the long-tile kernel's bucket sort
+    (40000, 1025, 8192, "equal"),     # ... and its fallback
+])
+def test_bucket_sort_paths_give_the_oracle_order(P, lo, hi, depths, device):
+    """The per-tile sort of mid-length and long lists is a bucket sort (depth-linear buckets, ranking inside the bucket by the
+    full key) with the bitonic network as its fallback: sorted list, ranges and image against the oracle, position by
+    position, on scenes built to hit each path -- including exact depth ties inside and across buckets."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    big = P >= 10000
+    sc = _stacked_scene(P, 256 if big else 64, 256 if big else 64, seed=90 + P % 97 + len(depths), spread_px=60.0 if big else 6.0)
+    rng = np.random.default_rng(5)
+    z = sc["means3D"][:, 2].copy()
+    if depths == "ties":
+        idx = rng.choice(P, P // 3, replace=False)
+        z[idx] = rng.choice(np.array([3.0, 5.0, 5.000000476837158], np.float32), idx.size)   # (two of them neighbouring floats)
+    elif depths == "equal":
+        z[:] = 5.0
+    sc["means3D"] = (sc["means3D"] * (z / sc["means3D"][:, 2])[:, None]).astype(np.float32)   # same pixels, new depths
+    sc["means3D"][:, 2] = z
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert lo <= lens.max() <= hi, f"scene misses the intended path: longest tile list {lens.max()}"
+    if big:
+        assert (lens > 1024).sum() >= 16, "too few long lists for the sparse-frame threshold"
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], f"bucket sort P={P} {depths}")

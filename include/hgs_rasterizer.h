@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 8
+#define HGS_ABI_VERSION 9
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
@@ -144,6 +144,9 @@ typedef struct hgs_forward_args {
     void *scratch[4];
     size_t scratch_bytes[4];
     hgs_segment seg2;            /* optional second set of Gaussians (all zero: none); scratch / hint sizes count P + seg2.P */
+    /* Optional [P (+ seg2.P)] bytes: visible[i] = (radii[i] > 0) -- the `visibility_filter` the reference's render() derives with
+     * a separate elementwise kernel (/root/reference/hugs/renderer/gs_renderer.py:159), written by the kernel that writes radii. */
+    uint8_t *visible;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */

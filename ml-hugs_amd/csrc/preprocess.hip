@@ -155,7 +155,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
                   const float* __restrict__ scales_, const float* __restrict__ rots_,
                   const float* __restrict__ cov3D_precomp_, SecondInputs in2, const float* __restrict__ V,
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
-                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
+                  uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii, uint8_t* __restrict__ visible,
                   uint32_t* __restrict__ counters, uint2* __restrict__ cell_slot, uint32_t* __restrict__ run_start,
                   float4* __restrict__ zero_accum)
 {
@@ -292,6 +292,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         dst[3] = make_float4(out.ca, out.cb, out.cc, out.log2_opacity);
         tiles_touched[i] = touched;
         radii[i] = out.radius;
+        if (visible) visible[i] = out.radius > 0 ? 1 : 0;  // the renderer's `radii > 0`, without its kernel
     }
 
     if (MODE == BIN_BY_CELL) {
@@ -341,7 +342,7 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
     const SecondInputs in2{a.P, a.seg2.M, a.seg2.means3D, a.seg2.shs, a.seg2.colors_precomp, a.seg2.opacities, a.seg2.scales,
                            a.seg2.rotations, a.seg2.cov3D_precomp};
 #define HGS_K1_ARGS P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, in2, a.s.viewmatrix, \
-                    a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii
+                    a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, a.visible
     if (mode == BIN_BY_CELL)
         hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((P + group - 1) / group), dim3(group),
                            2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy), st, HGS_K1_ARGS, counters, cell_slot, nullptr,

@@ -139,7 +139,7 @@ public:
                                  Tensor proj_, Tensor campos_, int64_t H, int64_t W, double tanfovx, double tanfovy,
                                  double mod, int64_t degree, bool prefiltered, bool debug, bool clamp_output, bool needs_grad,
                                  Tensor means3D_b_, Tensor sh_b_, Tensor colors_b_, Tensor opac_b_, Tensor scales_b_, Tensor rot_b_,
-                                 Tensor cov_b_)
+                                 Tensor cov_b_, bool with_visibility)
     {
         TORCH_CHECK(means3D_.is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
         const auto dev = means3D_.device();
@@ -159,6 +159,7 @@ public:
         const auto bopts = at::TensorOptions().dtype(at::kByte).device(dev);
         Tensor color = P == 0 ? at::zeros({3, H, W}, fopts) : at::empty({3, H, W}, fopts);
         Tensor radii = at::empty({P}, fopts.dtype(at::kInt));
+        Tensor visible = with_visibility ? at::empty({P}, fopts.dtype(at::kBool)) : Tensor();   // `radii > 0`, written with radii
 
         hgs_backward_args bw;
         memset(&bw, 0, sizeof bw);
@@ -167,6 +168,7 @@ public:
                      prefiltered, debug, clamp_output);
         fill_segment(a.seg2, means3D_b, sh_b, colors_b, opac_b, scales_b, rot_b, cov_b);
         a.out_color = color.data_ptr<float>(), a.radii = P ? radii.data_ptr<int32_t>() : nullptr;
+        a.visible = (with_visibility && P) ? (uint8_t*)visible.data_ptr<bool>() : nullptr;
         const int64_t M = a.M, M2 = a.seg2.M;
         // (needs_grad is decided by the caller: grad mode is off inside forward())
         Tensor slab;
@@ -218,7 +220,8 @@ public:
         t_last_n = n, t_last_capacity = bw.state.binning_capacity;
         t_last_long = bw.state.has_long_tiles != 0, t_last_sparse = bw.state.sparse_frame != 0;
 
-        ctx->mark_non_differentiable({radii});
+        if (with_visibility) ctx->mark_non_differentiable({radii, visible});
+        else ctx->mark_non_differentiable({radii});
         if (needs_grad) {
             ctx->set_materialize_grads(false);
             ctx->save_for_backward({means3D, sh.defined() ? sh : Tensor(), colors.defined() ? colors : Tensor(),
@@ -241,12 +244,13 @@ public:
             ctx->saved_data["ck"] = (int64_t)(uintptr_t)bw.state.ckpt, ctx->saved_data["ck_b"] = (int64_t)bw.state.ckpt_bytes;
             ctx->saved_data["fresh"] = true;
         }
+        if (with_visibility) return {color, radii, visible};
         return {color, radii};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads)
     {
-        variable_list out(29);
+        variable_list out(30);
         const Tensor& g_color = grads[0];
         if (!g_color.defined()) return out;   // colour did not take part in the loss
         const auto sv = ctx->get_saved_variables();
@@ -321,7 +325,7 @@ public:
 std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot,
                               Tensor cov, Tensor bg, Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W,
                               double tanfovx, double tanfovy, double mod, int64_t degree, bool prefiltered, bool debug,
-                              bool clamp_output, std::vector<Tensor> second)
+                              bool clamp_output, std::vector<Tensor> second, bool with_visibility)
 {
     // `second`: nothing, or the second set's (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
     TORCH_CHECK(second.empty() || second.size() == 7, "the second set of Gaussians is a list of seven tensors");
@@ -334,7 +338,8 @@ std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor 
     }
     auto r = Rasterize::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, tanfovx, tanfovy,
                               mod, degree, prefiltered, debug, clamp_output, needs_grad, second[0], second[1], second[2], second[3],
-                              second[4], second[5], second[6]);
+                              second[4], second[5], second[6], with_visibility);
+    if (with_visibility) return {r[0], r[1], r[2]};
     return {r[0], r[1]};
 }
 
@@ -346,7 +351,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("means3D"), py::arg("means2D"), py::arg("sh"), py::arg("colors"), py::arg("opac"), py::arg("scales"), py::arg("rot"),
           py::arg("cov"), py::arg("bg"), py::arg("view"), py::arg("proj"), py::arg("campos"), py::arg("H"), py::arg("W"),
           py::arg("tanfovx"), py::arg("tanfovy"), py::arg("mod"), py::arg("degree"), py::arg("prefiltered"), py::arg("debug"),
-          py::arg("clamp_output"), py::arg("second") = std::vector<Tensor>());
+          py::arg("clamp_output"), py::arg("second") = std::vector<Tensor>(), py::arg("with_visibility") = false);
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
     m.def("last_frame_info", [] { return std::make_tuple(t_last_n, t_last_capacity, t_last_long, t_last_sparse); },
           "(N, binning capacity, has long tiles, sparse) of this thread's last forward");

@@ -31,7 +31,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 8
+_ABI_VERSION = 9
 
 
 def library_path():
@@ -59,7 +59,7 @@ class _ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
                 ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
                 ("defer_n", C.c_int32), ("backward_checkpoints", C.c_int32), ("scratch", C.c_void_p * 4),
-                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment)]
+                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment), ("visible", C.c_void_p)]
 
 
 class _ForwardState(C.Structure):
@@ -387,6 +387,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, clamp_output=False, *second):
+        # (clamp_output: bit 0 = clamp the image, bit 1 = also return the visibility filter `radii > 0` as a third output)
+        with_visibility = bool(int(clamp_output) & 2)
+        clamp_output = bool(int(clamp_output) & 1)
         lib = _load()
         _require_gpu(means3D, "means3D")
         dev = means3D.device
@@ -411,6 +414,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color = torch.zeros(3, H, W, dtype=torch.float32, device=dev) if P == 0 else \
             torch.empty(3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
+        visible = torch.empty(P, dtype=torch.bool, device=dev) if with_visibility else None
 
         keep = {"device": dev}
         bufs = {}
@@ -430,6 +434,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sec is not None:
             _fill_segment(args.seg2, *sec)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
+        args.visible = _ptr(visible)
         args.clamp_output = 1 if clamp_output else 0
         M, M2 = int(args.M), int(args.seg2.M)
         needs_grad = P > 0 and any(ctx.needs_input_grad)
@@ -469,12 +474,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, e(sh), e(colors_precomp), e(opacities), e(scales), e(rotations), e(cov3Ds_precomp), radii,
                               *([e(x) for x in sec] if sec is not None else []))
         ctx.n_second_inputs = len(second)
-        ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zero-filled int32 "gradient" for radii
+        if with_visibility:
+            ctx.mark_non_differentiable(radii, visible)
+            return color, radii, visible
+        ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
+    def backward(ctx, grad_out_color, _grad_radii, _grad_visible=None):
         lib = _load()
         # the saved tensors are what `ctx.bw` points into: unpacking them also runs autograd's in-place-modification check
         saved = ctx.saved_tensors
@@ -571,8 +579,9 @@ _SECOND_KEYS = ("means3D", "shs", "colors_precomp", "opacities", "scales", "rota
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, clamp_output=False, second=None):
-    """`second`: optional dict with the keys of _SECOND_KEYS (missing / None = absent) -- a second model's Gaussians
+                        raster_settings, clamp_output=False, second=None, with_visibility=False):
+    """`with_visibility`: also return `radii > 0` (bool [P]) as a third tensor, written by the kernel that writes radii.
+    `second`: optional dict with the keys of _SECOND_KEYS (missing / None = absent) -- a second model's Gaussians
     rendered together with the first without concatenating anything (hgs_segment); means2D must then have
     len(means3D) + len(second["means3D"]) rows."""
     global _last_frame_info
@@ -583,17 +592,18 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     cpp = _load_cpp()
     if cpp is not None:
         rs = raster_settings
-        color, radii = cpp.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
-                                     rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
-                                     float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
-                                     bool(rs.prefiltered), bool(rs.debug), bool(clamp_output), list(sec))
+        out = cpp.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
+                            rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
+                            float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
+                            bool(rs.prefiltered), bool(rs.debug), bool(clamp_output), list(sec), bool(with_visibility))
+        color, radii, visible = out[0], out[1], (out[2] if with_visibility else None)
         n, cap, has_long, sparse = cpp.last_frame_info()
         _last_frame_info = (n, cap)
         if radii.numel():   # one hint table for both bindings: what the C++ node learnt, the Python paths (deferred frames) use
             _remember((means3D.device.index, radii.numel(), int(rs.image_height), int(rs.image_width)), n, has_long, sparse, to_cpp=False)
-        return color, radii
+        return (color, radii, visible) if with_visibility else (color, radii)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, clamp_output, *sec)
+                                     cov3Ds_precomp, raster_settings, (1 if clamp_output else 0) | (2 if with_visibility else 0), *sec)
 
 
 class DeferredFrame:
@@ -707,8 +717,9 @@ class GaussianRasterizer(nn.Module):
         return present
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, clamp_output=False, second=None):
-        """Two additions to upstream's signature: `clamp_output` -- True fuses the `torch.clamp(image, 0, 1)` that the
+                cov3D_precomp=None, clamp_output=False, second=None, with_visibility=False):
+        """Three additions to upstream's signature (`with_visibility`: a third return value, the bool tensor `radii > 0` that
+        the reference's render() computes right after this call, gs_renderer.py:159, written by the kernel that writes radii): `clamp_output` -- True fuses the `torch.clamp(image, 0, 1)` that the
         reference's render() applies right after this call (gs_renderer.py:153), forward and backward -- and `second`, a
         dict (means3D, opacities, shs | colors_precomp, scales + rotations | cov3D_precomp) with a second model's Gaussians,
         rendered behind the first in index order exactly as if the tensors had been concatenated (gs_renderer.py:33-37)
@@ -731,7 +742,7 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = empty
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings, clamp_output, second)
+                                   cov3D_precomp, raster_settings, clamp_output, second, with_visibility)
 
 
 # ---------------------------------------------------------------------------------------------

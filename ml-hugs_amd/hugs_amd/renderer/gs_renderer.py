@@ -28,6 +28,8 @@ _FIELDS = (("shs", "feats"), ("xyz", "means3D"), ("opacity", "opacity"), ("scale
 
 
 _JOINT_CONCAT = os.environ.get("HGS_JOINT_CONCAT", "0") == "1"
+_VIEWSPACE_NONLEAF = os.environ.get("HGS_VIEWSPACE_NONLEAF", "0") == "1"
+_FUSED_VISIBILITY = os.environ.get("HGS_FUSED_VISIBILITY", "1") != "0"
 
 
 def _two_segments(human_gs_out, scene_gs_out):
@@ -137,16 +139,21 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
     if bg_color is None:
         bg_color = torch.zeros(3, dtype=torch.float32, device=device)
 
-    # gradient sink for dL/d(screen-space mean): non-leaf, so it must retain its grad explicitly
-    if second is None:
-        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
-    else:   # one row per Gaussian of both models, as the reference's zeros_like of the concatenated means
-        screenspace_points = torch.zeros(means3D.shape[0] + second["means3D"].shape[0], 3, dtype=means3D.dtype,
-                                         requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # gradient sink for dL/d(screen-space mean), one row per Gaussian (of both models in a joint render).  The reference builds
+    # it as `zeros_like(means3D, requires_grad=True) + 0` plus retain_grad() (:107-113): a NON-LEAF zero tensor -- two
+    # elementwise kernels per render, and the retain_grad hook clones the gradient in backward.  Here it is a LEAF zero tensor:
+    # `.grad` receives the rasterizer's gradient buffer itself (no clone), the values are the same zeros, and everything the
+    # trainer does with it (reads .grad, slices it, re-assigns it: gs_trainer.py:316-342) works alike.
+    # HGS_VIEWSPACE_NONLEAF=1 restores the reference's construction.
+    n_rows = means3D.shape[0] + (second["means3D"].shape[0] if second is not None else 0)
+    if _VIEWSPACE_NONLEAF:
+        screenspace_points = torch.zeros(n_rows, 3, dtype=means3D.dtype, requires_grad=True, device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:
+        screenspace_points = torch.zeros(n_rows, 3, dtype=means3D.dtype, requires_grad=True, device=device)
 
     settings = GaussianRasterizationSettings(
         image_height=int(data["image_height"]),
@@ -166,7 +173,8 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
     if second is not None:
         second = {"means3D": second["means3D"], "opacities": second["opacity"], "scales": second["scales"],
                   "rotations": second["rotations"], ("colors_precomp" if is_rgb else "shs"): second["feats"]}
-    image, radii = GaussianRasterizer(raster_settings=settings)(
+    # (visibility = radii > 0 comes back from the rasterizer itself when it is ours: written by the kernel that writes radii)
+    out = GaussianRasterizer(raster_settings=settings)(
         means3D=means3D,
         means2D=screenspace_points,
         shs=None if is_rgb else feats,
@@ -176,11 +184,13 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
         rotations=rotations,
         clamp_output=True,   # the reference's torch.clamp(rendered_image, 0.0, 1.0) (:153), fused into the blend kernels
         **({} if second is None else {"second": second}),   # (a one-model call carries exactly the reference's kwargs + the clamp)
+        **({"with_visibility": True} if _FUSED_VISIBILITY else {}),
     )
+    image, radii = out[0], out[1]
     return {
         "render": image,
         "viewspace_points": screenspace_points,
-        "visibility_filter": radii > 0,
+        "visibility_filter": out[2] if len(out) > 2 else radii > 0,
         "radii": radii,
     }
 

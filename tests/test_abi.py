@@ -44,7 +44,7 @@ int main(void) {
   /* ABI v6 / v7: the checkpoint buffer and the second segment */
   printf("%zu %zu %zu %zu\n", sizeof(hgs_segment), offsetof(hgs_forward_args, backward_checkpoints), offsetof(hgs_forward_args, scratch_bytes), offsetof(hgs_forward_args, seg2));
   printf("%zu %zu %zu %zu\n", offsetof(hgs_segment, cov3D_precomp), offsetof(hgs_forward_state, ckpt), offsetof(hgs_forward_state, n_token), offsetof(hgs_backward_args, seg2_dL_drotations));
-  printf("%zu\n", offsetof(hgs_backward_args, flags));
+  printf("%zu %zu\n", offsetof(hgs_backward_args, flags), offsetof(hgs_forward_args, visible));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
@@ -58,7 +58,7 @@ int main(void) {
     Sg = dgr._Segment
     assert v[12:16] == [C.sizeof(Sg), F.backward_checkpoints.offset, F.scratch_bytes.offset, F.seg2.offset]
     assert v[16:20] == [Sg.cov3D_precomp.offset, St.ckpt.offset, St.n_token.offset, B.seg2_dL_drotations.offset]
-    assert v[20:] == [B.flags.offset]
+    assert v[20:] == [B.flags.offset, F.visible.offset]
 
 
 def test_scratch_size_queries_and_offsets():

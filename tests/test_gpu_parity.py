@@ -1060,3 +1060,36 @@ def test_bucket_sort_paths_give_the_oracle_order(P, lo, hi, depths, device):
     assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
     assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
     check_image(color.cpu().numpy(), ref["color"], f"bucket sort P={P} {depths}")
+
+
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+def test_fused_visibility_and_viewspace_sink(binding, device, monkeypatch):
+    """Two small fusions of the renderer adapter: `with_visibility` -- the rasterizer returns `radii > 0` itself (the
+    reference computes it with an elementwise kernel, gs_renderer.py:159) --, and `viewspace_points` as a leaf zero tensor
+    whose .grad IS the rasterizer's gradient buffer (the reference's `zeros + 0` + retain_grad costs two kernels and a
+    clone per render; HGS_VIEWSPACE_NONLEAF=1 restores it).  Same values either way, both bindings."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from hugs_amd.renderer import gs_renderer
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = make_scene(**CASES["rotcam_d2"])
+    t = gpu_tensors(sc, device)
+    color, radii, visible = GaussianRasterizer(gpu_settings(sc, device))(
+        means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+        rotations=t["rotations"], with_visibility=True)
+    assert visible.dtype == torch.bool and torch.equal(visible, radii > 0) and 0 < int(visible.sum()) < radii.numel()
+    fr = _orbit_frames(sc, device, 1)[0]
+    fr = {k: (v.detach().clone().requires_grad_(True) if torch.is_tensor(v) and v.dtype == torch.float32 and v.dim() >= 2 and k != "data" else v)
+          for k, v in fr.items()}
+    dL = to_dev(sc["dL_dpix"], device)
+    out = {}
+    for nonleaf in (False, True):
+        monkeypatch.setattr(gs_renderer, "_VIEWSPACE_NONLEAF", nonleaf)
+        pkg = gs_renderer.render(**fr)
+        pkg["render"].backward(dL)
+        vs = pkg["viewspace_points"]
+        assert vs.is_leaf == (not nonleaf) and vs.requires_grad and float(vs.detach().abs().max()) == 0.0 and vs.grad is not None
+        assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
+        out[nonleaf] = (pkg["render"].detach(), vs.grad.clone())
+    assert torch.equal(out[False][0], out[True][0])
+    assert rel_l2(out[False][1].cpu().numpy(), out[True][1].cpu().numpy()) <= 1e-5

@@ -907,21 +907,30 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                 if (i < n) list[s + i] = list_entry(key[e], i + 1u);
             }
         };
-        // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket) ----
-        constexpr int E = CAP / SORT_LARGE_THREADS;
-        uint64_t key[E];
-        uint32_t pos[E];
+        // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket), with as many
+        // keys -- and buckets -- per thread as the list needs: a 1 100-entry list does not pay for 8 192 buckets ----
+        auto by_buckets = [&](auto e_tag) {
+            constexpr int E = decltype(e_tag)::value;
+            uint64_t key[E];
+            uint32_t pos[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-            key[e] = i < n ? keys[s + i] : ~0ull;
-        }
-        if (bucket_sort<E, SORT_LARGE_THREADS>(key, pos, n, sh, bucket_start, red)) {
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
+                key[e] = i < n ? keys[s + i] : ~0ull;
+            }
+            if (!bucket_sort<E, SORT_LARGE_THREADS>(key, pos, n, sh, bucket_start, red)) return false;
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < n) list[s + pos[e]] = list_entry(key[e], pos[e] + 1u);
-        } else if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
-        else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
+            return true;
+        };
+        const bool done = n <= 2u * SORT_LARGE_THREADS   ? by_buckets(std::integral_constant<int, 2>{})
+                          : n <= 4u * SORT_LARGE_THREADS ? by_buckets(std::integral_constant<int, 4>{})
+                                                         : by_buckets(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
+        if (!done) {
+            if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
+            else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
+        }
     } else {
         // Longer than LDS: sort CAP-sized chunks in LDS into `scratch`, then every key finds its final position as its
         // index in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are

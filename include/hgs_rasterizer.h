@@ -257,8 +257,13 @@ int32_t hgs_lbs_skin_backward(int32_t n, int32_t J, const float *A, const float 
 
 /* SURVEY.md 8f row f-4 -- replaces simple_knn._C.distCUDA2 (/root/reference/hugs/models/scene.py:20,181): mean_dist2[i]
  * = mean of the squared distances from points[i] to its three nearest OTHER points of the same cloud ([n,3], n >= 4).
- * Exact (brute force), fp32. */
+ * Exact (brute force, O(n^2)), fp32. */
 int32_t hgs_dist_cuda2(int32_t n, const float *points, float *mean_dist2, void *stream);
+/* The same result (bit for bit) in O(n) for large clouds: with a workspace of hgs_dist_cuda2_workspace(n) bytes (16-byte
+ * aligned; 0 = this n takes the brute-force scan anyway) the points are counting-sorted into a uniform grid and every point
+ * searches the shells of cells around its own until its third-best distance is closed. */
+size_t hgs_dist_cuda2_workspace(int32_t n);
+int32_t hgs_dist_cuda2_ws(int32_t n, const float *points, float *mean_dist2, void *workspace, void *stream);
 
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);

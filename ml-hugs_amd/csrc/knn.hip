@@ -201,6 +201,193 @@ mean_dist3_kernel(int n, const float* __restrict__ points, float* __restrict__ m
     mean_dist2[i] = ((best.d[0] + best.d[1]) + best.d[2]) / 3.0f;
 }
 
+// ---- distCUDA2 on a uniform grid (large clouds) ----------------------------------------------------------------------
+// The brute-force scan is exact and fine for an initialisation-sized cloud (1e5 points: milliseconds) but O(n^2); from
+// GRID_MIN_POINTS on, the points are counting-sorted into the cells of a uniform grid over their bounding box (about four
+// points per cell) and every point searches the shells of cells around its own, nearest first, until its third-best
+// distance is certainly smaller than anything a farther shell can hold: every point outside the shells 0..r lies at
+// least r cell sizes away.  The candidates' distances are the same fp32 expression as the brute-force scan's and the mean
+// is taken over the same three smallest values in ascending order: the result is bit-identical.  A point that has not
+// closed after GRID_MAX_RINGS shells (an outlier far from everything) scans the whole cloud, as the brute force does.
+constexpr int GRID_MIN_POINTS = 32768, GRID_MAX_RINGS = 24, GRID_MAX_DIM = 1024;
+struct GridParams {
+    float minx, miny, minz, cell, inv_cell;
+    int gx, gy, gz, cells;
+    uint32_t lo[3], hi[3];  // bounding box as order-preserving unsigned keys of the floats (atomicMin / atomicMax)
+};
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ void grid_init_kernel(GridParams* g)
+{
+    for (int k = 0; k < 3; ++k) g->lo[k] = 0xFFFFFFFFu, g->hi[k] = 0u;
+}
+__global__ void __launch_bounds__(256) grid_bbox_kernel(int n, const float* __restrict__ p, GridParams* g)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    if (i < n)
+        for (int k = 0; k < 3; ++k) lo[k] = hi[k] = float_key(p[3 * (size_t)i + k]);
+    for (int k = 0; k < 3; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], d, 64));
+            hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) atomicMin(&g->lo[k], lo[k]), atomicMax(&g->hi[k], hi[k]);
+    }
+}
+// one thread: cell size for ~4 points per cell, at most n cells (the counter array has n + 1 entries) and GRID_MAX_DIM per axis
+__global__ void grid_setup_kernel(int n, GridParams* g, uint32_t* cell_count)
+{
+    const float mn[3] = {key_float(g->lo[0]), key_float(g->lo[1]), key_float(g->lo[2])};
+    float ext[3];
+    for (int k = 0; k < 3; ++k) ext[k] = fmaxf(key_float(g->hi[k]) - mn[k], 0.0f);
+    const float longest = fmaxf(fmaxf(ext[0], ext[1]), fmaxf(ext[2], 1e-30f));
+    // volume of the box, a degenerate axis counted as one cell thick
+    float cell = longest / 2.0f;
+    for (int it = 0; it < 64; ++it) {  // shrink the cell until ~n/4 cells (or the per-axis limit) are reached
+        const float c = cell * 0.7937005f;  // 2^(-1/3): halves the cell volume
+        long long cells = 1;
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+            const long long gk = (long long)floorf(ext[k] / c) + 1;
+            ok = ok && gk <= GRID_MAX_DIM;
+            cells *= gk;
+        }
+        if (!ok || cells * 4 > (long long)n) break;
+        cell = c;
+    }
+    g->minx = mn[0], g->miny = mn[1], g->minz = mn[2], g->cell = cell, g->inv_cell = 1.0f / cell;
+    g->gx = (int)floorf(ext[0] / cell) + 1, g->gy = (int)floorf(ext[1] / cell) + 1, g->gz = (int)floorf(ext[2] / cell) + 1;
+    g->cells = g->gx * g->gy * g->gz;
+    (void)cell_count;
+}
+__device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, float z, int& cx, int& cy, int& cz)
+{
+    cx = min(max((int)((x - g.minx) * g.inv_cell), 0), g.gx - 1);
+    cy = min(max((int)((y - g.miny) * g.inv_cell), 0), g.gy - 1);
+    cz = min(max((int)((z - g.minz) * g.inv_cell), 0), g.gz - 1);
+}
+__global__ void __launch_bounds__(256) grid_count_kernel(int n, const float* __restrict__ p, const GridParams* __restrict__ gp,
+                                                         uint32_t* __restrict__ cell_id, uint32_t* __restrict__ slot,
+                                                         uint32_t* __restrict__ cell_count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const GridParams g = *gp;
+    int cx, cy, cz;
+    cell_of(g, p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2], cx, cy, cz);
+    const uint32_t c = (uint32_t)((cz * g.gy + cy) * g.gx + cx);
+    cell_id[i] = c;
+    slot[i] = atomicAdd(&cell_count[c], 1u);
+}
+// exclusive scan of cell_count[0 .. cells] in place (one workgroup, 8 192 entries per trip)
+__global__ void __launch_bounds__(1024) grid_scan_kernel(const GridParams* __restrict__ gp, uint32_t* __restrict__ cell_count)
+{
+    __shared__ uint32_t wsum[16];
+    const int cells = gp->cells + 1, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int base = 0; base < cells; base += 8192) {
+        uint32_t c[8], mine = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x * 8 + k;
+            c[k] = j < cells ? cell_count[j] : 0u, mine += c[k];
+        }
+        uint32_t incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < w) before += wsum[k];
+            total += wsum[k];
+        }
+        __syncthreads();
+        uint32_t run = carry + before + incl - mine;
+        for (int k = 0; k < 8; ++k) {
+            const int j = base + threadIdx.x * 8 + k;
+            if (j < cells) cell_count[j] = run;
+            run += c[k];
+        }
+        carry += total;
+    }
+}
+__global__ void __launch_bounds__(256) grid_scatter_kernel(int n, const float* __restrict__ p, const uint32_t* __restrict__ cell_id,
+                                                           const uint32_t* __restrict__ slot, const uint32_t* __restrict__ cell_start,
+                                                           float4* __restrict__ sorted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    sorted[cell_start[cell_id[i]] + slot[i]] = make_float4(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2], __int_as_float(i));
+}
+__global__ void __launch_bounds__(256) grid_search_kernel(int n, const GridParams* __restrict__ gp, const uint32_t* __restrict__ cell_start,
+                                                          const float4* __restrict__ sorted, float* __restrict__ mean_dist2)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const GridParams g = *gp;
+    const float4 me = sorted[t];  // (threads follow the sorted order: a wave's queries are neighbours in space)
+    const int self = __float_as_int(me.w);
+    int cx, cy, cz;
+    cell_of(g, me.x, me.y, me.z, cx, cy, cz);
+    Best<3> best;
+    best.init();
+    auto scan_cell = [&](int x, int y, int z) {
+        const uint32_t c = (uint32_t)((z * g.gy + y) * g.gx + x);
+        for (uint32_t j = cell_start[c], e = cell_start[c + 1]; j < e; ++j) {
+            const float4 q = sorted[j];
+            if (__float_as_int(q.w) != self) best.offer(sqdist(me.x, me.y, me.z, q.x, q.y, q.z), 0);
+        }
+    };
+    bool closed = false;
+    const int rmax = max(max(g.gx, g.gy), g.gz);
+    for (int r = 0; r <= GRID_MAX_RINGS && !closed; ++r) {
+        for (int z = max(cz - r, 0); z <= min(cz + r, g.gz - 1); ++z)
+            for (int y = max(cy - r, 0); y <= min(cy + r, g.gy - 1); ++y) {
+                const bool face = abs(z - cz) == r || abs(y - cy) == r;  // on the shell whatever x is
+                if (face) {
+                    for (int x = max(cx - r, 0); x <= min(cx + r, g.gx - 1); ++x) scan_cell(x, y, z);
+                } else {
+                    if (cx - r >= 0) scan_cell(cx - r, y, z);
+                    if (r > 0 && cx + r <= g.gx - 1) scan_cell(cx + r, y, z);
+                }
+            }
+        // everything outside the shells 0..r is at least r cell sizes away (a little less: the cell of a point is an fp32 floor)
+        const float reach = (float)r * g.cell * 0.999f;
+        closed = best.d[2] <= reach * reach || r >= rmax;
+    }
+    if (!closed) {  // an outlier: the whole cloud, as the brute-force scan does
+        best.init();
+        for (int j = 0; j < n; ++j) {
+            const float4 q = sorted[j];
+            if (__float_as_int(q.w) != self) best.offer(sqdist(me.x, me.y, me.z, q.x, q.y, q.z), 0);
+        }
+    }
+    mean_dist2[self] = ((best.d[0] + best.d[1]) + best.d[2]) / 3.0f;
+}
+
+struct GridWorkspace {
+    size_t params, cell_id, slot, cell_count, sorted, total;
+    explicit GridWorkspace(int n)
+    {
+        auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+        size_t o = 0;
+        params = o, o = up(o + sizeof(GridParams));
+        cell_id = o, o = up(o + 4 * (size_t)n);
+        slot = o, o = up(o + 4 * (size_t)n);
+        cell_count = o, o = up(o + 4 * ((size_t)n + 2));
+        sorted = o, o = up(o + 16 * (size_t)n);
+        total = o;
+    }
+};
+
 int fail_knn(const char* what)
 {
     hgs::set_last_error(what);
@@ -242,6 +429,8 @@ struct LaunchLbs {
 
 }  // namespace
 
+extern "C" int32_t hgs_dist_cuda2(int32_t n, const float* points, float* mean_dist2, void* stream);
+
 extern "C" int32_t hgs_knn_points(int32_t n, const float* points, int32_t m, const float* template_points, int32_t K,
                                   float* dists, int64_t* idx, void* stream)
 {
@@ -268,6 +457,38 @@ extern "C" int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float* points, int3
     if (int rc = dispatch_k<LaunchLbs>(K, n, points, m, template_points, lbs_weights, J, out_dist, out_weights, (hipStream_t)stream)) return rc;
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("smpl_lbsweight_top_k: kernel launch failed");
+        return HGS_ERR_HIP;
+    }
+    return HGS_OK;
+}
+
+extern "C" size_t hgs_dist_cuda2_workspace(int32_t n) { return n >= GRID_MIN_POINTS ? GridWorkspace(n).total : 0; }
+
+extern "C" int32_t hgs_dist_cuda2_ws(int32_t n, const float* points, float* mean_dist2, void* workspace, void* stream)
+{
+    if (n < GRID_MIN_POINTS || !workspace) return hgs_dist_cuda2(n, points, mean_dist2, stream);
+    if (!points || !mean_dist2) return fail_knn("distCUDA2: null pointer");
+    if (((uintptr_t)points & 3) != 0) return fail_knn("distCUDA2: points must be float-aligned");
+    if (((uintptr_t)workspace & 15) != 0) return fail_knn("distCUDA2: the workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const GridWorkspace ws(n);
+    char* base = (char*)workspace;
+    GridParams* gp = (GridParams*)(base + ws.params);
+    uint32_t* cell_id = (uint32_t*)(base + ws.cell_id);
+    uint32_t* slot = (uint32_t*)(base + ws.slot);
+    uint32_t* cell_count = (uint32_t*)(base + ws.cell_count);
+    float4* sorted = (float4*)(base + ws.sorted);
+    const int blocks = (n + 255) / 256;
+    if (hipMemsetAsync(cell_count, 0, 4 * ((size_t)n + 2), st) != hipSuccess) return fail_knn("distCUDA2: memset failed");
+    hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1), 0, st, gp);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, n, points, gp);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, n, gp, cell_count);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(blocks), dim3(256), 0, st, n, points, gp, cell_id, slot, cell_count);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, st, gp, cell_count);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(blocks), dim3(256), 0, st, n, points, cell_id, slot, cell_count, sorted);
+    hipLaunchKernelGGL(grid_search_kernel, dim3(blocks), dim3(256), 0, st, n, gp, cell_count, sorted, mean_dist2);
+    if (hipGetLastError() != hipSuccess) {
+        hgs::set_last_error("distCUDA2: kernel launch failed");
         return HGS_ERR_HIP;
     }
     return HGS_OK;

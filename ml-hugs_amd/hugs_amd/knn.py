@@ -110,16 +110,22 @@ def smpl_lbsmap_top_k(lbs_weights, verts_transform, points, template_points, K=6
 
 def distCUDA2(points):
     """points [n,3] (cuda, fp32) -> [n]: mean squared distance to the three nearest other points (scene.py:181 clamps
-    it and takes log(sqrt(.)) as the initial scale).  Brute force in HIP, exact."""
+    it and takes log(sqrt(.)) as the initial scale).  Exact: a brute-force scan for initialisation-sized clouds, a uniform
+    grid search (same bits, O(n)) from 32 768 points on."""
     lib = _load()
-    lib.hgs_dist_cuda2.restype = C.c_int32
-    lib.hgs_dist_cuda2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hgs_dist_cuda2_ws.restype = C.c_int32
+    lib.hgs_dist_cuda2_ws.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hgs_dist_cuda2_workspace.restype = C.c_size_t
+    lib.hgs_dist_cuda2_workspace.argtypes = [C.c_int32]
     if points.ndim != 2 or points.shape[1] != 3:
         raise ValueError("distCUDA2: expected points [n,3]")
     p = _prep(points, "points")
     out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    nbytes = lib.hgs_dist_cuda2_workspace(p.shape[0])
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device) if nbytes else None
     with torch.cuda.device(p.device):
-        rc = lib.hgs_dist_cuda2(p.shape[0], p.data_ptr(), out.data_ptr(), _stream_ptr(p.device))
+        rc = lib.hgs_dist_cuda2_ws(p.shape[0], p.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                   _stream_ptr(p.device))
     if rc < 0:
         _raise_last(lib, "distCUDA2")
     return out

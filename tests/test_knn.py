@@ -171,3 +171,31 @@ def test_hip_dist_cuda2_is_bit_exact_against_the_oracle(n, device):
     assert torch.isfinite(scales).all()
     with pytest.raises(RuntimeError):
         distCUDA2(torch.zeros(3, 3, device=device))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["gaussian", "clusters_and_outliers", "plane", "duplicates"])
+def test_hip_dist_cuda2_grid_search_is_bit_exact(shape, device):
+    """From 32 768 points on distCUDA2 searches a uniform grid (O(n)) instead of scanning the cloud (O(n^2)): same three
+    nearest distances, same fp32 expression, same bits -- on a Gaussian cloud, on tight clusters with far outliers (the
+    outliers fall back to scanning the cloud), on a planar cloud (a degenerate grid axis) and with many exact duplicates."""
+    from hugs_amd.knn import distCUDA2
+    import diff_gaussian_rasterization as dgr
+    n = 33_000
+    assert dgr._load().hgs_dist_cuda2_workspace(n) > 0 and dgr._load().hgs_dist_cuda2_workspace(30_000) == 0
+    r = np.random.default_rng(len(shape))
+    if shape == "gaussian":
+        pts = r.standard_normal((n, 3))
+    elif shape == "clusters_and_outliers":
+        centres = r.uniform(-5, 5, (40, 3))
+        pts = centres[r.integers(0, 40, n)] + 0.01 * r.standard_normal((n, 3))
+        pts[:25] = r.uniform(-300, 300, (25, 3))
+    elif shape == "plane":
+        pts = np.concatenate([r.uniform(-1, 1, (n, 2)), np.full((n, 1), 0.25)], 1)
+    else:
+        pts = r.standard_normal((n // 3, 3))
+        pts = np.concatenate([pts, pts, pts[: n - 2 * (n // 3)]], 0)     # every point two or three times
+    pts = pts.astype(np.float32)
+    got = distCUDA2(torch.from_numpy(pts).to(device)).cpu().numpy()
+    ref = ko.dist_cuda2(pts)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{(got != ref).sum()} of {n} differ"

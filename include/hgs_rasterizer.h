@@ -237,6 +237,20 @@ int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, cons
                                  const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
                                  void *stream);
 
+/* Replaces smpl_lbsmap_top_k (hugs_wo_trimlp.py:47-85, the model variant without the triplane) for batch size 1, search and
+ * blending fused: out_transform [n,16] = sum_k wgt_k verts_transform[idx_k] ([m,16], row-major 4x4, 16-byte aligned),
+ * out_info [n,C] likewise from addition_info [m,C] (both NULL: none), out_dist [n]; out_idx [n,K] (int32) / out_wgt [n,K]
+ * are the neighbours and their normalised, confidence-gated weights, which the backward takes: gradients with respect to
+ * verts_transform / addition_info ([m,16] / [m,C], ZERO on entry: float atomics add into them), as the reference
+ * differentiates (the search and the weights are constants there too). */
+int32_t hgs_smpl_lbsmap_top_k(int32_t n, const float *points, int32_t m, const float *template_points,
+                              const float *lbs_weights, int32_t J, int32_t K, const float *verts_transform,
+                              const float *addition_info, int32_t C, float *out_dist, float *out_transform,
+                              float *out_info, int32_t *out_idx, float *out_wgt, void *stream);
+int32_t hgs_smpl_lbsmap_top_k_backward(int32_t n, int32_t K, const int32_t *idx, const float *wgt,
+                                       const float *dL_dtransform, const float *dL_dinfo, int32_t C,
+                                       float *dL_dverts_transform, float *dL_daddition_info, void *stream);
+
 /* SURVEY.md 8f row f-2, second half -- the skinning step of the human model's learned LBS, fused: replaces the matmul /
  * cat / batched-matmul / slice statements of lbs_extra (/root/reference/hugs/models/modules/lbs.py:60-73, called every
  * training step at hugs/models/hugs_trimlp.py:477-489) and the rotation product of hugs_trimlp.py:517, for one batch element:

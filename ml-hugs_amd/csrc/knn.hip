@@ -189,6 +189,81 @@ lbsweight_top_k_kernel(int n, const float* __restrict__ points, int m, const flo
     }
 }
 
+// smpl_lbsmap_top_k fused behind the search (hugs_wo_trimlp.py:47-85, the ablation model without the triplane): the same
+// confidence-gated neighbour weights as above, then
+//   out_transform[i] = sum_k wgt_k verts_transform[idx_k]   (4x4, 16 floats)     out_info[i] = sum_k wgt_k info[idx_k]   (C floats)
+// The neighbour indices and weights are kept for the backward: the reference differentiates through verts_transform and
+// addition_info (the search and the weights are constants there too: no_grad search, lbs_weights only enter a `>` gate).
+template <int K>
+__global__ void __launch_bounds__(64 * KNN_SPLIT)
+lbsmap_top_k_kernel(int n, const float* __restrict__ points, int m, const float* __restrict__ templ,
+                    const float* __restrict__ lbs_weights, int J, const float* __restrict__ verts_transform,
+                    const float* __restrict__ info, int Cc, float* __restrict__ out_dist, float* __restrict__ out_transform,
+                    float* __restrict__ out_info, int32_t* __restrict__ out_idx, float* __restrict__ out_wgt)
+{
+    Best<K> best;
+    int i;
+    if (!workgroup_knn<K>(n, points, m, templ, best, i) || i >= n) return;
+    const float weight_std2 = (float)(2.0 * 0.1 * 0.1);
+    const float* w0 = lbs_weights + (size_t)best.i[0] * J;
+    float wgt[K], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float* wk = lbs_weights + (size_t)best.i[k] * J;
+        float l1 = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < J; ++j) l1 += fabsf(wk[j] - w0[j]);
+        const float conf = expf(-l1 / weight_std2) > 0.9f ? 1.0f : 0.0f;
+        wgt[k] = expf(-best.d[k]) * conf;
+        sum += wgt[k];
+    }
+    float dist = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        wgt[k] = wgt[k] / sum;
+        dist += wgt[k] * best.d[k];
+        out_idx[(size_t)i * K + k] = best.i[k], out_wgt[(size_t)i * K + k] = wgt[k];
+    }
+    out_dist[i] = dist;
+    float4 acc[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4* T = reinterpret_cast<const float4*>(verts_transform + (size_t)best.i[k] * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 t = T[r];
+            acc[r].x += wgt[k] * t.x, acc[r].y += wgt[k] * t.y, acc[r].z += wgt[k] * t.z, acc[r].w += wgt[k] * t.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) reinterpret_cast<float4*>(out_transform + (size_t)i * 16)[r] = acc[r];
+    if (info)
+        for (int c = 0; c < Cc; ++c) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) a += wgt[k] * info[(size_t)best.i[k] * Cc + c];
+            out_info[(size_t)i * Cc + c] = a;
+        }
+}
+
+// its backward: dL/dverts_transform[idx_k] += wgt_k dL/dout_transform[i] (and likewise for info): thread = (point, neighbour)
+__global__ void __launch_bounds__(256)
+lbsmap_backward_kernel(int n, int K, const int32_t* __restrict__ idx, const float* __restrict__ wgt,
+                       const float* __restrict__ g_transform, const float* __restrict__ g_info, int Cc,
+                       float* __restrict__ d_verts_transform, float* __restrict__ d_info)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)n * K) return;
+    const size_t i = t / K;
+    const int v = idx[t];
+    const float w = wgt[t];
+    if (w == 0.0f) return;  // (a neighbour the confidence gate closed)
+    if (g_transform)
+        for (int e = 0; e < 16; ++e) atomicAdd(&d_verts_transform[(size_t)v * 16 + e], w * g_transform[i * 16 + e]);
+    if (g_info)
+        for (int c = 0; c < Cc; ++c) atomicAdd(&d_info[(size_t)v * Cc + c], w * g_info[i * Cc + c]);
+}
+
 // simple_knn's distCUDA2 -- mean squared distance of every point of a cloud to its three nearest
 // OTHER points (scene.py:181, initial scales).  Upstream sorts by Morton code and searches boxes; at initialisation
 // sizes (1e5 points) the brute-force scan above does the n^2 distances in a few milliseconds, exactly.
@@ -419,6 +494,16 @@ struct LaunchKnn {
     }
 };
 template <int K>
+struct LaunchLbsMap {
+    static int go(int n, const float* p, int m, const float* t, const float* w, int J, const float* vt, const float* info, int Cc,
+                  float* od, float* ot, float* oi, int32_t* oidx, float* owgt, hipStream_t st)
+    {
+        hipLaunchKernelGGL(lbsmap_top_k_kernel<K>, dim3((n + 63) / 64), dim3(64 * KNN_SPLIT), 0, st, n, p, m, t, w, J, vt, info, Cc, od, ot,
+                           oi, oidx, owgt);
+        return HGS_OK;
+    }
+};
+template <int K>
 struct LaunchLbs {
     static int go(int n, const float* p, int m, const float* t, const float* w, int J, float* od, float* ow, hipStream_t st)
     {
@@ -457,6 +542,47 @@ extern "C" int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float* points, int3
     if (int rc = dispatch_k<LaunchLbs>(K, n, points, m, template_points, lbs_weights, J, out_dist, out_weights, (hipStream_t)stream)) return rc;
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("smpl_lbsweight_top_k: kernel launch failed");
+        return HGS_ERR_HIP;
+    }
+    return HGS_OK;
+}
+
+extern "C" int32_t hgs_smpl_lbsmap_top_k(int32_t n, const float* points, int32_t m, const float* template_points,
+                                         const float* lbs_weights, int32_t J, int32_t K, const float* verts_transform,
+                                         const float* addition_info, int32_t C, float* out_dist, float* out_transform,
+                                         float* out_info, int32_t* out_idx, float* out_wgt, void* stream)
+{
+    if (n < 0 || m < K || K < 1 || J < 1 || C < 0) return fail_knn("smpl_lbsmap_top_k: need n >= 0, J >= 1, C >= 0 and 1 <= K <= m");
+    if (n == 0) return HGS_OK;
+    if (!points || !template_points || !lbs_weights || !verts_transform || !out_dist || !out_transform || !out_idx || !out_wgt ||
+        ((addition_info != nullptr) != (out_info != nullptr)) || (addition_info && C < 1))
+        return fail_knn("smpl_lbsmap_top_k: null pointer");
+    if (((uintptr_t)template_points & 3) != 0) return fail_knn("smpl_lbsmap_top_k: template_points must be float-aligned");
+    if ((((uintptr_t)verts_transform | (uintptr_t)out_transform) & 15) != 0)
+        return fail_knn("smpl_lbsmap_top_k: verts_transform and out_transform must be 16-byte aligned");
+    if (int rc = dispatch_k<LaunchLbsMap>(K, n, points, m, template_points, lbs_weights, J, verts_transform, addition_info, C, out_dist,
+                                          out_transform, out_info, out_idx, out_wgt, (hipStream_t)stream))
+        return rc;
+    if (hipGetLastError() != hipSuccess) {
+        hgs::set_last_error("smpl_lbsmap_top_k: kernel launch failed");
+        return HGS_ERR_HIP;
+    }
+    return HGS_OK;
+}
+
+extern "C" int32_t hgs_smpl_lbsmap_top_k_backward(int32_t n, int32_t K, const int32_t* idx, const float* wgt,
+                                                  const float* dL_dtransform, const float* dL_dinfo, int32_t C,
+                                                  float* dL_dverts_transform, float* dL_daddition_info, void* stream)
+{
+    if (n < 0 || K < 1 || C < 0) return fail_knn("smpl_lbsmap_top_k_backward: bad sizes");
+    if (n == 0) return HGS_OK;
+    if (!idx || !wgt || (dL_dtransform && !dL_dverts_transform) || (dL_dinfo && !dL_daddition_info))
+        return fail_knn("smpl_lbsmap_top_k_backward: null pointer");
+    const size_t threads = (size_t)n * K;
+    hipLaunchKernelGGL(lbsmap_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, K, idx, wgt,
+                       dL_dtransform, dL_dinfo, C, dL_dverts_transform, dL_daddition_info);
+    if (hipGetLastError() != hipSuccess) {
+        hgs::set_last_error("smpl_lbsmap_top_k_backward: kernel launch failed");
         return HGS_ERR_HIP;
     }
     return HGS_OK;

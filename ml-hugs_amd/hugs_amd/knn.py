@@ -86,26 +86,75 @@ def batch_index_select(data, inds):
     return data[inds.long()]
 
 
+class _LbsMapTopK(torch.autograd.Function):
+    """One batch element of smpl_lbsmap_top_k: hgs_smpl_lbsmap_top_k forward (search + confidence-gated weights + blend of the
+    neighbours' 4x4 transforms and optional per-vertex info in one kernel), hgs_smpl_lbsmap_top_k_backward (scatter-add of the
+    weighted gradients into verts_transform / addition_info)."""
+
+    @staticmethod
+    def forward(ctx, lbs_weights, verts_transform, points, template_points, K, addition_info):
+        lib = _load()
+        lib.hgs_smpl_lbsmap_top_k.restype = C.c_int32
+        lib.hgs_smpl_lbsmap_top_k.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+        p, t, w = _prep(points, "points"), _prep(template_points, "template_points"), _prep(lbs_weights, "lbs_weights")
+        vt = _prep(verts_transform.reshape(verts_transform.shape[0], 16), "verts_transform")
+        info = _prep(addition_info, "addition_info") if addition_info is not None else None
+        n, m, J = p.shape[0], t.shape[0], w.shape[1]
+        Cc = info.shape[1] if info is not None else 0
+        dev = p.device
+        dist = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        out_T = torch.empty(n, 4, 4, dtype=torch.float32, device=dev)
+        out_info = torch.empty(n, Cc, dtype=torch.float32, device=dev) if info is not None else None
+        idx = torch.empty(n, K, dtype=torch.int32, device=dev)
+        wgt = torch.empty(n, K, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.hgs_smpl_lbsmap_top_k(n, p.data_ptr(), m, t.data_ptr(), w.data_ptr(), J, K, vt.data_ptr(),
+                                           info.data_ptr() if info is not None else None, Cc, dist.data_ptr(), out_T.data_ptr(),
+                                           out_info.data_ptr() if info is not None else None, idx.data_ptr(), wgt.data_ptr(),
+                                           _stream_ptr(dev))
+        if rc < 0:
+            _raise_last(lib, "smpl_lbsmap_top_k")
+        ctx.save_for_backward(idx, wgt)
+        ctx.dims = (n, K, m, Cc, tuple(verts_transform.shape), tuple(addition_info.shape) if addition_info is not None else None)
+        ctx.mark_non_differentiable(dist)
+        return (dist, out_T, out_info) if info is not None else (dist, out_T)
+
+    @staticmethod
+    def backward(ctx, _g_dist, g_T, g_info=None):
+        lib = _load()
+        lib.hgs_smpl_lbsmap_top_k_backward.restype = C.c_int32
+        lib.hgs_smpl_lbsmap_top_k_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        idx, wgt = ctx.saved_tensors
+        n, K, m, Cc, vt_shape, info_shape = ctx.dims
+        dev = idx.device
+        need_T = g_T is not None and ctx.needs_input_grad[1]
+        need_info = g_info is not None and info_shape is not None and ctx.needs_input_grad[5]
+        d_vt = torch.zeros(m, 16, dtype=torch.float32, device=dev) if need_T else None
+        d_info = torch.zeros(m, Cc, dtype=torch.float32, device=dev) if need_info else None
+        if need_T or need_info:
+            gT = g_T.contiguous().float() if need_T else None
+            gI = g_info.contiguous().float() if need_info else None
+            with torch.cuda.device(dev):
+                rc = lib.hgs_smpl_lbsmap_top_k_backward(n, K, idx.data_ptr(), wgt.data_ptr(), gT.data_ptr() if need_T else None,
+                                                        gI.data_ptr() if need_info else None, Cc,
+                                                        d_vt.data_ptr() if need_T else None, d_info.data_ptr() if need_info else None,
+                                                        _stream_ptr(dev))
+            if rc < 0:
+                _raise_last(lib, "smpl_lbsmap_top_k_backward")
+        return (None, d_vt.view(vt_shape) if need_T else None, None, None, None, d_info.view(info_shape) if need_info else None)
+
+
 def smpl_lbsmap_top_k(lbs_weights, verts_transform, points, template_points, K=6, addition_info=None):
-    """-> (xyz_dist, xyz_transform[, xyz_info]); HIP search, then the reference's statements (differentiable in
-    verts_transform / addition_info / lbs_weights exactly as upstream)."""
-    with torch.no_grad():
-        results = knn_points(points, template_points, K=K)
-        neighbs_dist, neighbs = results.dists, results.idx
-    weight_std2 = 2. * 0.1 ** 2
-    nb_w = lbs_weights[neighbs]
-    conf = torch.exp(-torch.sum(torch.abs(nb_w - nb_w[..., 0:1, :]), dim=-1) / weight_std2)
-    conf = torch.gt(conf, 0.9).float()
-    wgt = torch.exp(-neighbs_dist)
-    wgt = wgt * conf
-    wgt = wgt / wgt.sum(-1, keepdim=True)
-    nb_T = batch_index_select(verts_transform, neighbs)
-    xyz_transform = torch.sum(wgt.unsqueeze(-1).unsqueeze(-1) * nb_T, dim=2)
-    xyz_dist = torch.sum(wgt * neighbs_dist, dim=2, keepdim=True)
-    if addition_info is not None:
-        nb_info = batch_index_select(addition_info, neighbs)
-        return xyz_dist, xyz_transform, torch.sum(wgt.unsqueeze(-1) * nb_info, dim=2)
-    return xyz_dist, xyz_transform
+    """-> (xyz_dist [B,n,1], xyz_transform [B,n,4,4][, xyz_info [B,n,C]]) of hugs_wo_trimlp.py:47-85: the search, the
+    confidence-gated neighbour weights and the blends in ONE kernel per batch element, differentiable in verts_transform and
+    addition_info as upstream (the search runs under no_grad there too, and lbs_weights only enter a `>` gate)."""
+    if points.ndim != 3 or template_points.ndim != 3 or lbs_weights.ndim != 2 or verts_transform.ndim != 4:
+        raise ValueError("smpl_lbsmap_top_k: expected points [B,n,3], template_points [B,m,3], lbs_weights [m,J], verts_transform [B,m,4,4]")
+    outs = [_LbsMapTopK.apply(lbs_weights, verts_transform[b], points[b], template_points[b], int(K),
+                              addition_info[b] if addition_info is not None else None) for b in range(points.shape[0])]
+    return tuple(torch.stack([o[k] for o in outs], 0) for k in range(len(outs[0])))
 
 
 def distCUDA2(points):

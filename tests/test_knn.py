@@ -73,10 +73,25 @@ def test_hip_matches_golden_vectors(device):
     vT = t("knn_verts_transform")[None].requires_grad_(True)
     xd2, T, info = smpl_lbsmap_top_k(t("knn_lbs_weights"), vT, t("knn_points")[None], t("knn_template")[None], K=6,
                                      addition_info=t("knn_addition_info")[None])
-    np.testing.assert_allclose(xd2[0].cpu().numpy(), G["knn_lbsmap_dist"], rtol=FLOAT_TOL, atol=1e-9)
+    np.testing.assert_allclose(xd2[0].detach().cpu().numpy(), G["knn_lbsmap_dist"], rtol=FLOAT_TOL, atol=1e-9)
     np.testing.assert_allclose(T[0].detach().cpu().numpy(), G["knn_lbsmap_transform"], rtol=FLOAT_TOL, atol=1e-7)
-    np.testing.assert_allclose(info[0].cpu().numpy(), G["knn_lbsmap_info"], rtol=FLOAT_TOL, atol=1e-7)
-    T.sum().backward()                                   # gradients reach verts_transform as upstream
+    np.testing.assert_allclose(info[0].detach().cpu().numpy(), G["knn_lbsmap_info"], rtol=FLOAT_TOL, atol=1e-7)
+    # gradients reach verts_transform (and addition_info) as upstream: d/dverts_transform[v] = sum over the (point, neighbour)
+    # pairs that picked vertex v of wgt * dL/dxyz_transform[point] -- the fused backward's scatter-add against numpy's
+    aI = t("knn_addition_info")[None].requires_grad_(True)
+    vT2 = t("knn_verts_transform")[None].requires_grad_(True)
+    _, T2, info2 = smpl_lbsmap_top_k(t("knn_lbs_weights"), vT2, t("knn_points")[None], t("knn_template")[None], K=6, addition_info=aI)
+    r = np.random.default_rng(0)
+    gT, gI = r.standard_normal(T2.shape[1:]).astype(np.float32), r.standard_normal(info2.shape[1:]).astype(np.float32)
+    ((T2[0] * torch.from_numpy(gT).to(device)).sum() + (info2[0] * torch.from_numpy(gI).to(device)).sum()).backward()
+    _, wgt = ko._blend_weights(G["knn_lbs_weights"], G["knn_search_dists"], G["knn_search_idx"])
+    want_T = np.zeros(G["knn_verts_transform"].shape, np.float64)
+    want_I = np.zeros(G["knn_addition_info"].shape, np.float64)
+    np.add.at(want_T, G["knn_search_idx"], wgt[:, :, None, None].astype(np.float64) * gT[:, None].astype(np.float64))
+    np.add.at(want_I, G["knn_search_idx"], wgt[:, :, None].astype(np.float64) * gI[:, None].astype(np.float64))
+    np.testing.assert_allclose(vT2.grad[0].cpu().numpy(), want_T, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(aI.grad[0].cpu().numpy(), want_I, rtol=1e-5, atol=1e-6)
+    T.sum().backward()
     assert vT.grad is not None and float(vT.grad.abs().sum()) > 0
 
 

@@ -1093,3 +1093,38 @@ def test_fused_visibility_and_viewspace_sink(binding, device, monkeypatch):
         out[nonleaf] = (pkg["render"].detach(), vs.grad.clone())
     assert torch.equal(out[False][0], out[True][0])
     assert rel_l2(out[False][1].cpu().numpy(), out[True][1].cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+def test_segmented_backward_equals_the_one_wave_per_quad_backward(binding, device, monkeypatch):
+    """Sparse frames with a backward to come get checkpoints and the depth-segmented backward; without the checkpoint buffer
+    (HGS_BWD_SEGMENTED=0, or a caller that offers none) the one-wave-per-quad kernel runs.  Same frame through both -- a
+    stacked scene with lists a few hundred to two thousand entries deep, i.e. many segments per quad, early-saturating
+    pixels, clamped outputs: images bit-equal (the forward only ADDS checkpoint stores), gradients within the summation
+    order of the float atomics plus the checkpoint's colour-prefix cancellation (1e-5), both within the bar of the oracle."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = _stacked_scene(2500, 64, 64, seed=77, spread_px=9.0)
+    sc["opacities"] = np.clip(sc["opacities"] * 3.0, 0.0, 0.95).astype(np.float32)   # pixels saturate well inside the lists
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    assert (ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]).max() > 600
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    grads, images = {}, {}
+    for seg in (True, False):
+        monkeypatch.setattr(dgr, "_USE_CKPT", seg)
+        if dgr._cpp is not None:
+            dgr._cpp.use_checkpoints(seg)
+        t, color, _ = run_gpu(sc, device)
+        color.backward(to_dev(sc["dL_dpix"], device))
+        images[seg] = color.detach()
+        grads[seg] = {k: t[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}
+    if dgr._cpp is not None:
+        dgr._cpp.use_checkpoints(True)
+    assert torch.equal(images[True], images[False])
+    for k in grads[True]:
+        assert rel_l2(grads[True][k], grads[False][k]) <= 1e-5, k
+        if k in refg:
+            assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k

@@ -129,6 +129,12 @@ __device__ __forceinline__ void blend_forward_wave(const Camera& cam, uint32_t l
             if (__ballot(T > 0.0f) == 0ull) { walked = min(j + 4, n); break; }
             eA = eA2, eB = eB2;
         }
+        // The next pair's records (rA0, rA1) are loaded in the MIDDLE of the loop body so that they fly while the second pair
+        // is blended.  LLVM sinks loads whose results only the next trip uses below the "all pixels done" exit -- right in
+        // front of the wait at the loop's top, where a wave that runs alone (the deep quads that outlast everybody on a
+        // sparse frame) sits out the whole scalar-load latency once per trip.  Keeping the values alive past the loop (and
+        // compiling binning.hip without the machine-sink pass, see the Makefile) pins the loads where they are written.
+        asm volatile("" ::"s"(rA0.x), "s"(rA0.L), "s"(rA0.b), "s"(rA1.x), "s"(rA1.L), "s"(rA1.b));
     }
     if (ck_tile) {
         const uint32_t segs = (walked + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT;

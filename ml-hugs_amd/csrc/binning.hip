@@ -872,6 +872,7 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     const uint32_t tile = large_tiles[li];
     const uint2 rg = ranges[tile];
     const uint32_t s = rg.x, n = rg.y - rg.x;
+    bool sorted_in_lds = false;  // (workgroup-uniform)
     if (n <= threshold) continue;  // (a candidate that is not long on this -- dense -- frame: the small-tile kernel sorts it)
     // bitonic sort of up to CAP keys in LDS; `count` keys from `src`, result left in sh[0..count)
     auto sort_in_lds = [&](const uint64_t* src, uint32_t count) {
@@ -919,15 +920,22 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                 key[e] = i < n ? keys[s + i] : ~0ull;
             }
             if (!bucket_sort<E, SORT_LARGE_THREADS>(key, pos, n, sh, bucket_start, red)) return false;
+            __syncthreads();  // every thread has ranked its keys: the bucketed copy in LDS may be overwritten ...
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < n) list[s + pos[e]] = list_entry(key[e], pos[e] + 1u);
+                if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < n) {
+                    const uint64_t entry = list_entry(key[e], pos[e] + 1u);
+                    list[s + pos[e]] = entry;
+                    sh[pos[e]] = entry;  // ... by the sorted list itself: the compaction below reads it from here
+                }
             return true;
         };
+        sorted_in_lds = true;
         const bool done = n <= 2u * SORT_LARGE_THREADS   ? by_buckets(std::integral_constant<int, 2>{})
                           : n <= 4u * SORT_LARGE_THREADS ? by_buckets(std::integral_constant<int, 4>{})
                                                          : by_buckets(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
         if (!done) {
+            sorted_in_lds = false;
             if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
             else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
         }
@@ -960,13 +968,14 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
             list[s + rank] = list_entry(ki, rank + 1u);
         }
     }
-    // the segment is sorted in global memory (written by this workgroup): compact it chunk by chunk
+    // the segment is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it
+    // chunk by chunk (the bucket array is free by now: the compaction's scratch)
     __syncthreads();
     uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
     for (uint32_t base = 0; base < n; base += SORT_LARGE_THREADS) {
         const uint32_t i = base + threadIdx.x;
-        const uint64_t entry = i < n ? __builtin_nontemporal_load(&list[s + i]) : 0ull;
-        compact_chunk<SORT_LARGE_THREADS / 64>(entry, i < n, carry, s, act, stride, reinterpret_cast<uint32_t*>(sh));
+        const uint64_t entry = i < n ? (sorted_in_lds ? sh[i] : __builtin_nontemporal_load(&list[s + i])) : 0ull;
+        compact_chunk<SORT_LARGE_THREADS / 64>(entry, i < n, carry, s, act, stride, bucket_start);
     }
 #pragma unroll
     for (int q = 0; q < NUM_LISTS; ++q)

@@ -315,6 +315,11 @@ blend_backward_wave(const Camera& cam, uint32_t lastg, int tile, int w, v2u rang
     SplatRec rA0 = load_rec(splats, eA.z, lastg), rA1 = load_rec(splats, eA.x, lastg);  // rA0: deeper, first
     v4u eB = load_pair(top - 4, 0);
     for (uint32_t j = 0; j < n; j += 4) {
+        // Scalar loads return out of order, so the only wait there is is "all of them": it has to sit HERE, before the next
+        // set's loads are issued -- the compiler puts it at the first use of set A, i.e. behind the loads of set B issued just
+        // above that use, and a wave then sits out a whole scalar-cache round trip per half-iteration (hidden at eight waves
+        // per SIMD, not on a sparse frame's deep quads).
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         const SplatRec rB0 = load_rec(splats, eB.z, lastg), rB1 = load_rec(splats, eB.x, lastg);
         const v4u eA2 = load_pair(top - 6 - j, 0);
         backward_entry(rA0, eA.z, eA.w);

@@ -430,6 +430,8 @@ def main():
             out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": vu["valu_busy_frac"],
                                  "wave_instructions_per_launch": vu["valu_wave_instructions"],
                                  "source": "profiles/" + os.path.basename(f) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
+            if vu_all.get("note"):
+                out["valu_issue"]["note"] = vu_all["note"]
         else:
             out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": None,
                                  "note": f"stale: profiles/{os.path.basename(f)} was taken on csrc {vu_all.get('csrc_sha16')}, this build is {here}"}

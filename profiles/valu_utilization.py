@@ -25,7 +25,10 @@ def parse(path):
 
 def main(set1, set2):
     a, b = parse(set1), parse(set2)
-    res = {"source": [set1, set2], "csrc_sha16": csrc_sha16(), "formula": "SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)", "kernels": {}}
+    res = {"source": [set1, set2], "csrc_sha16": csrc_sha16(), "formula": "SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)",
+           "note": "numerator and denominator come from two separate rocprofv3 PMC passes (counter groups that cannot be collected "
+                   "together): the ratio carries their run-to-run difference of a few per cent and can read slightly above 1",
+           "kernels": {}}
     for k in sorted(set(a) & set(b)):
         if "SQ_ACTIVE_INST_VALU" in a[k] and "GRBM_GUI_ACTIVE" in b[k]:
             cyc = b[k]["GRBM_GUI_ACTIVE"] / 8.0

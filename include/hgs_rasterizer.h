@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 9
+#define HGS_ABI_VERSION 10
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
@@ -229,6 +229,16 @@ int32_t hgs_densification_stats(int32_t n, const float *viewspace_grad, const in
  * the lower template index first.  Pointers need float alignment only. */
 int32_t hgs_knn_points(int32_t n, const float *points, int32_t m, const float *template_points, int32_t K,
                        float *dists, int64_t *idx, void *stream);
+/* The searches above and below scan the whole template for every point (n x m distances).  Given a workspace of
+ * hgs_knn_workspace(n, m) bytes (16-byte aligned, contents don't matter; 0 = the grid would not pay: a template under 512
+ * vertices or fewer than 4 points per vertex, the *_ws forms then scan as well) the *_ws forms first put the template on a
+ * uniform grid, sort the points by the cell they fall into, and let every 64 neighbouring points test only the vertices of
+ * the cells around them; a point whose K-th neighbour is not certainly inside that box scans the whole template in a second
+ * pass.  The same neighbours in the same order, exact ties included, in a fraction of the distances (110 000 points x 6 890
+ * SMPL vertices: 0.38 -> 0.17 ms). */
+size_t hgs_knn_workspace(int32_t n, int32_t m);
+int32_t hgs_knn_points_ws(int32_t n, const float *points, int32_t m, const float *template_points, int32_t K,
+                          float *dists, int64_t *idx, void *workspace, void *stream);
 
 /* Replaces smpl_lbsweight_top_k (hugs_wo_trimlp.py:88-119; called on every training step at hugs_trimlp.py:318,480)
  * for batch size 1, search and blending fused: lbs_weights [m,J] (J = 24 for SMPL), out_dist [n] (xyz_dist),
@@ -236,6 +246,9 @@ int32_t hgs_knn_points(int32_t n, const float *points, int32_t m, const float *t
 int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, const float *template_points,
                                  const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
                                  void *stream);
+int32_t hgs_smpl_lbsweight_top_k_ws(int32_t n, const float *points, int32_t m, const float *template_points,
+                                    const float *lbs_weights, int32_t J, int32_t K, float *out_dist, float *out_weights,
+                                    void *workspace, void *stream);
 
 /* Replaces smpl_lbsmap_top_k (hugs_wo_trimlp.py:47-85, the model variant without the triplane) for batch size 1, search and
  * blending fused: out_transform [n,16] = sum_k wgt_k verts_transform[idx_k] ([m,16], row-major 4x4, 16-byte aligned),
@@ -246,7 +259,8 @@ int32_t hgs_smpl_lbsweight_top_k(int32_t n, const float *points, int32_t m, cons
 int32_t hgs_smpl_lbsmap_top_k(int32_t n, const float *points, int32_t m, const float *template_points,
                               const float *lbs_weights, int32_t J, int32_t K, const float *verts_transform,
                               const float *addition_info, int32_t C, float *out_dist, float *out_transform,
-                              float *out_info, int32_t *out_idx, float *out_wgt, void *stream);
+                              float *out_info, int32_t *out_idx, float *out_wgt, void *workspace /* hgs_knn_workspace(n, m) or NULL */,
+                              void *stream);
 int32_t hgs_smpl_lbsmap_top_k_backward(int32_t n, int32_t K, const int32_t *idx, const float *wgt,
                                        const float *dL_dtransform, const float *dL_dinfo, int32_t C,
                                        float *dL_dverts_transform, float *dL_daddition_info, void *stream);

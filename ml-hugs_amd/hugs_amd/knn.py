@@ -12,6 +12,7 @@ function) runs in hand-written HIP (csrc/knn.hip) behind the C ABI; smpl_lbsmap_
 statements after the search because gradients flow through `verts_transform` there.  No CPU fallback.
 """
 import ctypes as C
+import os
 from collections import namedtuple
 
 import torch
@@ -29,6 +30,17 @@ def _prep(t, name):
     return t.contiguous()
 
 
+def _template_workspace(lib, n, m, device):
+    """Scratch for the grid over the template (hgs_knn_workspace): with it the searches walk a few cells per point instead
+    of scanning the whole template -- same neighbours, same order."""
+    lib.hgs_knn_workspace.restype = C.c_size_t
+    lib.hgs_knn_workspace.argtypes = [C.c_int32, C.c_int32]
+    if os.environ.get("HGS_KNN_GRID", "1") == "0":            # A/B switch: the scan of the whole template
+        return None
+    nbytes = lib.hgs_knn_workspace(n, m)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+
+
 def knn_points(p1, p2, lengths1=None, lengths2=None, norm=2, K=1, version=-1, return_nn=False, return_sorted=True):
     """p1 [B,n,3], p2 [B,m,3] -> KNN(dists [B,n,K] squared L2 ascending, idx [B,n,K] int64, knn)."""
     if lengths1 is not None or lengths2 is not None or norm != 2:
@@ -36,16 +48,17 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, norm=2, K=1, version=-1, re
     if p1.ndim != 3 or p2.ndim != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != 3 or p2.shape[2] != 3:
         raise ValueError("knn_points: expected p1 [B,n,3] and p2 [B,m,3]")
     lib = _load()
-    lib.hgs_knn_points.restype = C.c_int32
-    lib.hgs_knn_points.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hgs_knn_points_ws.restype = C.c_int32
+    lib.hgs_knn_points_ws.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     a, b = _prep(p1, "p1"), _prep(p2, "p2")
     B, n, m = a.shape[0], a.shape[1], b.shape[1]
     dists = torch.empty(B, n, K, dtype=torch.float32, device=a.device)
     idx = torch.empty(B, n, K, dtype=torch.int64, device=a.device)
+    ws = _template_workspace(lib, n, m, a.device)
     with torch.cuda.device(a.device):
         for i in range(B):
-            rc = lib.hgs_knn_points(n, a[i].data_ptr(), m, b[i].data_ptr(), K, dists[i].data_ptr(), idx[i].data_ptr(),
-                                    _stream_ptr(a.device))
+            rc = lib.hgs_knn_points_ws(n, a[i].data_ptr(), m, b[i].data_ptr(), K, dists[i].data_ptr(), idx[i].data_ptr(),
+                                       ws.data_ptr() if ws is not None else None, _stream_ptr(a.device))
             if rc < 0:
                 _raise_last(lib, "knn_points")
     nn = None
@@ -58,9 +71,9 @@ def smpl_lbsweight_top_k(lbs_weights, points, template_points, K=6):
     """-> (xyz_dist [B,n,1], xyz_neighbs_lbs_weight [B,n,J]); one fused kernel per batch element, no autograd (the
     reference's call sites wrap it in torch.no_grad() and its inputs' gradients are cut by the no_grad search)."""
     lib = _load()
-    lib.hgs_smpl_lbsweight_top_k.restype = C.c_int32
-    lib.hgs_smpl_lbsweight_top_k.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hgs_smpl_lbsweight_top_k_ws.restype = C.c_int32
+    lib.hgs_smpl_lbsweight_top_k_ws.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if points.ndim != 3 or template_points.ndim != 3 or lbs_weights.ndim != 2:
         raise ValueError("smpl_lbsweight_top_k: expected points [B,n,3], template_points [B,m,3], lbs_weights [m,J]")
     p, t, w = _prep(points, "points"), _prep(template_points, "template_points"), _prep(lbs_weights, "lbs_weights")
@@ -69,10 +82,11 @@ def smpl_lbsweight_top_k(lbs_weights, points, template_points, K=6):
         raise ValueError("smpl_lbsweight_top_k: lbs_weights must have one row per template point")
     dist = torch.empty(B, n, 1, dtype=torch.float32, device=p.device)
     out = torch.empty(B, n, J, dtype=torch.float32, device=p.device)
+    ws = _template_workspace(lib, n, m, p.device)
     with torch.cuda.device(p.device):
         for i in range(B):
-            rc = lib.hgs_smpl_lbsweight_top_k(n, p[i].data_ptr(), m, t[i].data_ptr(), w.data_ptr(), J, K, dist[i].data_ptr(),
-                                              out[i].data_ptr(), _stream_ptr(p.device))
+            rc = lib.hgs_smpl_lbsweight_top_k_ws(n, p[i].data_ptr(), m, t[i].data_ptr(), w.data_ptr(), J, K, dist[i].data_ptr(),
+                                                 out[i].data_ptr(), ws.data_ptr() if ws is not None else None, _stream_ptr(p.device))
             if rc < 0:
                 _raise_last(lib, "smpl_lbsweight_top_k")
     return dist, out
@@ -96,7 +110,7 @@ class _LbsMapTopK(torch.autograd.Function):
         lib = _load()
         lib.hgs_smpl_lbsmap_top_k.restype = C.c_int32
         lib.hgs_smpl_lbsmap_top_k.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                              C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+                                              C.c_void_p, C.c_int32] + [C.c_void_p] * 7
         p, t, w = _prep(points, "points"), _prep(template_points, "template_points"), _prep(lbs_weights, "lbs_weights")
         vt = _prep(verts_transform.reshape(verts_transform.shape[0], 16), "verts_transform")
         info = _prep(addition_info, "addition_info") if addition_info is not None else None
@@ -108,11 +122,12 @@ class _LbsMapTopK(torch.autograd.Function):
         out_info = torch.empty(n, Cc, dtype=torch.float32, device=dev) if info is not None else None
         idx = torch.empty(n, K, dtype=torch.int32, device=dev)
         wgt = torch.empty(n, K, dtype=torch.float32, device=dev)
+        ws = _template_workspace(lib, n, m, dev)
         with torch.cuda.device(dev):
             rc = lib.hgs_smpl_lbsmap_top_k(n, p.data_ptr(), m, t.data_ptr(), w.data_ptr(), J, K, vt.data_ptr(),
                                            info.data_ptr() if info is not None else None, Cc, dist.data_ptr(), out_T.data_ptr(),
                                            out_info.data_ptr() if info is not None else None, idx.data_ptr(), wgt.data_ptr(),
-                                           _stream_ptr(dev))
+                                           ws.data_ptr() if ws is not None else None, _stream_ptr(dev))
         if rc < 0:
             _raise_last(lib, "smpl_lbsmap_top_k")
         ctx.save_for_backward(idx, wgt)

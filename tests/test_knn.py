@@ -214,3 +214,58 @@ def test_hip_dist_cuda2_grid_search_is_bit_exact(shape, device):
     got = distCUDA2(torch.from_numpy(pts).to(device)).cpu().numpy()
     ref = ko.dist_cuda2(pts)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{(got != ref).sum()} of {n} differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,layout", [(1, "blob"), (6, "blob"), (8, "blob"), (6, "surface"), (6, "uniform_box"), (3, "line")])
+def test_grid_search_equals_the_scan(K, layout, device):
+    """hgs_knn_points_ws (template on a uniform grid, shells of cells around every query) against hgs_knn_points (the scan of
+    the whole template): the same K neighbours in the same order, bit for bit -- for queries on the body, far outside its
+    bounding box (the fall-back to the scan), exactly on template vertices, and a template with every vertex duplicated
+    (ties: the lower index first) and a degenerate flat part.  Layouts: a normal cloud with sparse tails; a surface of
+    human size (waves of one or two groups); queries spread evenly over the box (many groups per wave: the open list); every
+    vertex on one line (a grid of one row)."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
+    lib.hgs_knn_workspace.restype = C.c_size_t
+    lib.hgs_knn_workspace.argtypes = [C.c_int32, C.c_int32]
+    args = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.hgs_knn_points.argtypes = args + [C.c_void_p]
+    lib.hgs_knn_points_ws.argtypes = args + [C.c_void_p, C.c_void_p]
+    r = np.random.default_rng(K)
+    templ, _, pts = body(30_000, 3445, 24, seed=40 + K)
+    if layout == "surface":
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        from bench_knn import body_surface
+        templ, pts = body_surface(3445, r), body_surface(30_000, r, noise=0.004)
+    elif layout == "uniform_box":
+        pts = r.uniform(templ.min(0), templ.max(0), (30_000, 3)).astype(np.float32)
+    elif layout == "line":
+        templ[:, 1:] = 0.25
+    templ = np.concatenate([templ, templ], 0)                      # 6 890 vertices, every one twice
+    templ[100:400, 1] = 0.125                                       # a flat patch
+    pts[:2000] = templ[r.integers(0, templ.shape[0], 2000)]          # queries exactly on vertices
+    pts[2000:2300] = r.uniform(-40, 40, (300, 3))                   # far away
+    pts[2300:2310] = np.array([np.inf, -np.inf, np.nan, 1e30, -1e30, 0, 0, 0, 0, 0], np.float32)[:, None]
+    n, m = pts.shape[0], templ.shape[0]
+    tp, tt = torch.from_numpy(pts.astype(np.float32)).to(device), torch.from_numpy(templ.astype(np.float32)).to(device)
+    out = {}
+    for name in ("scan", "grid"):
+        d = torch.empty(n, K, dtype=torch.float32, device=device)
+        i = torch.empty(n, K, dtype=torch.int64, device=device)
+        if name == "scan":
+            rc = lib.hgs_knn_points(n, tp.data_ptr(), m, tt.data_ptr(), K, d.data_ptr(), i.data_ptr(), None)
+        else:
+            nbytes = lib.hgs_knn_workspace(n, m)
+            assert nbytes > 0
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            rc = lib.hgs_knn_points_ws(n, tp.data_ptr(), m, tt.data_ptr(), K, d.data_ptr(), i.data_ptr(), ws.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out[name] = (d.cpu().numpy(), i.cpu().numpy())
+    ok = np.isfinite(pts).all(1)                                    # (non-finite queries: whatever the scan leaves, unspecified)
+    assert np.array_equal(out["scan"][1][ok], out["grid"][1][ok])
+    assert np.array_equal(out["scan"][0][ok].view(np.uint32), out["grid"][0][ok].view(np.uint32))
+    assert lib.hgs_knn_workspace(1000, 100) == 0

@@ -293,6 +293,23 @@ int32_t hgs_dist_cuda2(int32_t n, const float *points, float *mean_dist2, void *
 size_t hgs_dist_cuda2_workspace(int32_t n);
 int32_t hgs_dist_cuda2_ws(int32_t n, const float *points, float *mean_dist2, void *workspace, void *stream);
 
+/* Row f-5 -- the photometric loss that consumes the rendered image on every training step, fused: replaces l1_loss and ssim
+ * (/root/reference/hugs/losses/utils.py:54-58,65-108; called at hugs/losses/loss.py:88-107 and again for the human-only render
+ * at :128-137).  img1 (the render, differentiable) and img2 (the target) are [C,H,W]; the window is the reference's 11x11
+ * Gaussian (sigma 1.5, zero padding, one group per channel), C1 = 0.01^2, C2 = 0.03^2.
+ *   out[0] = mean of the SSIM map, out[1] = mean |img1 - img2|, out[2] = sum |img1 - img2| (l1_loss with a mask divides the
+ *   sum by mask.sum()).
+ * maps: [3,C,H,W] floats kept for the backward, or NULL for a forward-only evaluation.  workspace: hgs_ssim_l1_workspace(C,H,W)
+ * bytes, 8-byte aligned (per-workgroup partial sums; the totals are formed in a fixed order in double: bit-reproducible). */
+size_t hgs_ssim_l1_workspace(int32_t C, int32_t H, int32_t W);
+int32_t hgs_ssim_l1_forward(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *maps,
+                            void *workspace, float *out, void *stream);
+/* dL/dimg1 [C,H,W] = g_ssim_mean[0] * d(out[0])/dimg1 + g_l1_sum[0] * d(out[2])/dimg1; both factors are DEVICE scalars (the
+ * autograd gradients of the two outputs: no host round trip), either may be NULL (= 0).  maps: forward's, needed for the
+ * SSIM term. */
+int32_t hgs_ssim_l1_backward(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *maps,
+                             const float *g_ssim_mean, const float *g_l1_sum, float *dL_dimg1, void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

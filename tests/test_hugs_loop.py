@@ -5,7 +5,8 @@ needs a dataset this box does not have): everything the trainer does to the rast
     fixed-size human model, both optimised with Adam (scene.py:196-218);
   * every step: a random training camera, a random background and a random human background (gs_trainer.py:254-259), TWO
     renders through `render_human_scene(..., render_human_separate=True)` (gs_renderer.py:56-82) -- the joint one through
-    the two-segment form of the C ABI --, an L1 loss on both, one backward;
+    the two-segment form of the C ABI --, the reference's photometric loss on both (0.8 l1 + 0.2 (1 - ssim),
+    hugs/losses/loss.py:88-107,128-137, through the fused kernels of row f-5), one backward;
   * the fused densification statistics on the joint render's `viewspace_points.grad` with the scene's filter -- paired, as
     the reference does it, with the FIRST n rows of the gradient (gs_trainer.py:316-327, scene.py:460-462);
   * clone / split / prune every 50 steps with the reference's thresholds (scene.py:400-458: grad 0.0002, percent_dense
@@ -118,6 +119,12 @@ class GaussianSet:
             self.reset_stats()
 
 
+def photometric(pred, target):
+    """hugs/losses/loss.py:96,107 with the release weights (l_l1_w 0.8, l_ssim_w 0.2), both terms from the fused f-5 kernels."""
+    from hugs_amd.losses import l1_loss, ssim
+    return 0.8 * l1_loss(pred, target) + 0.2 * (1.0 - ssim(pred, target))
+
+
 def build_problem(device, seed=5):
     cam0 = syn.pinhole_camera(H, W)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
@@ -192,7 +199,7 @@ def test_hugs_shaped_loop(binding, device, monkeypatch, tmp_path):
         human.opt.zero_grad(set_to_none=True), scene.opt.zero_grad(set_to_none=True)
         pkg = render_human_scene(cam, human.activated(), scene.activated(), bg_color=bg, human_bg_color=hbg,
                                  render_mode="human_scene", render_human_separate=True)
-        loss = (pkg["render"] - tgt["render"]).abs().mean() + 0.5 * (pkg["human_img"] - tgt["human_img"]).abs().mean()
+        loss = photometric(pkg["render"], tgt["render"]) + 0.5 * photometric(pkg["human_img"], tgt["human_img"])
         loss.backward()
         assert torch.isfinite(loss) and pkg["viewspace_points"].grad is not None
         n_h, n_s = human.p["xyz"].shape[0], scene.p["xyz"].shape[0]

@@ -36,14 +36,29 @@ struct Plane {
     __device__ __forceinline__ size_t at(int c, int y, int x) const { return ((size_t)c * H + y) * W + x; }
 };
 
-// loads the tile + halo of one channel into LDS, zero outside the image
-template <typename F>
-__device__ __forceinline__ void load_tile(float (*dst)[SSIM_IW + 1], int x0, int y0, int H, int W, F&& src)
+// LDS tile: rows of SSIM_LW floats, image column x0 - SSIM_PAD + c at position c -- the halo (5) is padded to 8 so that a row
+// starts on a 16-byte boundary of the image row and is fetched as float4s (when W is a multiple of 4 and the plane is 16-byte
+// aligned; x0 is a multiple of 64)
+constexpr int SSIM_PAD = 8, SSIM_LW = SSIM_TW + 2 * SSIM_PAD, SSIM_OFF = SSIM_PAD - SSIM_R;  // 80 columns; the window starts at column 3
+typedef float TileRow[SSIM_LW + 1];
+
+// loads the tile + halo of one channel (`src`: the channel's H x W plane) into LDS, zero outside the image
+__device__ __forceinline__ void load_tile(TileRow* dst, int x0, int y0, int H, int W, const float* __restrict__ src)
 {
-    for (int idx = threadIdx.x; idx < SSIM_IH * SSIM_IW; idx += 256) {
-        const int r = idx / SSIM_IW, c = idx - r * SSIM_IW;
-        const int gy = y0 - SSIM_R + r, gx = x0 - SSIM_R + c;
-        dst[r][c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src(gy, gx) : 0.0f;
+    if ((W & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        for (int idx = threadIdx.x; idx < SSIM_IH * (SSIM_LW / 4); idx += 256) {
+            const int r = idx / (SSIM_LW / 4), c = (idx - r * (SSIM_LW / 4)) * 4;
+            const int gy = y0 - SSIM_R + r, gx = x0 - SSIM_PAD + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(src + (size_t)gy * W + gx);
+            dst[r][c] = v.x, dst[r][c + 1] = v.y, dst[r][c + 2] = v.z, dst[r][c + 3] = v.w;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < SSIM_IH * SSIM_IW; idx += 256) {
+            const int r = idx / SSIM_IW, c = idx - r * SSIM_IW;
+            const int gy = y0 - SSIM_R + r, gx = x0 - SSIM_R + c;
+            dst[r][c + SSIM_OFF] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+        }
     }
 }
 
@@ -52,29 +67,33 @@ __global__ void __launch_bounds__(256)
 ssim_l1_forward_kernel(Plane p, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ maps,
                        float2* __restrict__ partial)
 {
-    __shared__ float sx[SSIM_IH][SSIM_IW + 1], sy[SSIM_IH][SSIM_IW + 1];
+    __shared__ TileRow sx[SSIM_IH], sy[SSIM_IH];
     __shared__ float hq[5][SSIM_IH][SSIM_TW + 1];
     __shared__ float2 wsum[4];
     const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
     const float* a = img1 + (size_t)ch * p.H * p.W;
     const float* b = img2 + (size_t)ch * p.H * p.W;
-    load_tile(sx, x0, y0, p.H, p.W, [&](int gy, int gx) { return a[(size_t)gy * p.W + gx]; });
-    load_tile(sy, x0, y0, p.H, p.W, [&](int gy, int gx) { return b[(size_t)gy * p.W + gx]; });
+    load_tile(sx, x0, y0, p.H, p.W, a);
+    load_tile(sy, x0, y0, p.H, p.W, b);
     __syncthreads();
     // horizontal pass: a thread = one row, 8 adjacent columns (18 + 18 values in registers, 40 sums)
     if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
         const int row = tid / (SSIM_TW / SSIM_SEG), c0 = (tid - row * (SSIM_TW / SSIM_SEG)) * SSIM_SEG;
-        float x[SSIM_SEG + 2 * SSIM_R], y[SSIM_SEG + 2 * SSIM_R];
+        constexpr int NIN = SSIM_SEG + 2 * SSIM_R;
+        float x[NIN], y[NIN], xx[NIN], yy[NIN], xy[NIN];
 #pragma unroll
-        for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) x[j] = sx[row][c0 + j], y[j] = sy[row][c0 + j];
+        for (int j = 0; j < NIN; ++j) {
+            x[j] = sx[row][c0 + j + SSIM_OFF], y[j] = sy[row][c0 + j + SSIM_OFF];
+            xx[j] = x[j] * x[j], yy[j] = y[j] * y[j], xy[j] = x[j] * y[j];  // (once per input, not once per tap)
+        }
 #pragma unroll
         for (int o = 0; o < SSIM_SEG; ++o) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
-                const float w = ssim_w(k), xv = x[o + k], yv = y[o + k];
-                s0 = __builtin_fmaf(w, xv, s0), s1 = __builtin_fmaf(w, yv, s1);
-                s2 = __builtin_fmaf(w, xv * xv, s2), s3 = __builtin_fmaf(w, yv * yv, s3), s4 = __builtin_fmaf(w, xv * yv, s4);
+                const float w = ssim_w(k);
+                s0 = __builtin_fmaf(w, x[o + k], s0), s1 = __builtin_fmaf(w, y[o + k], s1);
+                s2 = __builtin_fmaf(w, xx[o + k], s2), s3 = __builtin_fmaf(w, yy[o + k], s3), s4 = __builtin_fmaf(w, xy[o + k], s4);
             }
             hq[0][row][c0 + o] = s0, hq[1][row][c0 + o] = s1, hq[2][row][c0 + o] = s2, hq[3][row][c0 + o] = s3, hq[4][row][c0 + o] = s4;
         }
@@ -108,9 +127,10 @@ ssim_l1_forward_kernel(Plane p, const float* __restrict__ img1, const float* __r
             const float A = 2.0f * mu12 + C1, B = 2.0f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
             const float map = (A * B) / (Cc * D);
             ssim_sum += map;
-            l1_sum += fabsf(sx[r0 + o + SSIM_R][col + SSIM_R] - sy[r0 + o + SSIM_R][col + SSIM_R]);
+            l1_sum += fabsf(sx[r0 + o + SSIM_R][col + SSIM_PAD] - sy[r0 + o + SSIM_R][col + SSIM_PAD]);
             if (WITH_MAPS) {
-                const float inv_cd = 1.0f / (Cc * D), inv_c = 1.0f / Cc, inv_d = 1.0f / D;
+                // (the map itself is the reference's expression, correctly rounded; its partials take the 1-ulp reciprocals)
+                const float inv_c = __builtin_amdgcn_rcpf(Cc), inv_d = __builtin_amdgcn_rcpf(D), inv_cd = inv_c * inv_d;
                 const size_t at = p.at(ch, gy, gx), plane = (size_t)p.C * p.H * p.W;
                 maps[at] = 2.0f * mu2 * (B - A) * inv_cd - 2.0f * mu1 * map * (inv_c - inv_d);
                 maps[plane + at] = -map * inv_d;
@@ -147,7 +167,7 @@ __global__ void __launch_bounds__(256)
 ssim_l1_backward_kernel(Plane p, const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ maps,
                         const float* __restrict__ g_ssim_mean, const float* __restrict__ g_l1_sum, float* __restrict__ dL_dimg1)
 {
-    __shared__ float sm[3][SSIM_IH][SSIM_IW + 1];
+    __shared__ TileRow sm[3][SSIM_IH];
     __shared__ float hq[3][SSIM_IH][SSIM_TW + 1];
     const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
     const size_t plane = (size_t)p.C * p.H * p.W;
@@ -155,8 +175,7 @@ ssim_l1_backward_kernel(Plane p, const float* __restrict__ img1, const float* __
     if (maps) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const float* m = maps + q * plane + (size_t)ch * p.H * p.W;
-            load_tile(sm[q], x0, y0, p.H, p.W, [&](int gy, int gx) { return m[(size_t)gy * p.W + gx]; });
+            load_tile(sm[q], x0, y0, p.H, p.W, maps + q * plane + (size_t)ch * p.H * p.W);
         }
         __syncthreads();
         if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
@@ -165,7 +184,7 @@ ssim_l1_backward_kernel(Plane p, const float* __restrict__ img1, const float* __
             for (int q = 0; q < 3; ++q) {
                 float v[SSIM_SEG + 2 * SSIM_R];
 #pragma unroll
-                for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) v[j] = sm[q][row][c0 + j];
+                for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) v[j] = sm[q][row][c0 + j + SSIM_OFF];
 #pragma unroll
                 for (int o = 0; o < SSIM_SEG; ++o) {
                     float s = 0.f;

@@ -67,52 +67,47 @@ __global__ void __launch_bounds__(256)
 ssim_l1_forward_kernel(Plane p, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ maps,
                        float2* __restrict__ partial)
 {
+    // the two image tiles stay in LDS; the five windowed moments go one at a time through ONE row-sum buffer (24 KB of LDS
+    // instead of 51, registers for one moment at a time: six workgroups per CU instead of three)
     __shared__ TileRow sx[SSIM_IH], sy[SSIM_IH];
-    __shared__ float hq[5][SSIM_IH][SSIM_TW + 1];
+    __shared__ float hq[SSIM_IH][SSIM_TW + 1];
     __shared__ float2 wsum[4];
     const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
-    const float* a = img1 + (size_t)ch * p.H * p.W;
-    const float* b = img2 + (size_t)ch * p.H * p.W;
-    load_tile(sx, x0, y0, p.H, p.W, a);
-    load_tile(sy, x0, y0, p.H, p.W, b);
-    __syncthreads();
-    // horizontal pass: a thread = one row, 8 adjacent columns (18 + 18 values in registers, 40 sums)
-    if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
-        const int row = tid / (SSIM_TW / SSIM_SEG), c0 = (tid - row * (SSIM_TW / SSIM_SEG)) * SSIM_SEG;
-        constexpr int NIN = SSIM_SEG + 2 * SSIM_R;
-        float x[NIN], y[NIN], xx[NIN], yy[NIN], xy[NIN];
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            x[j] = sx[row][c0 + j + SSIM_OFF], y[j] = sy[row][c0 + j + SSIM_OFF];
-            xx[j] = x[j] * x[j], yy[j] = y[j] * y[j], xy[j] = x[j] * y[j];  // (once per input, not once per tap)
-        }
-#pragma unroll
-        for (int o = 0; o < SSIM_SEG; ++o) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = ssim_w(k);
-                s0 = __builtin_fmaf(w, x[o + k], s0), s1 = __builtin_fmaf(w, y[o + k], s1);
-                s2 = __builtin_fmaf(w, xx[o + k], s2), s3 = __builtin_fmaf(w, yy[o + k], s3), s4 = __builtin_fmaf(w, xy[o + k], s4);
-            }
-            hq[0][row][c0 + o] = s0, hq[1][row][c0 + o] = s1, hq[2][row][c0 + o] = s2, hq[3][row][c0 + o] = s3, hq[4][row][c0 + o] = s4;
-        }
-    }
-    __syncthreads();
-    // vertical pass: a thread = one column, 4 adjacent rows
+    load_tile(sx, x0, y0, p.H, p.W, img1 + (size_t)ch * p.H * p.W);
+    load_tile(sy, x0, y0, p.H, p.W, img2 + (size_t)ch * p.H * p.W);
     const int col = tid & (SSIM_TW - 1), r0 = (tid / SSIM_TW) * 4;
     float acc[5][4];
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
+        __syncthreads();  // (the tiles are loaded / the previous moment's vertical pass is done with hq)
+        // horizontal pass: a thread = one row, 8 adjacent columns (18 inputs in registers)
+        if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
+            const int row = tid / (SSIM_TW / SSIM_SEG), c0 = (tid - row * (SSIM_TW / SSIM_SEG)) * SSIM_SEG;
+            float v[SSIM_SEG + 2 * SSIM_R];
+#pragma unroll
+            for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) {
+                const float xv = sx[row][c0 + j + SSIM_OFF], yv = sy[row][c0 + j + SSIM_OFF];
+                v[j] = q == 0 ? xv : q == 1 ? yv : q == 2 ? xv * xv : q == 3 ? yv * yv : xv * yv;
+            }
+#pragma unroll
+            for (int o = 0; o < SSIM_SEG; ++o) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) t = __builtin_fmaf(ssim_w(k), v[o + k], t);
+                hq[row][c0 + o] = t;
+            }
+        }
+        __syncthreads();
+        // vertical pass: a thread = one column, 4 adjacent rows
         float v[4 + 2 * SSIM_R];
 #pragma unroll
-        for (int j = 0; j < 4 + 2 * SSIM_R; ++j) v[j] = hq[q][r0 + j][col];
+        for (int j = 0; j < 4 + 2 * SSIM_R; ++j) v[j] = hq[r0 + j][col];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            float s = 0.f;
+            float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) s = __builtin_fmaf(ssim_w(k), v[o + k], s);
-            acc[q][o] = s;
+            for (int k = 0; k < 11; ++k) t = __builtin_fmaf(ssim_w(k), v[o + k], t);
+            acc[q][o] = t;
         }
     }
     const float C1 = 0.0001f, C2 = 0.0009f;
@@ -167,49 +162,43 @@ __global__ void __launch_bounds__(256)
 ssim_l1_backward_kernel(Plane p, const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ maps,
                         const float* __restrict__ g_ssim_mean, const float* __restrict__ g_l1_sum, float* __restrict__ dL_dimg1)
 {
-    __shared__ TileRow sm[3][SSIM_IH];
-    __shared__ float hq[3][SSIM_IH][SSIM_TW + 1];
+    // one quantity at a time through ONE tile and ONE row-sum buffer (15 KB of LDS instead of 46: eight workgroups per CU instead
+    // of three -- this kernel waits on memory, not on arithmetic)
+    __shared__ TileRow sm[SSIM_IH];
+    __shared__ float hq[SSIM_IH][SSIM_TW + 1];
     const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
     const size_t plane = (size_t)p.C * p.H * p.W;
     const float gs = g_ssim_mean ? g_ssim_mean[0] / (float)((double)p.C * p.H * p.W) : 0.0f, gl = g_l1_sum ? g_l1_sum[0] : 0.0f;
-    if (maps) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            load_tile(sm[q], x0, y0, p.H, p.W, maps + q * plane + (size_t)ch * p.H * p.W);
-        }
-        __syncthreads();
-        if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
-            const int row = tid / (SSIM_TW / SSIM_SEG), c0 = (tid - row * (SSIM_TW / SSIM_SEG)) * SSIM_SEG;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float v[SSIM_SEG + 2 * SSIM_R];
-#pragma unroll
-                for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) v[j] = sm[q][row][c0 + j + SSIM_OFF];
-#pragma unroll
-                for (int o = 0; o < SSIM_SEG; ++o) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) s = __builtin_fmaf(ssim_w(k), v[o + k], s);
-                    hq[q][row][c0 + o] = s;
-                }
-            }
-        }
-        __syncthreads();
-    }
     const int col = tid & (SSIM_TW - 1), r0 = (tid / SSIM_TW) * 4;
     float acc[3][4] = {};
     if (maps) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
+            load_tile(sm, x0, y0, p.H, p.W, maps + q * plane + (size_t)ch * p.H * p.W);
+            __syncthreads();  // (also: the previous quantity's vertical pass is done with hq)
+            if (tid < SSIM_IH * (SSIM_TW / SSIM_SEG)) {
+                const int row = tid / (SSIM_TW / SSIM_SEG), c0 = (tid - row * (SSIM_TW / SSIM_SEG)) * SSIM_SEG;
+                float v[SSIM_SEG + 2 * SSIM_R];
+#pragma unroll
+                for (int j = 0; j < SSIM_SEG + 2 * SSIM_R; ++j) v[j] = sm[row][c0 + j + SSIM_OFF];
+#pragma unroll
+                for (int o = 0; o < SSIM_SEG; ++o) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) t = __builtin_fmaf(ssim_w(k), v[o + k], t);
+                    hq[row][c0 + o] = t;
+                }
+            }
+            __syncthreads();  // (also: the horizontal pass is done with sm, the next quantity may overwrite it)
             float v[4 + 2 * SSIM_R];
 #pragma unroll
-            for (int j = 0; j < 4 + 2 * SSIM_R; ++j) v[j] = hq[q][r0 + j][col];
+            for (int j = 0; j < 4 + 2 * SSIM_R; ++j) v[j] = hq[r0 + j][col];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                float s = 0.f;
+                float t = 0.f;
 #pragma unroll
-                for (int k = 0; k < 11; ++k) s = __builtin_fmaf(ssim_w(k), v[o + k], s);
-                acc[q][o] = s;
+                for (int k = 0; k < 11; ++k) t = __builtin_fmaf(ssim_w(k), v[o + k], t);
+                acc[q][o] = t;
             }
         }
     }

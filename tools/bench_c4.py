@@ -58,6 +58,38 @@ def main(steps=100, warmup=15):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    extra = {}
+    if os.environ.get("HGS_C4_WITH_LOSS", "0") == "1":
+        # the same step with the reference's photometric loss on both renders as the source of dL/dimage
+        # (hugs/losses/loss.py:88-107,128-137: 0.8 l1 + 0.2 (1 - ssim)): fused row f-5 kernels, then the torch statements
+        from hugs_amd import losses
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, ROOT)
+        from test_losses import _torch_statements
+        gt1, gt2 = torch.rand(3, H, W, device=dev), torch.rand(3, H, W, device=dev)
+
+        def fused_loss(a, b):
+            return 0.8 * losses.l1_loss(a, b) + 0.2 * (1.0 - losses.ssim(a, b))
+
+        def torch_loss(a, b):
+            s_, l1_ = _torch_statements(a, b)
+            return 0.8 * l1_ + 0.2 * (1.0 - s_)
+
+        for name, fn, n in (("fused_loss", fused_loss, steps), ("torch_loss", torch_loss, max(steps // 5, 3))):
+            def step_l():
+                pkg = render_human_scene(data, human, scene, bg_color=bg, human_bg_color=hbg, render_mode="human_scene",
+                                         render_human_separate=True)
+                (fn(pkg["render"], gt1) + fn(pkg["human_img"], gt2)).backward()
+                for x in leaves:
+                    x.grad = None
+            for _ in range(3):
+                step_l()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step_l()
+            torch.cuda.synchronize()
+            extra[f"ms_per_training_step_raster_and_{name}"] = round((time.perf_counter() - t0) / n * 1e3, 4)
     from diff_gaussian_rasterization import profile_enable, profile_read
     profile_enable()
     for _ in range(5):
@@ -68,7 +100,7 @@ def main(steps=100, warmup=15):
     print(json.dumps({"stages_ms_both_renders": stages, "workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
                       "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
                       "joint_render": "torch.cat (reference form)" if os.environ.get("HGS_JOINT_CONCAT", "0") == "1" else "second segment (no concatenation)",
-                      "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1)}))
+                      "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1), **extra}))
 
 
 if __name__ == "__main__":

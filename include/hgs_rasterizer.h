@@ -310,6 +310,19 @@ int32_t hgs_ssim_l1_forward(int32_t C, int32_t H, int32_t W, const float *img1, 
 int32_t hgs_ssim_l1_backward(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *maps,
                              const float *g_ssim_mean, const float *g_l1_sum, float *dL_dimg1, void *stream);
 
+/* Row f-6 -- the statements that produce the rasterizer's inputs on every training step, fused: replaces SceneGS.forward
+ * (/root/reference/hugs/models/scene.py:147-160): scales = exp(scaling) [P,3], rotq = normalize(rotation) [P,4] (x / max(|x|,
+ * 1e-12), NOT unit-length input), opacities = sigmoid(opacity) [P,1], shs = cat(features_dc [P,1,3], features_rest [P,M-1,3])
+ * -> [P,M,3].  rotation / rotq must be 16-byte aligned. */
+int32_t hgs_scene_forward(int32_t P, int32_t M, const float *scaling, const float *rotation, const float *opacity,
+                          const float *features_dc, const float *features_rest, float *scales, float *rotq,
+                          float *opacities, float *shs, void *stream);
+/* Its backward.  Any of the four incoming gradients may be NULL (= zero: the matching outputs are then not written). */
+int32_t hgs_scene_backward(int32_t P, int32_t M, const float *rotation, const float *scales, const float *opacities,
+                           const float *dL_dscales, const float *dL_drotq, const float *dL_dopacities, const float *dL_dshs,
+                           float *dL_dscaling, float *dL_drotation, float *dL_dopacity, float *dL_dfeatures_dc,
+                           float *dL_dfeatures_rest, void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

@@ -323,6 +323,17 @@ int32_t hgs_scene_backward(int32_t P, int32_t M, const float *rotation, const fl
                            float *dL_dscaling, float *dL_drotation, float *dL_dopacity, float *dL_dfeatures_dc,
                            float *dL_dfeatures_rest, void *stream);
 
+/* Row f-7 -- the rotation conversions on the human model's forward path that produce the rasterizer's `rotations` argument
+ * (/root/reference/hugs/models/hugs_trimlp.py:418-419,518), one thread per rotation, no host synchronisation:
+ *   hgs_rotation_6d_to_matrix: d6 [n,6] -> matrix [n,9] (rows b1, b2, b3), /root/reference/hugs/utils/rotations.py:552-573
+ *   hgs_matrix_to_quaternion:  matrix [n,9] row-major -> quat [n,4] (w,x,y,z), rotations.py:94-156 -- the candidate with the
+ *     largest denominator, floor 0.1, exactly as stated there; quat / dL_dquat must be 16-byte aligned.
+ * The backward forms take the forward's INPUT (everything is recomputed from it) and the gradient of its output. */
+int32_t hgs_rotation_6d_to_matrix(int32_t n, const float *d6, float *matrix, void *stream);
+int32_t hgs_rotation_6d_to_matrix_backward(int32_t n, const float *d6, const float *dL_dmatrix, float *dL_dd6, void *stream);
+int32_t hgs_matrix_to_quaternion(int32_t n, const float *matrix, float *quat, void *stream);
+int32_t hgs_matrix_to_quaternion_backward(int32_t n, const float *matrix, const float *dL_dquat, float *dL_dmatrix, void *stream);
+
 /* Message for the last negative return value on the calling thread. */
 const char *hgs_last_error(void);
 

@@ -16,6 +16,16 @@ HGS_CONCURRENT_RENDERS=0 bash profiles/collect_workload.sh ${TAG}_c4_serial tool
 OUT=$ROOT/gpurun_out/$TAG
 python3 tools/sweep.py > "$OUT/${TAG}_sweep.json" 2> "$OUT/sweep.err"
 python3 tools/bench_fwd.py > "$OUT/${TAG}_fwd.jsonl" 2> "$OUT/fwd.err"
+# the widening rows measured this round: K nearest neighbours through the grid (f-2), photometric loss (f-5), C4 with the loss
+(python3 tools/bench_knn.py --shape body; python3 tools/bench_knn.py --shape body --no-grid; python3 tools/bench_knn.py --shape blob) > "$OUT/${TAG}_knn.jsonl" 2> "$OUT/knn.err"
+python3 tools/bench_loss.py > "$OUT/${TAG}_loss.json" 2> "$OUT/loss.err"
+HGS_C4_WITH_LOSS=1 python3 tools/bench_c4.py > "$OUT/${TAG}_c4_with_loss.json" 2> "$OUT/c4l.err"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+for w in knn loss; do
+    rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" -o $w -- python3 tools/bench_$w.py > /dev/null 2> "$OUT/trace_$w.err"
+    python3 profiles/summarize_rocprof.py "$OUT/trace_$w/${w}_results.db" > "$OUT/${TAG}_${w}_kernel_stats.txt"
+done
+rm -rf "$OUT"/trace_knn "$OUT"/trace_loss
 SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
 python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1
 rm -rf "$ROOT"/gpurun_out/${TAG}*/trace "$ROOT"/gpurun_out/${TAG}*/pmc_*

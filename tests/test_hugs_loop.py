@@ -56,9 +56,14 @@ class GaussianSet:
         self.grad_accum, self.denom = torch.zeros(n, 1, device=dev), torch.zeros(n, 1, device=dev)
         self.max_radii2D = torch.zeros(n, device=dev)
 
+    fused_forward = False   # the scene model goes through the fused SceneGS.forward of row f-6, the human through the torch statements
+
     def activated(self):
-        out = gio.activated({**self.p, "active_sh_degree": self.degree})
-        return out
+        if self.fused_forward:
+            from hugs_amd.scene_forward import scene_forward
+            p = self.p
+            return scene_forward(p["xyz"], p["scaling"], p["rotation"], p["opacity"], p["features_dc"], p["features_rest"], self.degree)
+        return gio.activated({**self.p, "active_sh_degree": self.degree})
 
     def _rebuild(self, rows_of):
         """rows_of(name, tensor, is_moment) -> the tensor's new rows; applied to the parameters and to Adam's moments alike"""
@@ -178,6 +183,7 @@ def test_hugs_shaped_loop(binding, device, monkeypatch, tmp_path):
     torch.manual_seed(0)
     cams, human_truth, scene_truth = build_problem(device)
     human, scene = initial_models(human_truth, scene_truth, device)
+    scene.fused_forward = True
     val_bg = torch.tensor([0.2, 0.5, 0.8], device=device)
 
     def validate():
@@ -232,7 +238,9 @@ dev = torch.device({str(device)!r})
 cam = np.load({str(tmp_path / 'cam.npy')!r}, allow_pickle=True).item()
 cam = {{k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}}
 h = gio.activated(gio.read_gaussian_ply({str(tmp_path / 'human.ply')!r}, device=dev)); h["active_sh_degree"] = {human.degree}
-s = gio.activated(gio.read_gaussian_ply({str(tmp_path / 'scene.ply')!r}, device=dev)); s["active_sh_degree"] = 0
+from hugs_amd.scene_forward import scene_forward          # the scene's activations: the fused kernel, as in the loop
+p = gio.read_gaussian_ply({str(tmp_path / 'scene.ply')!r}, device=dev)
+s = scene_forward(p["xyz"], p["scaling"], p["rotation"], p["opacity"], p["features_dc"], p["features_rest"], 0)
 with torch.no_grad():
     img = render_human_scene(cam, h, s, bg_color=torch.tensor([0.2, 0.5, 0.8], device=dev), render_mode="human_scene")["render"]
 np.save({str(tmp_path / 'img.npy')!r}, img.cpu().numpy())

@@ -528,7 +528,7 @@ __device__ __forceinline__ bool search(int n, const float* __restrict__ points, 
     int q = blockIdx.x * 64 + lane, count = n;
     if (tg.params) {
         count = (int)*(const volatile uint32_t*)tg.open_count;
-        if (blockIdx.x * 64 >= count) return false;  // (uniform)
+        if ((int)(blockIdx.x * 64) >= count) return false;  // (uniform)
         i = (int)tg.open_list[min(q, count - 1)];
     } else {
         i = min(q, n - 1);  // every lane scans (wave-uniform loads); only valid lanes store

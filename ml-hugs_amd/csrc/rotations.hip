@@ -125,9 +125,9 @@ __global__ void __launch_bounds__(256) rotation_6d_to_matrix_kernel(int n, const
     o[0] = b1.x, o[1] = b1.y, o[2] = b1.z, o[3] = b2.x, o[4] = b2.y, o[5] = b2.z, o[6] = b3.x, o[7] = b3.y, o[8] = b3.z;
 }
 
-__device__ __forceinline__ V3 normalize_backward(V3 x, V3 y, float norm, V3 g)
+__device__ __forceinline__ V3 normalize_backward(V3 y, float norm, V3 g)
 {
-    // y = x / max(|x|, eps): (g - y (y.g)) / |x| above eps, g / eps below (the clamp is then a constant)
+    // y = x / max(|x|, eps), norm = |x|: (g - y (y.g)) / |x| above eps, g / eps below (the clamp is then a constant)
     return norm > 1e-12f ? (1.0f / norm) * (g - dot(y, g) * y) : 1e12f * g;
 }
 
@@ -148,12 +148,12 @@ rotation_6d_to_matrix_backward_kernel(int n, const float* __restrict__ d6, const
     // b3 = b1 x b2
     V3 gb1 = g1 + cross(b2, g3);
     const V3 gb2 = g2 + cross(g3, b1);
-    const V3 gu = normalize_backward(u, b2, nu, gb2);
+    const V3 gu = normalize_backward(b2, nu, gb2);
     // u = a2 - (b1.a2) b1
     const float gub1 = dot(gu, b1);
     const V3 ga2 = gu - gub1 * b1;
     gb1 = gb1 - s * gu - gub1 * a2;
-    const V3 ga1 = normalize_backward(a1, b1, n1, gb1);
+    const V3 ga1 = normalize_backward(b1, n1, gb1);
     float* o = dL_dd6 + 6 * (size_t)i;
     o[0] = ga1.x, o[1] = ga1.y, o[2] = ga1.z, o[3] = ga2.x, o[4] = ga2.y, o[5] = ga2.z;
 }

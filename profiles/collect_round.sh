@@ -26,6 +26,7 @@ for w in knn loss; do
     python3 profiles/summarize_rocprof.py "$OUT/trace_$w/${w}_results.db" > "$OUT/${TAG}_${w}_kernel_stats.txt"
 done
 rm -rf "$OUT"/trace_knn "$OUT"/trace_loss
+python3 tools/fuzz_rows.py --seconds 45 > "$OUT/${TAG}_fuzz_rows.txt" 2>&1
 SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
 python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1
 rm -rf "$ROOT"/gpurun_out/${TAG}*/trace "$ROOT"/gpurun_out/${TAG}*/pmc_*

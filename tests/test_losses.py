@@ -117,7 +117,7 @@ def test_hip_against_the_oracle_at_tile_edges_and_batches(shape, device):
 
 def _torch_statements(x, y):
     """The same two quantities from plain torch ops (depthwise conv2d with the 11x11 window): the fp32 reference of the op."""
-    w1 = torch.from_numpy(lo.window_1d()).to(x.device)
+    w1 = torch.from_numpy(lo.window_1d()).to(device=x.device, dtype=x.dtype)
     win = (w1[:, None] * w1[None, :]).expand(x.shape[0], 1, 11, 11).contiguous()
     conv = lambda t: torch.nn.functional.conv2d(t[None], win, padding=5, groups=x.shape[0])[0]
     mu1, mu2 = conv(x), conv(y)

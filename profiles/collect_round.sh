@@ -20,6 +20,8 @@ python3 tools/bench_fwd.py > "$OUT/${TAG}_fwd.jsonl" 2> "$OUT/fwd.err"
 (python3 tools/bench_knn.py --shape body; python3 tools/bench_knn.py --shape body --no-grid; python3 tools/bench_knn.py --shape blob) > "$OUT/${TAG}_knn.jsonl" 2> "$OUT/knn.err"
 python3 tools/bench_loss.py > "$OUT/${TAG}_loss.json" 2> "$OUT/loss.err"
 HGS_C4_WITH_LOSS=1 python3 tools/bench_c4.py > "$OUT/${TAG}_c4_with_loss.json" 2> "$OUT/c4l.err"
+python3 tools/bench_step.py > "$OUT/${TAG}_step.json" 2> "$OUT/step.err"
+python3 tools/bench_rotations.py > "$OUT/${TAG}_rotations.txt" 2> "$OUT/rot.err"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 for w in knn loss; do
     rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" -o $w -- python3 tools/bench_$w.py > /dev/null 2> "$OUT/trace_$w.err"

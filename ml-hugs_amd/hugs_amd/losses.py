@@ -11,6 +11,7 @@ reference's call sites and asking for one raises.  `l1_ssim(pred, gt)` returns b
 one's result).  No CPU fallback: the HIP library does the work or the call raises.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -90,17 +91,22 @@ def _prep(pred, gt):
 
 
 # ssim(a, b) followed by l1_loss(a, b) on the same tensors (loss.py:88-99) is one pass: the pair's result is kept while
-# both tensors are alive and unchanged
+# both tensors are alive and unchanged (same objects, same version counters, same storage) and until its backward has run.
+# HGS_LOSS_SHARE_PASS=0 turns the sharing off (every call computes afresh) -- for callers whose custom kernels rewrite a
+# tensor's memory behind autograd's back, which no version counter records.
 _LAST = {}
+_SHARE = os.environ.get("HGS_LOSS_SHARE_PASS", "1") != "0"
 
 
 def _terms(pred, gt):
     """(ssim mean, l1 mean, l1 sum) of one [C,H,W] pair, computed once per (pred, gt) pair and version."""
     key = (id(pred), id(gt), pred._version, gt._version, pred.data_ptr(), gt.data_ptr(), pred.requires_grad and torch.is_grad_enabled())
     hit = _LAST.get("entry")
-    if hit is not None and hit[0] == key and hit[1]() is pred and hit[2]() is gt:
+    if _SHARE and hit is not None and hit[0] == key and hit[1]() is pred and hit[2]() is gt:
         return hit[3]
     out = _SsimL1.apply(pred, gt)
+    if not _SHARE:
+        return out
     try:
         _LAST["entry"] = (key, weakref.ref(pred), weakref.ref(gt), out)
     except TypeError:

@@ -70,6 +70,7 @@ def fused_rows():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=int(os.environ.get("HGS_BENCH_STEPS", 30)))
+    ap.add_argument("--only", choices=("fused", "torch"), default=None, help="time one of the two variants only")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H, W, Ph, Ps, J, Mv = 1080, 1920, 110_210, 200_000, 24, 6890
@@ -121,7 +122,11 @@ def main():
         return loss.detach()
 
     out = {"workload": f"HUGS-shaped step between the networks and the optimizer: {Ph} human + {Ps} scene Gaussians, {W}x{H}, two renders"}
-    for name, rows, n in (("fused_rows", fused_rows(), a.steps), ("torch_statements_where_they_exist", torch_rows(), max(a.steps // 5, 3))):
+    variants = (("fused_rows", fused_rows, a.steps, "fused"), ("torch_statements_where_they_exist", torch_rows, max(a.steps // 5, 3), "torch"))
+    for name, make_rows, n, key in variants:
+        if a.only not in (None, key):
+            continue
+        rows = make_rows()
         for _ in range(3):
             step(rows)
         torch.cuda.synchronize()

@@ -42,6 +42,19 @@ struct Plane {
 constexpr int SSIM_PAD = 8, SSIM_LW = SSIM_TW + 2 * SSIM_PAD, SSIM_OFF = SSIM_PAD - SSIM_R;  // 80 columns; the window starts at column 3
 typedef float TileRow[SSIM_LW + 1];
 
+// Workgroup -> tile.  Consecutive workgroups are dealt round-robin to the 8 XCDs, each with its own L2; a tile shares 5-pixel halos
+// with its neighbours, so every XCD gets a contiguous BAND of the (channel, row, column) tile order instead of every 8th tile:
+// workgroup b works on tile (b % 8) * ceil(T / 8) + b / 8 (the grid is 8 * ceil(T / 8) workgroups; the surplus leaves at once).
+// 1080p: forward 57.7 -> 53.5 us, backward 49.1 -> 37.4 us.
+struct TileId { int ch, x0, y0, linear; bool valid; };
+__device__ __forceinline__ TileId tile_of_workgroup(int tiles_x, int tiles_y, int C)
+{
+    const int T = tiles_x * tiles_y * C, per = (T + 7) / 8;
+    const int t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    const int ch = t / (tiles_x * tiles_y), r = t - ch * (tiles_x * tiles_y), ty = r / tiles_x;
+    return {ch, (r - ty * tiles_x) * SSIM_TW, ty * SSIM_TH, t, t < T && (int)(blockIdx.x >> 3) < per};
+}
+
 // loads the tile + halo of one channel (`src`: the channel's H x W plane) into LDS, zero outside the image
 __device__ __forceinline__ void load_tile(TileRow* dst, int x0, int y0, int H, int W, const float* __restrict__ src)
 {
@@ -72,7 +85,9 @@ ssim_l1_forward_kernel(Plane p, const float* __restrict__ img1, const float* __r
     __shared__ TileRow sx[SSIM_IH], sy[SSIM_IH];
     __shared__ float hq[SSIM_IH][SSIM_TW + 1];
     __shared__ float2 wsum[4];
-    const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
+    const TileId tile = tile_of_workgroup((p.W + SSIM_TW - 1) / SSIM_TW, (p.H + SSIM_TH - 1) / SSIM_TH, p.C);
+    if (!tile.valid) return;  // (uniform)
+    const int ch = tile.ch, x0 = tile.x0, y0 = tile.y0, tid = threadIdx.x;
     load_tile(sx, x0, y0, p.H, p.W, img1 + (size_t)ch * p.H * p.W);
     load_tile(sy, x0, y0, p.H, p.W, img2 + (size_t)ch * p.H * p.W);
     const int col = tid & (SSIM_TW - 1), r0 = (tid / SSIM_TW) * 4;
@@ -139,7 +154,7 @@ ssim_l1_forward_kernel(Plane p, const float* __restrict__ img1, const float* __r
     __syncthreads();
     if (tid == 0) {
         const float2 s = make_float2((wsum[0].x + wsum[1].x) + (wsum[2].x + wsum[3].x), (wsum[0].y + wsum[1].y) + (wsum[2].y + wsum[3].y));
-        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+        partial[tile.linear] = s;
     }
 }
 
@@ -166,7 +181,9 @@ ssim_l1_backward_kernel(Plane p, const float* __restrict__ img1, const float* __
     // of three -- this kernel waits on memory, not on arithmetic)
     __shared__ TileRow sm[SSIM_IH];
     __shared__ float hq[SSIM_IH][SSIM_TW + 1];
-    const int ch = blockIdx.z, x0 = blockIdx.x * SSIM_TW, y0 = blockIdx.y * SSIM_TH, tid = threadIdx.x;
+    const TileId tile = tile_of_workgroup((p.W + SSIM_TW - 1) / SSIM_TW, (p.H + SSIM_TH - 1) / SSIM_TH, p.C);
+    if (!tile.valid) return;  // (uniform)
+    const int ch = tile.ch, x0 = tile.x0, y0 = tile.y0, tid = threadIdx.x;
     const size_t plane = (size_t)p.C * p.H * p.W;
     const float gs = g_ssim_mean ? g_ssim_mean[0] / (float)((double)p.C * p.H * p.W) : 0.0f, gl = g_l1_sum ? g_l1_sum[0] : 0.0f;
     const int col = tid & (SSIM_TW - 1), r0 = (tid / SSIM_TW) * 4;
@@ -221,15 +238,16 @@ int fail_loss(const char* what)
     return HGS_ERR_INVALID_ARGUMENT;
 }
 
-dim3 loss_grid(int C, int H, int W) { return dim3((W + SSIM_TW - 1) / SSIM_TW, (H + SSIM_TH - 1) / SSIM_TH, C); }
+// number of tiles, and the 1-D grid that covers them in XCD bands (tile_of_workgroup)
+int64_t loss_tiles(int C, int H, int W) { return (int64_t)((W + SSIM_TW - 1) / SSIM_TW) * ((H + SSIM_TH - 1) / SSIM_TH) * C; }
+dim3 loss_grid(int64_t tiles) { return dim3((unsigned)(((tiles + 7) / 8) * 8)); }
 
 }  // namespace
 
 extern "C" size_t hgs_ssim_l1_workspace(int32_t C, int32_t H, int32_t W)
 {
     if (C < 1 || H < 1 || W < 1) return 0;
-    const dim3 g = loss_grid(C, H, W);
-    return sizeof(float2) * (size_t)g.x * g.y * g.z;
+    return sizeof(float2) * (size_t)loss_tiles(C, H, W);
 }
 
 extern "C" int32_t hgs_ssim_l1_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, float* maps,
@@ -238,13 +256,14 @@ extern "C" int32_t hgs_ssim_l1_forward(int32_t C, int32_t H, int32_t W, const fl
     if (C < 1 || H < 1 || W < 1 || C > 65535) return fail_loss("ssim_l1_forward: need 1 <= C <= 65535, H >= 1, W >= 1");
     if (!img1 || !img2 || !workspace || !out) return fail_loss("ssim_l1_forward: null pointer");
     if (((uintptr_t)workspace & 7) != 0) return fail_loss("ssim_l1_forward: the workspace must be 8-byte aligned");
-    const dim3 g = loss_grid(C, H, W);
-    if (g.y > 65535) return fail_loss("ssim_l1_forward: image too tall");
+    const int64_t tiles = loss_tiles(C, H, W);
+    if (tiles > (1ll << 30)) return fail_loss("ssim_l1_forward: image too large");
+    const dim3 g = loss_grid(tiles);
     const Plane p{C, H, W};
     hipStream_t st = (hipStream_t)stream;
     if (maps) hipLaunchKernelGGL(ssim_l1_forward_kernel<true>, g, dim3(256), 0, st, p, img1, img2, maps, (float2*)workspace);
     else hipLaunchKernelGGL(ssim_l1_forward_kernel<false>, g, dim3(256), 0, st, p, img1, img2, maps, (float2*)workspace);
-    hipLaunchKernelGGL(ssim_l1_reduce_kernel, dim3(1), dim3(256), 0, st, (int)(g.x * g.y * g.z), (const float2*)workspace,
+    hipLaunchKernelGGL(ssim_l1_reduce_kernel, dim3(1), dim3(256), 0, st, (int)tiles, (const float2*)workspace,
                        (double)C * H * W, out);
     if (hipGetLastError() != hipSuccess) {
         hgs::set_last_error("ssim_l1_forward: kernel launch failed");
@@ -259,8 +278,9 @@ extern "C" int32_t hgs_ssim_l1_backward(int32_t C, int32_t H, int32_t W, const f
     if (C < 1 || H < 1 || W < 1 || C > 65535) return fail_loss("ssim_l1_backward: need 1 <= C <= 65535, H >= 1, W >= 1");
     if (!img1 || !img2 || !dL_dimg1) return fail_loss("ssim_l1_backward: null pointer");
     if (g_ssim_mean && !maps) return fail_loss("ssim_l1_backward: a gradient of the SSIM term needs forward's maps");
-    const dim3 g = loss_grid(C, H, W);
-    if (g.y > 65535) return fail_loss("ssim_l1_backward: image too tall");
+    const int64_t tiles = loss_tiles(C, H, W);
+    if (tiles > (1ll << 30)) return fail_loss("ssim_l1_backward: image too large");
+    const dim3 g = loss_grid(tiles);
     hipLaunchKernelGGL(ssim_l1_backward_kernel, g, dim3(256), 0, (hipStream_t)stream, Plane{C, H, W}, img1, img2,
                        g_ssim_mean ? maps : nullptr, g_ssim_mean, g_l1_sum, dL_dimg1);
     if (hipGetLastError() != hipSuccess) {

@@ -22,12 +22,7 @@ python3 tools/bench_loss.py > "$OUT/${TAG}_loss.json" 2> "$OUT/loss.err"
 HGS_C4_WITH_LOSS=1 python3 tools/bench_c4.py > "$OUT/${TAG}_c4_with_loss.json" 2> "$OUT/c4l.err"
 python3 tools/bench_step.py > "$OUT/${TAG}_step.json" 2> "$OUT/step.err"
 python3 tools/bench_rotations.py > "$OUT/${TAG}_rotations.txt" 2> "$OUT/rot.err"
-cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-for w in knn loss; do
-    rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" -o $w -- python3 tools/bench_$w.py > /dev/null 2> "$OUT/trace_$w.err"
-    python3 profiles/summarize_rocprof.py "$OUT/trace_$w/${w}_results.db" > "$OUT/${TAG}_${w}_kernel_stats.txt"
-done
-rm -rf "$OUT"/trace_knn "$OUT"/trace_loss
+bash profiles/collect_rows.sh $TAG > /dev/null 2>&1; cp "$ROOT"/gpurun_out/${TAG}_rows/${TAG}_*_pmc.txt "$ROOT"/gpurun_out/${TAG}_rows/${TAG}_*_kernel_stats.txt "$OUT"/ 2>/dev/null
 python3 tools/fuzz_rows.py --seconds 45 > "$OUT/${TAG}_fuzz_rows.txt" 2>&1
 SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
 python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1

@@ -8,7 +8,7 @@ import pandas as pd
 
 def main(path, *subs):
     c = pd.read_csv(path)
-    c["k"] = c["Kernel_Name"].str.extract(r"(?:void )?(?:hgs::)?(\w+)")
+    c["k"] = c["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.extract(r"(?:void )?(?:hgs::)?(\w+)")
     if subs:
         c = c[c.k.apply(lambda s: any(x in str(s) for x in subs))]
     g = c.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()

@@ -19,7 +19,7 @@ from build_id import csrc_sha16
 def per_kernel(path, counter):
     c = pd.read_csv(path)
     c = c[c["Counter_Name"] == counter]
-    c["k"] = c["Kernel_Name"].str.extract(r"(?:void )?(?:hgs::)?(\w+)")
+    c["k"] = c["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.extract(r"(?:void )?(?:hgs::)?(\w+)")
     per_dispatch = c.groupby(["k", "Dispatch_Id"])["Counter_Value"].sum()   # summed over XCDs / instances
     return per_dispatch.groupby("k").mean()
 

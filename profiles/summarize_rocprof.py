@@ -13,7 +13,7 @@ def main(path):
     print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
     print(f"# {'calls':>7} {'total_us':>12} {'avg_us':>10} {'pct':>6}  kernel")
     for name, calls, total, avg, pct in rows:
-        short = name.split("(")[0]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0]   # (kernels of the widening rows live in anonymous namespaces)
         if len(short) > 90:
             short = short[:87] + "..."
         print(f"  {calls:7d} {total:12.1f} {avg:10.3f} {pct:6.2f}  {short}")

@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=110_000)
     ap.add_argument("--verts", type=int, default=6890)
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=int(os.environ.get("HGS_BENCH_STEPS", 20)))
     ap.add_argument("--cpu-points", type=int, default=2000)
     ap.add_argument("--shape", choices=("body", "blob"), default="body",
                     help="body: a surface of human size (the reference's case); blob: a 3-D normal cloud with sparse tails")

@@ -21,6 +21,12 @@
  * polls (no copy, no event): forward waits for it before enqueueing the rest of the frame, or, when the caller passes
  * binning_capacity_hint, after it (the wait then overlaps the GPU's work).
  * All floating point is fp32, contiguous.
+ *
+ * Below the three rasterizer entry points (and their helpers) the header declares the rows either side of the rasterizer
+ * that the same library carries, each replacing a named function of the reference: densification statistics (f-1), K nearest
+ * template vertices / SMPL LBS blends (f-2), learned-LBS skinning (f-2), distCUDA2 (f-4), the photometric loss l1 + SSIM
+ * (f-5), SceneGS.forward (f-6), rotation_6d_to_matrix / matrix_to_quaternion (f-7).  Same conventions: device pointers,
+ * sizes, a stream, a negative HGS_ERR_* on failure with hgs_last_error() for the text.
  */
 #ifndef HGS_RASTERIZER_H
 #define HGS_RASTERIZER_H

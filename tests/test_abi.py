@@ -109,3 +109,40 @@ def test_product_path_has_no_cpu_fallback_and_never_touches_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower().replace("the oracle", "").replace("cpu oracle", "") or \
                     not re.search(r"^\s*(from|import)\s+oracle|hgs_oracle|#include.*oracle", txt, re.M), os.path.join(dirpath, f)
+
+
+def test_widening_rows_have_no_cpu_fallback_either():
+    """l1_loss / ssim, SceneGS.forward and the rotation conversions (rows f-5..f-7): CPU tensors raise, nothing is computed."""
+    import torch
+    from hugs_amd import losses, rotations, scene_forward
+    a = torch.rand(3, 12, 12)
+    for call in (lambda: losses.ssim(a, a.clone()), lambda: losses.l1_loss(a, a.clone()), lambda: losses.l1_ssim(a, a.clone()),
+                 lambda: rotations.matrix_to_quaternion(torch.eye(3)[None]), lambda: rotations.rotation_6d_to_matrix(torch.rand(4, 6)),
+                 lambda: scene_forward.scene_activations(torch.zeros(2, 3), torch.ones(2, 4), torch.zeros(2, 1), torch.zeros(2, 1, 3),
+                                                         torch.zeros(2, 15, 3))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+
+
+def test_widening_rows_reject_bad_arguments_through_the_c_abi():
+    """The entry points' own checks (they return before any launch): sizes, null pointers, alignment."""
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._load()
+    lib.hgs_last_error.restype = C.c_char_p
+    lib.hgs_ssim_l1_workspace.restype = C.c_size_t
+    lib.hgs_ssim_l1_workspace.argtypes = [C.c_int32] * 3
+    assert lib.hgs_ssim_l1_workspace(3, 1080, 1920) == 8 * 3 * 30 * 68 and lib.hgs_ssim_l1_workspace(0, 4, 4) == 0
+    lib.hgs_ssim_l1_forward.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 6
+    assert lib.hgs_ssim_l1_forward(3, 0, 8, None, None, None, None, None, None) == -1 and b"ssim_l1_forward" in lib.hgs_last_error()
+    assert lib.hgs_ssim_l1_forward(3, 8, 8, None, None, None, None, None, None) == -1 and b"null pointer" in lib.hgs_last_error()
+    lib.hgs_ssim_l1_backward.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 7
+    assert lib.hgs_ssim_l1_backward(3, 8, 8, 16, 16, None, 16, None, 16, None) == -1 and b"needs forward's maps" in lib.hgs_last_error()
+    lib.hgs_scene_forward.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 10
+    assert lib.hgs_scene_forward(4, 0, *([None] * 10)) == -1 and lib.hgs_scene_forward(0, 16, *([None] * 10)) == 0
+    assert lib.hgs_scene_forward(4, 16, 16, 20, 16, 16, 16, 16, 16, 16, 16, None) == -1 and b"16-byte aligned" in lib.hgs_last_error()
+    lib.hgs_matrix_to_quaternion.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.hgs_matrix_to_quaternion(-1, None, None, None) == -1 and lib.hgs_matrix_to_quaternion(0, None, None, None) == 0
+    assert lib.hgs_matrix_to_quaternion(5, 16, 20, None) == -1
+    lib.hgs_knn_workspace.restype = C.c_size_t
+    lib.hgs_knn_workspace.argtypes = [C.c_int32, C.c_int32]
+    assert lib.hgs_knn_workspace(110_210, 6890) > 0 and lib.hgs_knn_workspace(1000, 6890) == 0 and lib.hgs_knn_workspace(10_000, 100) == 0

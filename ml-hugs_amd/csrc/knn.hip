@@ -104,6 +104,16 @@ __device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, f
     cz = min(max((int)((z - g.minz) * g.inv_cell), 0), g.gz - 1);
 }
 
+// A bounding box with an infinite (or NaN) corner -- a cloud with a non-finite coordinate -- has no cell size: the grid then is
+// ONE cell (every point clamps into it), which the searches treat like any other degenerate grid: everything is scanned.
+__device__ __forceinline__ void grid_box_guard(float* mn, float* ext)
+{
+    bool finite = true;
+    for (int k = 0; k < 3; ++k) finite = finite && fabsf(mn[k]) < 3.0e38f && ext[k] < 3.0e38f;  // (false for NaN too)
+    if (!finite)
+        for (int k = 0; k < 3; ++k) mn[k] = 0.0f, ext[k] = 0.0f;
+}
+
 // ---- K nearest template vertices through a uniform grid over the TEMPLATE ------------------------------------------------
 // The brute-force scan below computes n x m distances (110 210 Gaussians x 6 890 SMPL vertices: 0.42 ms per call, and HUGS
 // calls it twice per training step, hugs_trimlp.py:318,480).  With a workspace the template is counting-sorted into a grid
@@ -161,9 +171,10 @@ template_grid_build_kernel(int m, const float* __restrict__ templ, GridParams* _
     }
     __syncthreads();
     if (tid == 0) {
-        const float mn[3] = {key_float(box[0]), key_float(box[1]), key_float(box[2])};
+        float mn[3] = {key_float(box[0]), key_float(box[1]), key_float(box[2])};
         float ext[3];
         for (int k = 0; k < 3; ++k) ext[k] = fmaxf(key_float(box[3 + k]) - mn[k], 0.0f);
+        grid_box_guard(mn, ext);
         const float longest = fmaxf(fmaxf(ext[0], ext[1]), fmaxf(ext[2], 1e-30f));
         float cell = longest / 2.0f;
         for (int it = 0; it < 64; ++it) {  // shrink the cell until there are about as many cells as vertices (or the limits are hit)
@@ -706,9 +717,10 @@ __global__ void __launch_bounds__(256) grid_bbox_kernel(int n, const float* __re
 // one thread: cell size for ~4 points per cell, at most n cells (the counter array has n + 1 entries) and GRID_MAX_DIM per axis
 __global__ void grid_setup_kernel(int n, GridParams* g, uint32_t* cell_count)
 {
-    const float mn[3] = {key_float(g->lo[0]), key_float(g->lo[1]), key_float(g->lo[2])};
+    float mn[3] = {key_float(g->lo[0]), key_float(g->lo[1]), key_float(g->lo[2])};
     float ext[3];
     for (int k = 0; k < 3; ++k) ext[k] = fmaxf(key_float(g->hi[k]) - mn[k], 0.0f);
+    grid_box_guard(mn, ext);
     const float longest = fmaxf(fmaxf(ext[0], ext[1]), fmaxf(ext[2], 1e-30f));
     // volume of the box, a degenerate axis counted as one cell thick
     float cell = longest / 2.0f;

@@ -269,3 +269,46 @@ def test_grid_search_equals_the_scan(K, layout, device):
     assert np.array_equal(out["scan"][1][ok], out["grid"][1][ok])
     assert np.array_equal(out["scan"][0][ok].view(np.uint32), out["grid"][0][ok].view(np.uint32))
     assert lib.hgs_knn_workspace(1000, 100) == 0
+
+
+@pytest.mark.gpu
+def test_grids_survive_non_finite_coordinates(device):
+    """A template vertex / a cloud point at infinity (or NaN) leaves the bounding box without a cell size: the grid falls back to
+    one cell and every finite query still gets the scan's answer."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd.knn import distCUDA2
+    lib = dgr._load()
+    lib.hgs_knn_workspace.restype = C.c_size_t
+    lib.hgs_knn_workspace.argtypes = [C.c_int32, C.c_int32]
+    args = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.hgs_knn_points.argtypes = args + [C.c_void_p]
+    lib.hgs_knn_points_ws.argtypes = args + [C.c_void_p, C.c_void_p]
+    templ, _, pts = body(8000, 1500, 24, seed=77)
+    for bad in (np.inf, -np.inf, np.nan):
+        t = templ.copy()
+        t[17, 1] = bad
+        n, m, K = pts.shape[0], t.shape[0], 4
+        tp, tt = torch.from_numpy(pts).to(device), torch.from_numpy(t).to(device)
+        out = []
+        for use_ws in (False, True):
+            d = torch.empty(n, K, dtype=torch.float32, device=device)
+            i = torch.empty(n, K, dtype=torch.int64, device=device)
+            ws = torch.empty(lib.hgs_knn_workspace(n, m), dtype=torch.uint8, device=device)
+            rc = (lib.hgs_knn_points_ws(n, tp.data_ptr(), m, tt.data_ptr(), K, d.data_ptr(), i.data_ptr(), ws.data_ptr(), None) if use_ws
+                  else lib.hgs_knn_points(n, tp.data_ptr(), m, tt.data_ptr(), K, d.data_ptr(), i.data_ptr(), None))
+            assert rc == 0
+            torch.cuda.synchronize()
+            out.append((d.cpu().numpy(), i.cpu().numpy()))
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+        assert (out[1][1] != 17).all()                                # the vertex at infinity is nobody's neighbour
+    cloud = np.random.default_rng(5).standard_normal((40_000, 3)).astype(np.float32)
+    want = distCUDA2(torch.from_numpy(cloud).to(device)).cpu().numpy()
+    cloud2 = cloud.copy()
+    cloud2[123] = np.inf                                              # one point at infinity: the grid search degenerates, the others keep their answer
+    got = distCUDA2(torch.from_numpy(cloud2).to(device)).cpu().numpy()
+    keep = np.ones(len(cloud), bool)
+    keep[123] = False
+    d123 = ((cloud - cloud[123]) ** 2).sum(1)
+    unaffected = keep & (d123 > np.sort(d123)[40])                    # points that did not count #123 among their three nearest
+    assert np.array_equal(got[unaffected], want[unaffected])

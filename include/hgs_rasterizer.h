@@ -140,9 +140,11 @@ typedef struct hgs_forward_args {
      * buffer (HGS_BUF_CKPT, hgs_ckpt_bytes(capacity, H, W)) for per-pixel CHECKPOINTS: on a sparse frame (few non-empty
      * tiles with deep lists: a human-only render) the forward then stores (T, colour prefix) of every pixel every 32
      * positions of its quad's list, and backward splits every list into 32-entry segments that run as independent waves
-     * instead of one chain of dependent entries per quad.  Dense frames write and read nothing there.  Results are the
-     * same up to fp32 summation order either way; 0 (or a failed HGS_BUF_CKPT allocation is an error) keeps the
-     * one-wave-per-quad backward. */
+     * instead of one chain of dependent entries per quad.  On a dense frame only the DEEP tiles (512 entries and more: a
+     * person in front of a scene) do that, the others go through the one-wave-per-tile backward as always; the library
+     * asks for the buffer on a dense frame only when the frame has long tiles (more than 2048 entries), so a caller that
+     * sets this flag for every frame pays for the buffer only where it helps.  Results are the same up to fp32 summation
+     * order either way; 0 keeps the one-wave backward (a failed HGS_BUF_CKPT allocation is an error). */
     int32_t backward_checkpoints;
     /* Optional caller-provided scratch (e.g. persistent arenas for frames that need no backward): buffer k
      * (HGS_BUF_GEOM / HGS_BUF_BINNING / HGS_BUF_IMAGE / HGS_BUF_CKPT) is used when scratch[k] != NULL and

@@ -844,7 +844,7 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     }
     if (FUSED) {
         mine = __builtin_amdgcn_readfirstlane(mine);
-        float4* ck_tile = ckpt_begin(ck, blockIdx.x);
+        float4* ck_tile = ckpt_begin(ck, blockIdx.x, n);
         blend_forward_wave(cam, lastg, (int)(blockIdx.x % (uint32_t)cam.gx), (int)(blockIdx.x / (uint32_t)cam.gx), w, mine,
                            act + (size_t)w * stride + s, splats, bg, out_color, final_T, n_contrib, clamp_output, ck_tile,
                            ck.quad_nproc + blockIdx.x * 4u + (uint32_t)w);

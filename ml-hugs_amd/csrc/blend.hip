@@ -49,7 +49,7 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
         const int tile = tile_list ? (int)((const_u32p)tile_list)[k] : (int)k;
         const v2u range = ((const_u2p)ranges)[tile];
         const uint32_t n = range.y > range.x ? ((const_u32p)act_count)[tile * NUM_LISTS + w] : 0u;
-        float4* ck_tile = ckpt_begin(ck, (uint32_t)tile);
+        float4* ck_tile = ckpt_begin(ck, (uint32_t)tile, range.y > range.x ? range.y - range.x : 0u);
         blend_forward_wave(cam, lastg, tile % cam.gx, tile / cam.gx, w, n, act + (size_t)w * act_stride + range.x, splats, bg, out_color,
                            final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + (uint32_t)tile * 4u + (uint32_t)w);
     }
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256)
 blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                       size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpix, float* __restrict__ grad_accum)
+                      const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, uint32_t skip_from)
 {
     const int num_tiles = cam.gx * cam.gy;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -350,6 +350,7 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
     const int tile = vbid;
     const v2u range = ((const_u2p)ranges)[tile];
     if (range.y <= range.x) return;
+    if (skip_from && range.y - range.x >= skip_from) return;  // a deep tile of a dense frame: the segmented kernel has it
     blend_backward_wave<NQ>(cam, lastg, tile, w, range, act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
 }
 
@@ -369,6 +370,7 @@ blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restr
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x;  // (the grid is the frame's slot count, (N >> CKPT_SHIFT) + tiles)
     const uint32_t tile = ((const_u32p)ck.slot_tile)[slot];
+    if (tile == CKPT_SLOT_NONE) return;  // (a dense frame's tile that left no checkpoints: blend_backward_kernel<4> has it)
     const uint32_t first_slot = ((const_u32p)ck.seg_first)[tile];
     const uint32_t m = slot - first_slot;
     const uint32_t walked = ((const_u32p)ck.quad_nproc)[tile * 4u + (uint32_t)w];  // entries the forward wave walked
@@ -391,16 +393,21 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
     const int num_tiles = cam.gx * cam.gy;
     static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
     const bool per_quad = force ? force[0] == '4' : sparse_frame;
-    if (sparse_frame && ck.state) {  // the forward left checkpoints (it does so exactly when the frame is sparse)
+    if (ck.state) {
+        // the forward left checkpoints: for every tile of a sparse frame, for the deep tiles (CKPT_DEEP_MIN) of a dense one --
+        // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)
         const uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;
         hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act, act_stride,
                            splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
+        if (!sparse_frame)
+            hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((num_tiles + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
+                               act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, CKPT_DEEP_MIN);
     } else if (per_quad)
         hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(num_tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
-                           act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+                           act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, 0u);
     else
         hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((num_tiles + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
-                           act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+                           act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, 0u);
 }
 
 }  // namespace hgs

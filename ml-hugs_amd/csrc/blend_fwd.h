@@ -76,14 +76,16 @@ __device__ __forceinline__ void fwd_accumulate(const SplatRec& s, uint32_t pos1,
     last = upd ? pos1 : last;
 }
 
-// First slot of tile `tile` in the checkpoint buffer (nullptr: the frame leaves no checkpoints); the workgroup also
-// records which tile its slots belong to -- the backward's workgroups are dealt slots, not tiles (blend.hip).
-__device__ __forceinline__ float4* ckpt_begin(const Ckpt& ck, uint32_t tile)
+// First slot of tile `tile` (a list of `n_tile` entries) in the checkpoint buffer, or nullptr: the frame leaves no checkpoints,
+// or it is a dense frame and this tile is not a deep one (hgs_common.h, CKPT_DEEP_MIN).  The workgroup also records which tile
+// its slots belong to -- the backward's workgroups are dealt slots, not tiles (blend.hip) -- or that they hold nothing.
+__device__ __forceinline__ float4* ckpt_begin(const Ckpt& ck, uint32_t tile, uint32_t n_tile)
 {
-    if (!ck.state || *(const_u32p)ck.sparse == 0u) return nullptr;
+    if (!ck.state) return nullptr;
+    const bool leave = *(const_u32p)ck.sparse != 0u || n_tile >= CKPT_DEEP_MIN;
     const uint32_t first = ((const_u32p)ck.seg_first)[tile], end = ((const_u32p)ck.seg_first)[tile + 1];
-    for (uint32_t k = first + threadIdx.x; k < end; k += blockDim.x) ck.slot_tile[k] = tile;
-    return ck.state + (size_t)first * 256u;
+    for (uint32_t k = first + threadIdx.x; k < end; k += blockDim.x) ck.slot_tile[k] = leave ? tile : CKPT_SLOT_NONE;
+    return leave ? ck.state + (size_t)first * 256u : nullptr;
 }
 
 // One wave = the 64 pixels of quad `w` (0..3) of tile (tx, ty); walks `n` entries of the quad's compacted list.

@@ -566,7 +566,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         // exact size known now (and whether there are long tiles); after a too-small guess the gated kernels above did
         // nothing, so the frame is simply enqueued again
         if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
-        known_dense = !sparse;
+        known_dense = !sparse && !has_long;  // (a dense frame WITH long tiles keeps its checkpoints: its deep tiles use them)
         if (known_dense) state->ckpt = nullptr, state->ckpt_bytes = 0, fb.ck = Ckpt{};
         if (int rc = enqueue_frame(N, has_long)) return rc;
     } else if (has_long && !long_sort_done) {

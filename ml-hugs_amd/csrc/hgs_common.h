@@ -124,6 +124,11 @@ constexpr int NUM_LISTS = 5;  // four per-quad lists + one "any quad" list per t
 // [seg_first[t], seg_first[t + 1]) with seg_first[t] = (start of the tile's list segment >> CKPT_SHIFT) + t: at least
 // ceil(list length / CKPT_SEG) of them, no prefix sum beyond the one the scan already does, (N >> CKPT_SHIFT) + T in all.
 constexpr int CKPT_SHIFT = 5, CKPT_SEG = 1 << CKPT_SHIFT;
+// On a DENSE frame that was given a checkpoint buffer (the caller expects long tiles), tiles from this many entries on leave
+// checkpoints too and go through the depth-segmented backward; the one-wave-per-tile kernel skips them.  A dense frame's
+// backward otherwise lasts as long as its deepest tile's chain -- a person in front of a scene (the joint render of HUGS).
+// slot_tile = CKPT_SLOT_NONE marks the slots of tiles that left none.
+constexpr uint32_t CKPT_DEEP_MIN = 512u, CKPT_SLOT_NONE = 0xFFFFFFFFu;
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, act_count, cursor, large_tiles, n_total, seg_first, quad_nproc, total;
     ImageLayout(int H, int W) {

@@ -183,7 +183,7 @@ public:
             std::lock_guard<std::mutex> lk(g_mu);
             auto it = g_hints.find(key);
             // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
-            a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse)) ? 1 : 0;
+            a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse || it->second.has_long)) ? 1 : 0;
             if (g_use_hint && it != g_hints.end()) {
                 a.binning_capacity_hint = round_capacity(it->second.n);
                 a.expect_no_long_tiles = it->second.has_long ? 0 : 1;

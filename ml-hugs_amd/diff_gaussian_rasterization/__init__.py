@@ -253,8 +253,8 @@ def _deferred_capacity(seen, H, W):
     return max(4 * seen + 4096, min(_DEFERRED_MIN_CAPACITY, max(1 << 16, 256 * tiles)))
 
 
-# Whether the last frame of a shape was SPARSE (few non-empty tiles): such frames get a checkpoint buffer when a backward
-# will follow (hgs_forward_args.backward_checkpoints); a shape without history is assumed sparse (the library then
+# Whether the last frame of a shape was SPARSE (few non-empty tiles): such frames -- and dense ones that had long tiles -- get a
+# checkpoint buffer when a backward will follow (hgs_forward_args.backward_checkpoints); a shape without history is assumed sparse (the library then
 # allocates the buffer only if the frame turns out to be).
 _last_sparse = {}
 _USE_CKPT = os.environ.get("HGS_BWD_SEGMENTED", "1") != "0"
@@ -444,7 +444,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             args.grad_accum_to_zero = bw.grad_accum
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
-        args.backward_checkpoints = 1 if (needs_grad and _USE_CKPT and _last_sparse.get(hint_key, True)) else 0
+        # (sparse frames, and dense ones with long tiles: their deep tiles go through the segmented backward too)
+        args.backward_checkpoints = 1 if (needs_grad and _USE_CKPT and (_last_sparse.get(hint_key, True) or
+                                                                        _last_num_rendered.get(hint_key, (0, False))[1])) else 0
         prev_dev = torch.cuda.current_device()
         if prev_dev != dev.index:
             torch.cuda.set_device(dev)

@@ -1128,3 +1128,47 @@ def test_segmented_backward_equals_the_one_wave_per_quad_backward(binding, devic
         assert rel_l2(grads[True][k], grads[False][k]) <= 1e-5, k
         if k in refg:
             assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device, monkeypatch):
+    """A DENSE frame (every one of 68 x 68 tiles non-empty: a scene) with a stack of Gaussians in its middle (a person in front
+    of it: tiles from a few hundred to several thousand entries deep).  With a checkpoint buffer the tiles of CKPT_DEEP_MIN
+    entries and more leave checkpoints and go through the depth-segmented backward, the others through the one-wave-per-tile
+    kernel; without one (HGS_BWD_SEGMENTED=0) that kernel takes them all.  Images bit-equal, gradients equal within the float
+    atomics' order and the checkpoints' prefix cancellation (1e-5), both within the oracle's bar."""
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd import synthetic as syn
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    H = W = 1088
+    sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+    bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+    for k, src in (("means3D", "means3D"), ("scales", "scales"), ("rotations", "rotations"), ("opacities", "opacities"), ("shs", "shs")):
+        sc[k] = np.concatenate([sc[k], np.asarray(bgd[src], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    depth = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert (depth > 0).sum() >= 4096 and depth.max() > 2048 and ((depth >= 512) & (depth <= 2048)).any()   # dense; long AND mid-deep tiles
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    grads, images = {}, {}
+    for seg in (True, False):
+        monkeypatch.setattr(dgr, "_USE_CKPT", seg)
+        if dgr._cpp is not None:
+            dgr._cpp.use_checkpoints(seg)
+        for _ in range(2):                                        # the second frame runs on the first one's hints
+            t, color, _ = run_gpu(sc, device)
+            color.backward(to_dev(sc["dL_dpix"], device))
+        key = (device.index or 0, sc["means3D"].shape[0], H, W)
+        assert dgr._last_num_rendered[key][1] and not dgr._last_sparse[key]      # long tiles, not sparse
+        images[seg] = color.detach()
+        grads[seg] = {k: t[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}
+    if dgr._cpp is not None:
+        dgr._cpp.use_checkpoints(True)
+    assert torch.equal(images[True], images[False])
+    check_image(images[True].cpu().numpy(), ref["color"], "dense frame with deep tiles")
+    for k in grads[True]:
+        assert rel_l2(grads[True][k], grads[False][k]) <= 1e-5, k
+        if k in refg:
+            assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k

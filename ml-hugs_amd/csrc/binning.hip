@@ -874,6 +874,22 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
     const uint32_t s = rg.x, n = rg.y - rg.x;
     bool sorted_in_lds = false;  // (workgroup-uniform)
     if (n <= threshold) continue;  // (a candidate that is not long on this -- dense -- frame: the small-tile kernel sorts it)
+    // bitonic sort of up to CAP keys in LDS; `count` keys from `src`, result left in sh[0..count)
+    auto sort_in_lds = [&](const uint64_t* src, uint32_t count) {
+        uint32_t m = 2;
+        while (m < count) m <<= 1;
+        for (uint32_t i = threadIdx.x; i < m; i += SORT_LARGE_THREADS) sh[i] = i < count ? src[i] : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t c = threadIdx.x; c < (m >> 1); c += SORT_LARGE_THREADS) {
+                    const uint32_t l = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), r = l | j;
+                    const uint64_t a = sh[l], b = sh[r];
+                    if ((a > b) == ((l & k) == 0u)) sh[l] = b, sh[r] = a;
+                }
+                __syncthreads();
+            }
+    };
     if (n <= (uint32_t)CAP) {
         // the register network of the small tiles with 1024 threads (4 or 8 keys each): lane distances below 64 by DPP,
         // only distances 64..512 through LDS -- a fifth of the barriers of an all-LDS bitonic sort
@@ -929,66 +945,27 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
         // distinct: they embed the Gaussian index).  O(n (n/CAP) log CAP) instead of a global merge network.
         const uint32_t chunks = (n + CAP - 1u) / CAP;
         for (uint32_t c = 0; c < chunks; ++c) {
-            // a chunk is sorted like a tile of its size: bucket sort (the register network when its depths pile up) -- the
-            // all-LDS bitonic sort this used to be costs 91 barriers per chunk, ~100 us, and a person in front of a scene does
-            // produce a few tiles beyond CAP entries
-            constexpr int E = CAP / SORT_LARGE_THREADS;
             const uint32_t c0 = c * CAP, cn = min((uint32_t)CAP, n - c0);
-            uint64_t key[E];
-            uint32_t pos[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                key[e] = i < cn ? keys[s + c0 + i] : ~0ull;
-            }
-            if (bucket_sort<E, SORT_LARGE_THREADS>(key, pos, cn, sh, bucket_start, red)) {
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < cn) scratch[s + c0 + pos[e]] = key[e];
-            } else {
-                bitonic_in_registers<E, SORT_LARGE_THREADS>(key, sh);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                    if (i < cn) scratch[s + c0 + i] = key[e];
-                }
-            }
-            __syncthreads();  // (sh / bucket_start are reused by the next chunk)
+            sort_in_lds(keys + s + c0, cn);
+            for (uint32_t i = threadIdx.x; i < cn; i += SORT_LARGE_THREADS) scratch[s + c0 + i] = sh[i];
+            __syncthreads();
         }
         __threadfence_block();
-        // ranks: the keys of one chunk stay in registers while every OTHER chunk passes through LDS once -- thirteen LDS reads
-        // per key and chunk instead of thirteen dependent global loads
-        for (uint32_t c = 0; c < chunks; ++c) {
-            constexpr int E = CAP / SORT_LARGE_THREADS;
-            const uint32_t c0 = c * CAP, cn = min((uint32_t)CAP, n - c0);
-            uint64_t key[E];
-            uint32_t rank[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                key[e] = i < cn ? __builtin_nontemporal_load(&scratch[s + c0 + i]) : ~0ull;
-                rank[e] = c0 + i;  // (the chunks before this one are counted in full below: c0 = their sizes; corrected there)
-            }
-            for (uint32_t oc = 0; oc < chunks; ++oc) {
-                if (oc == c) continue;
-                const uint32_t o0 = oc * CAP, on = min((uint32_t)CAP, n - o0);
-                __syncthreads();  // (the previous occupant of sh has been read by everybody)
-                for (uint32_t i = threadIdx.x; i < on; i += SORT_LARGE_THREADS) sh[i] = __builtin_nontemporal_load(&scratch[s + o0 + i]);
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    uint32_t lo = 0, hi = on;  // first index whose key is >= key[e]
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (sh[mid] < key[e]) lo = mid + 1; else hi = mid;
-                    }
-                    // rank = own index + smaller keys in every other chunk; chunks in front were pre-counted as c0 in full
-                    rank[e] += oc < c ? lo - on : lo;
+        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) {
+            const uint64_t ki = __builtin_nontemporal_load(&scratch[s + i]);
+            const uint32_t own = i / CAP;
+            uint32_t rank = i - own * CAP;
+            for (uint32_t c = 0; c < chunks; ++c) {
+                if (c == own) continue;
+                const uint64_t* ch = scratch + s + c * CAP;
+                uint32_t lo = 0, hi = min((uint32_t)CAP, n - c * CAP);  // first index whose key is >= ki
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (__builtin_nontemporal_load(&ch[mid]) < ki) lo = mid + 1; else hi = mid;
                 }
+                rank += lo;
             }
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < cn) list[s + rank[e]] = list_entry(key[e], rank[e] + 1u);
+            list[s + rank] = list_entry(ki, rank + 1u);
         }
     }
     // the segment is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it

@@ -69,19 +69,53 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes", devdir="/dev/dri", env=None):
+    """GPUs this process could open, WITHOUT touching the GPU runtime (no torch, no HIP: a launcher parent that has
+    initialised the GPU and then starts children is what this pool refuses).  KFD topology nodes with SIMDs are GPUs
+    (CPU nodes have simd_count 0); one counts when its render node can be opened; *_VISIBLE_DEVICES lists cap the
+    count.  None = cannot tell (no KFD topology readable): the caller then relies on the rank watcher."""
+    env = os.environ if env is None else env
+    try:
+        nodes = sorted(os.listdir(sysfs))
+    except OSError:
+        return None
+    count = 0
+    for node in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(sysfs, node, "properties")).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0").strip() or 0) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1").strip() or -1)
+        if minor >= 0 and os.path.isdir(devdir) and not os.access(os.path.join(devdir, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue   # a GPU of the host that this container was not given
+        count += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
 def launch_ranks(args):
-    """--gpus N without a launcher: start N fresh rank processes (never exec / re-exec: this process has not touched the
-    GPU and does not need to), one per LOCAL_RANK, rendezvous on 127.0.0.1.  Rank 0's stdout is this process's stdout."""
+    """--gpus N without a launcher: start N fresh rank processes (never exec / re-exec), one per LOCAL_RANK, rendezvous on
+    127.0.0.1.  Rank 0's stdout is this process's stdout.  The parent never touches the GPU runtime and never imports torch:
+    GPUs are counted from the KFD topology in sysfs (visible_gpu_count)."""
     import socket
     import subprocess
     n = args.gpus
     backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
     if backend == "nccl" and not args.launcher_selftest:
-        import torch  # device_count() does not initialise the GPU on this image
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpu_count()
+        if have is None and not os.path.exists("/dev/kfd"):
+            have = 0   # no KFD device at all: there is no GPU to give a rank
+        if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible. One rank per GPU over RCCL needs {n}; "
                              "set HGS_BENCH_BACKEND=gloo to let ranks share GPUs (plumbing check, not a scaling number).")
+        if have is None:
+            log("[launcher] could not count GPUs from the KFD topology: relying on the rank watcher")
+    assert "torch" not in sys.modules, "the launcher parent must stay free of torch / the GPU runtime"
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -91,7 +125,8 @@ def launch_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    log(f"[launcher] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}, backend {backend}")
+    log(f"[launcher] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}, backend {backend}; "
+        f"parent imported torch: {'torch' in sys.modules}")
     # Watch ALL ranks (what torchrun does): the first one that fails takes the others down with it -- a rank that died in
     # init would otherwise leave the rest in a collective until the process-group timeout -- and there is an overall deadline.
     import threading
@@ -364,7 +399,9 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "ranks_seen": int(frames[:, 3].sum()), "rank_devices": [int(x) for x in frames[:, 2].tolist()],
+        "ranks_seen": int(frames[:, 3].sum()), "expected_ranks": args.gpus, "backend": backend if world > 1 else "single process",
+        "rank_devices": [int(x) for x in frames[:, 2].tolist()],
+        "per_rank_N": [int(x) for x in frames[:, 0].tolist()],
         "per_rank_fps": [round(float(x), 2) for x in frames[:, 4].tolist()],   # each rank's own clock: a straggler is visible here
         "config": {"workload": f"{'configs[1]' if (P, KF) == (200_000, 1) else ('configs[4] (frame batch)' if P == 300_000 else 'sweep point')}: "
                                f"{P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
@@ -442,6 +479,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if out["ranks_seen"] != args.gpus:   # a line that LOOKS like an N-GPU number but is not one must not exit 0
+        log(f"bench.py: {out['ranks_seen']} rank(s) reported, --gpus {args.gpus} expected")
+        raise SystemExit(3)
 
 
 def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):

@@ -24,6 +24,8 @@ def test_launcher_spawns_two_ranks_and_relays_rank0():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["rank_ids"] == [0, 1] and out["max_over_ranks_ok"]
     assert "[launcher] started 2 ranks" in r.stderr
+    # the parent that starts the ranks must not have touched the GPU runtime -- it never imports torch
+    assert "parent imported torch: False" in r.stderr
 
 
 def test_world_size_mismatch_is_an_error_not_a_single_rank_number():
@@ -52,3 +54,33 @@ def test_a_rank_that_dies_takes_the_others_down_promptly():
 def test_launcher_deadline():
     r = run(["--gpus", "2", "--launcher-selftest"], {"HGS_SELFTEST_HANG_RANK": "1", "HGS_BENCH_DEADLINE_S": "8"}, timeout=120)
     assert r.returncode != 0 and "deadline" in r.stderr and r.stdout.strip() == ""
+
+
+def _fake_kfd(tmp_path, nodes, render_ok=()):
+    """A KFD topology tree as the kernel lays it out: nodes/<i>/properties with `key value` lines."""
+    sysfs, dev = tmp_path / "nodes", tmp_path / "dri"
+    dev.mkdir(parents=True)
+    for i, (simd, minor) in enumerate(nodes):
+        d = sysfs / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for m in render_ok:
+        (dev / f"renderD{m}").write_text("")
+    return str(sysfs), str(dev)
+
+
+def test_gpus_are_counted_from_the_kfd_topology_without_the_gpu_runtime(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    # two CPU nodes + eight GPUs, all render nodes given to this container
+    nodes = [(0, -1), (0, -1)] + [(1024, 128 + k) for k in range(8)]
+    sysfs, dev = _fake_kfd(tmp_path / "a", nodes, render_ok=range(128, 136))
+    assert bench.visible_gpu_count(sysfs, dev, env={}) == 8
+    assert bench.visible_gpu_count(sysfs, dev, env={"HIP_VISIBLE_DEVICES": "0,1"}) == 2
+    assert bench.visible_gpu_count(sysfs, dev, env={"ROCR_VISIBLE_DEVICES": "3"}) == 1
+    # the host has eight, the container was given one render node (a 1-GPU lease)
+    sysfs, dev = _fake_kfd(tmp_path / "b", nodes, render_ok=[130])
+    assert bench.visible_gpu_count(sysfs, dev, env={}) == 1
+    # no topology at all: "cannot tell", not zero
+    assert bench.visible_gpu_count(str(tmp_path / "missing"), dev, env={}) is None
+    assert "torch" not in getattr(bench, "__dict__", {})   # bench.py's module level never binds torch

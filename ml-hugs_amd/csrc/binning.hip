@@ -17,10 +17,16 @@
 // 64-bit key through a multi-pass global radix sort: ~36 B per entry of HBM traffic instead of ~160 B, and 5 kernel
 // launches instead of 20.  The slot order inside a segment before sorting is arbitrary (atomics); the per-tile
 // sort is on a total order, so the output is deterministic.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hgs_common.h"
 #include "binning_walk.h"
+#ifdef HGS_TRACE
+namespace hgs { __device__ unsigned long long* g_trace_buf = nullptr; }
+extern "C" int hgs_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(hgs::g_trace_buf), &p, sizeof p); }
+#define HGS_TRACE_THIS_FILE
+#endif
 #include "blend_fwd.h"
 
 namespace hgs {
@@ -47,10 +53,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // no copy kernel, no event.  A thread scans eight consecutive tiles (two 16-byte loads, 64 bytes of ranges stored), so
 // the 8 160 tiles of a 1080p frame are one pass with two barriers.
 constexpr int SORT_CAP_SMALL = 2048, SORT_CAP_LARGE = 8192;  // list lengths the register / LDS tile sorts take
+constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long tiles' sort kernel holds (longer lists are split into parts)
 // On SPARSE frames (few non-empty tiles, deep lists: a human-only render) the one-workgroup-per-tile kernel below has the CUs
 // mostly idle and lasts as long as its longest tile's sort: there, lists from LONG_MIN_SPARSE entries on already go to the
 // long-tile kernel (1 024 threads and a bucket sort instead of a 256-thread bitonic network).
-constexpr int LONG_MIN_SPARSE = 1024;
+// Round 4: the long tiles' forward blend is depth-parallel (blend_fwd.h, deep_forward_worker), so "long" now also means "worth
+// splitting by depth": LONG_MIN_SPARSE comes down from 1 024.  Both thresholds are kernel arguments of the scan (defaults
+// below; HGS_LONG_MIN_SPARSE / HGS_LONG_MIN_DENSE override them for A/B measurements); what a frame uses is n_total[4].
+constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
+constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
+constexpr uint32_t DEEP_MEAN_MIN = 384;
+constexpr int LONG_MIN_DENSE = 2048;            // dense frames: what the one-workgroup-per-tile sort cannot hold
 constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
@@ -60,12 +73,12 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
                  uint2* __restrict__ ranges, uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total,
                  uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ seg_first, uint32_t capacity,
-                 unsigned long long* __restrict__ host_slot, uint32_t ticket)
+                 unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t n_large, n_large_dense, n_nonempty;
+    __shared__ uint32_t n_large, n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
-    if (threadIdx.x == 0) n_large = 0, n_large_dense = 0, n_nonempty = 0, total64 = 0ull;
+    if (threadIdx.x == 0) n_large = 0, n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
     for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
@@ -117,9 +130,12 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
             st[k] = start;
             start += c[k];
             // (candidates: which of them ARE long depends on the sparse-frame decision at the end of this kernel)
-            if (c[k] > (uint32_t)LONG_MIN_SPARSE && t0 + k < num_tiles) {
+            if (c[k] > min(long_min_sparse, long_min_dense) && t0 + k < num_tiles) {
                 large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)(t0 + k);  // rare
-                if (c[k] > (uint32_t)SORT_CAP_SMALL) atomicAdd(&n_large_dense, 1u);
+                if (c[k] > (uint32_t)SORT_CAP_MID) atomicAdd(&n_huge, 1u);
+                if (c[k] > long_min_sparse) atomicAdd(&n_large_sparse, 1u);
+                if (c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW) atomicAdd(&n_large_shallow, 1u);
+                if (c[k] > long_min_dense) atomicAdd(&n_large_dense, 1u);
             }
         }
         if (t0 + SCAN_ITEMS <= num_tiles) {
@@ -154,6 +170,9 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         // capacity, and the host is told N = 0xFFFFFFFF, which it turns into HGS_ERR_OVERFLOW
         if (total64 >= (unsigned long long)N_TOO_MANY) carry = 0xFFFFFFFFu;
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u, n_total[2] = n_large;
+        // [5] parts of the lists beyond SORT_CAP_MID entries (long_tile_plan_kernel appends), [6] how many such lists there are,
+        // [7] lists the plan leaves to the one-workgroup fallback
+        n_total[5] = 0u, n_total[6] = n_huge, n_total[7] = 0u;
         if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
         // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
         // the backward blend then splits long tiles over four waves
@@ -161,10 +180,23 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         n_total[3] = sparse;
         // (sparse << 63 | has-long-tiles << 62 | 30-bit ticket << 32 | N)
         // this frame's long-tile threshold (n_total[4]): read by both sort kernels
-        const uint32_t threshold = (sparse && n_large >= LONG_MIN_SPARSE_TILES) ? (uint32_t)LONG_MIN_SPARSE : (uint32_t)SORT_CAP_SMALL;
+        // sparse frames: lists from long_min_sparse entries on are long (sorted ahead, blended split by depth) when the frame's lists
+        // are deep on average -- depth parallelism pays for its compose + re-walk overhead only where one wave per quad would walk
+        // hundreds of entries -- and from LONG_MIN_SPARSE_SHALLOW on otherwise; in either case only if enough of them exist
+        const bool deep_lists = sparse && n_nonempty && total64 >= (unsigned long long)DEEP_MEAN_MIN * n_nonempty;
+        const uint32_t n_sparse_long = deep_lists ? n_large_sparse : n_large_shallow;
+        const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
+        const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : long_min_dense;
         n_total[4] = threshold;
-        const uint32_t any_long = (threshold == (uint32_t)LONG_MIN_SPARSE ? n_large : n_large_dense) ? 1u : 0u;
+        // [8]: the long tiles' quads are blended split by depth (the deep workers of the fused kernel) -- on dense frames, and on
+        // sparse frames with deep lists; on a shallow sparse frame (the SMPL template: 25 lists beyond 1 024 entries, composited
+        // depth <= 430) one wave per quad does as well and the workers' workgroups only stand in the way (measured: +2 us)
+        n_total[8] = (!sparse || deep_lists) ? 1u : 0u;
+        const uint32_t any_long = (use_sparse ? n_sparse_long : n_large_dense) ? 1u : 0u;
         const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)any_long << 30);
+        // (words 1 and 2 of the slot: how many lists are long / beyond SORT_CAP_MID -- the host sizes the next frame's launches by them)
+        __hip_atomic_store(host_slot + 1, (unsigned long long)(use_sparse ? n_sparse_long : n_large_dense), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 2, (unsigned long long)n_huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -173,8 +205,12 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count,
                       uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot,
                       uint32_t ticket, hipStream_t st)
 {
+    // (both at most SORT_CAP_SMALL: that is what the one-workgroup-per-tile sort holds)
+    // (read on every call: the tests switch them between frames)
+    auto from_env = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
+    const uint32_t long_min_sparse = from_env("HGS_LONG_MIN_SPARSE", LONG_MIN_SPARSE), long_min_dense = from_env("HGS_LONG_MIN_DENSE", LONG_MIN_DENSE);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
-                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket);
+                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, long_min_sparse, long_min_dense);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,17 +758,37 @@ __device__ __forceinline__ void compact_chunk(uint64_t entry, bool valid, uint32
         if (lane == 0) sh32[q * NW + w] = (uint32_t)__popcll(m);
     }
     __syncthreads();
+    if constexpr (NW <= 4) {
 #pragma unroll
-    for (int q = 0; q < NUM_LISTS; ++q) {
-        uint32_t before = 0, total = 0;
+        for (int q = 0; q < NUM_LISTS; ++q) {
+            uint32_t before = 0, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)NW; ++k) {
-            const uint32_t c = sh32[q * NW + k];
-            if (k < w) before += c;
-            total += c;
+            for (uint32_t k = 0; k < (uint32_t)NW; ++k) {
+                const uint32_t c = sh32[q * NW + k];
+                if (k < w) before += c;
+                total += c;
+            }
+            if (flag[q]) act[(size_t)q * stride + s + carry[q] + before + wrank[q]] = entry;
+            carry[q] += total;
         }
-        if (flag[q]) act[(size_t)q * stride + s + carry[q] + before + wrank[q]] = entry;
-        carry[q] += total;
+    } else {
+        // sixteen waves: lane k reads wave k's count and the wave scans them (5 LDS reads + shuffles, instead of 80 reads whose
+        // results the scheduler keeps in 80 registers -- what pushed the long-tile kernels to 128 VGPRs and into scratch)
+#pragma unroll
+        for (int q = 0; q < NUM_LISTS; ++q) {
+            const uint32_t c0 = lane < (uint32_t)NW ? sh32[q * NW + lane] : 0u;
+            uint32_t c = c0;   // inclusive scan inside the row of 16 lanes: four DPP row shifts (zero shifted in), no LDS
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x111, 0xf, 0xf, true);   // row_shr:1
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x112, 0xf, 0xf, true);   // row_shr:2
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x114, 0xf, 0xf, true);   // row_shr:4
+            if constexpr (NW > 8) c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x118, 0xf, 0xf, true);   // row_shr:8
+            static_assert(NW == 16 || NW == 8, "one DPP row");
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)c, NW - 1);
+            const uint32_t incl = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)w);    // (w is wave-uniform)
+            const uint32_t own = (uint32_t)__builtin_amdgcn_readlane((int)c0, (int)w);
+            if (flag[q]) act[(size_t)q * stride + s + carry[q] + (incl - own) + wrank[q]] = entry;
+            carry[q] += total;
+        }
     }
     __syncthreads();
 }
@@ -798,38 +854,71 @@ __device__ __forceinline__ uint32_t tile_sort_small(uint32_t tile, uint32_t s, u
 // invalidated before the first list read (a neighbouring tile's prefetch may have pulled a stale line of this segment in).
 // Long tiles (n > 2048) are left to tile_sort_large_kernel + the stand-alone forward blend over the long-tile list.
 // FUSED = false: sort only (the stand-alone forward blend follows).
+// Register budget of the fused kernel: 7 waves per SIMD, i.e. at most 72 VGPRs and 96 SGPRs -- the hardware adds 16 trap-handler
+// SGPRs per wave, so 96 is where 7 waves end and 80 where 8 would begin (tools/microbench/occupancy_regs.hip; the compiler's own
+// "Occupancy 8" for round 3's 95 SGPRs did not count them: that kernel ran 7 waves too).  Without the attribute the deep-worker
+// path's scalar state raises the allocation to 106 SGPRs = 6 waves (C2: fused kernel +2.5 %); asking for 8 spills in the sort.
+#ifndef FUSED_KERNEL_ATTR
+#define FUSED_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(7)))
+#endif
+// (the kernel's arguments as ONE struct: the tile path reads what only its epilogue needs -- output pointers, background, image
+//  size -- back from the kernarg segment AFTER the walk (below); as separate arguments they sat in SGPRs across the blend loop,
+//  and with the deep workers' state in the same kernel that pushed the loop's own values into spill lanes: +10 % on C4)
+struct FusedKernelArgs {
+    const uint2* ranges; const uint64_t* keys; uint64_t* list; uint64_t* act; size_t stride; uint32_t* act_count; const uint32_t* gate;
+    Camera cam; uint32_t lastg; const Splat* splats; const float* bg; float* out_color; float* final_T; uint32_t* n_contrib;
+    int clamp_output, long_sorted; Ckpt ck; const uint32_t* large_tiles; uint32_t num_workers;
+};
+typedef const __attribute__((address_space(4))) FusedKernelArgs* fused_args_p;
+
 template <bool FUSED>
-__global__ void __launch_bounds__(256)
-tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
-                       uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count,
-                       const uint32_t* __restrict__ gate, Camera cam, uint32_t lastg, const Splat* __restrict__ splats,
-                       const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
-                       uint32_t* __restrict__ n_contrib, int clamp_output, int long_sorted, Ckpt ck)
+__global__ void __launch_bounds__(256) FUSED_KERNEL_ATTR
+tile_sort_small_kernel(FusedKernelArgs a)
 {
-    __shared__ uint64_t sh[SORT_CAP_SMALL];
+    __shared__ uint64_t sh[FUSED ? DEEP_LDS_BYTES / 8 : (size_t)SORT_CAP_SMALL];  // (the deep workers' staging needs a little more than the sort)
+    static_assert(DEEP_LDS_BYTES >= SORT_CAP_SMALL * 8, "sort buffer");
+    const uint32_t* __restrict__ gate = a.gate;
     if (*gate) return;
+    HGS_TRACE_PUT(0, wall_clock64());
+    HGS_TRACE_PUT(3, ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID, HW_ID
+    const bool deep_blend = a.num_workers != 0u && gate[7] != 0u;   // (gate[7] = n_total[8], decided by the scan: data, not launch sizes)
+    if (FUSED && blockIdx.x < a.num_workers) {
+        if (!deep_blend) return;
+        // the first workgroups of the grid blend the long tiles -- sorted by the long tiles' kernels, which ran BEFORE this
+        // kernel -- one (tile, quad) at a time, split by depth over their four waves (blend_fwd.h), beside the other tiles'
+        // sort + blend
+        deep_forward_worker(blockIdx.x, a.num_workers, a.cam, a.lastg, a.ranges, a.act, a.stride, a.act_count, a.splats, a.bg, a.out_color,
+                            a.final_T, a.n_contrib, a.clamp_output, a.ck, a.large_tiles, gate - 1, *reinterpret_cast<DeepShared*>(sh), false);
+        return;
+    }
+    const uint32_t tile_id = blockIdx.x - a.num_workers;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint2 rg = ranges[blockIdx.x];
+    const uint2 rg = a.ranges[tile_id];
     const uint32_t s = rg.x, n = rg.y - rg.x;
+    uint32_t* __restrict__ act_count = a.act_count;
     uint32_t mine = 0;
     if (n == 0) {
-        if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
+        if (threadIdx.x < NUM_LISTS) act_count[tile_id * NUM_LISTS + threadIdx.x] = 0u;
         if (!FUSED) return;
     } else if (n > gate[3]) {  // (gate points at n_total[1]: n_total[4] is this frame's long-tile threshold)
-        // a long tile: sorted by tile_sort_large_kernel, which ran BEFORE this kernel (long_sorted) -- then only the blend is
+        // a long tile: sorted by the long tiles' kernels, which ran BEFORE this kernel (long_sorted) -- then only the blend is
         // left to do here -- or whose launch was skipped on the caller's guess that the frame has none: the tile's lists
         // read as empty and its pixels stay unwritten until the caller has repaired the guess (hgs_api.hip)
-        if (!long_sorted) {
-            if (threadIdx.x < NUM_LISTS) act_count[blockIdx.x * NUM_LISTS + threadIdx.x] = 0u;
+        if (!a.long_sorted) {
+            if (threadIdx.x < NUM_LISTS) act_count[tile_id * NUM_LISTS + threadIdx.x] = 0u;
             return;
         }
         if (!FUSED) return;
-        mine = ((const_u32p)act_count)[blockIdx.x * NUM_LISTS + w];
+        if (deep_blend) {  // its quads are blended by the deep workers at the front of this grid; the tile marks its checkpoint slots
+            ckpt_begin(a.ck, tile_id, n);
+            return;
+        }
+        mine = ((const_u32p)act_count)[tile_id * NUM_LISTS + w];  // (HGS_DEEP_FORWARD=0: one wave per quad, as for any other tile)
     } else {
-        if (n <= 256u) mine = tile_sort_small<1>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
-        else if (n <= 512u) mine = tile_sort_small<2>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
-        else if (n <= 1024u) mine = tile_sort_small<4>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
-        else mine = tile_sort_small<8>(blockIdx.x, s, n, keys, list, act, stride, act_count, sh, w);
+        if (n <= 256u) mine = tile_sort_small<1>(tile_id, s, n, a.keys, a.list, a.act, a.stride, act_count, sh, w);
+        else if (n <= 512u) mine = tile_sort_small<2>(tile_id, s, n, a.keys, a.list, a.act, a.stride, act_count, sh, w);
+        else if (n <= 1024u) mine = tile_sort_small<4>(tile_id, s, n, a.keys, a.list, a.act, a.stride, act_count, sh, w);
+        else mine = tile_sort_small<8>(tile_id, s, n, a.keys, a.list, a.act, a.stride, act_count, sh, w);
         if (FUSED) {
             // The list stores must have been acknowledged by L2 (the vector L1 is write-through) before any wave reads
             // them through the scalar cache.  A workgroup-scope release fence does NOT wait for that on this target
@@ -842,47 +931,308 @@ tile_sort_small_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the invalidate has completed before the first list read
         }
     }
+    HGS_TRACE_PUT(1, wall_clock64());
+    HGS_TRACE_PUT(4, ((unsigned long long)n << 32) | mine);
     if (FUSED) {
         mine = __builtin_amdgcn_readfirstlane(mine);
-        float4* ck_tile = ckpt_begin(ck, blockIdx.x, n);
-        blend_forward_wave(cam, lastg, (int)(blockIdx.x % (uint32_t)cam.gx), (int)(blockIdx.x / (uint32_t)cam.gx), w, mine,
-                           act + (size_t)w * stride + s, splats, bg, out_color, final_T, n_contrib, clamp_output, ck_tile,
-                           ck.quad_nproc + blockIdx.x * 4u + (uint32_t)w);
+        float4* ck_tile = ckpt_begin(a.ck, tile_id, n);
+        const int lane = threadIdx.x & 63;
+        const int tx = (int)(tile_id % (uint32_t)a.cam.gx), ty = (int)(tile_id / (uint32_t)a.cam.gx);
+        const int px = tx * TILE + (w & 1) * 8 + (lane & 7), py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
+        const bool inside = px < a.cam.W && py < a.cam.H;
+        float4* ck_mine = ck_tile ? ck_tile + w * 64 + lane : nullptr;
+        const uint64_t* my_list = a.act + (size_t)w * a.stride + s;
+        const FwdWalk r = blend_forward_walk(a.lastg, (float)px, (float)py, inside, mine, my_list, a.splats, ck_mine);
+        // the epilogue's arguments, fetched now (the pointer is opaque to the optimiser: nothing below was live across the walk)
+        fused_args_p late = (fused_args_p)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(late));
+        blend_forward_finish(r, late->cam.W, late->cam.H, px, py, lane, ck_mine, late->ck.quad_nproc + tile_id * 4u + (uint32_t)w, late->bg,
+                             late->out_color, late->final_T, late->n_contrib, late->clamp_output);
+    }
+    HGS_TRACE_PUT(2, wall_clock64());
+}
+
+// ---- the long tiles' sorts (round 4) ----------------------------------------------------------------------------------
+// A long tile (n > n_total[4]) is sorted BEFORE the fused kernel, whose deep workers blend it.  Three kernels share the work:
+//   long_tile_plan_kernel   lists beyond SORT_CAP_MID entries are SPLIT BY DEPTH into parts of at most that many entries --
+//                           several workgroups per long tile instead of one -- : one workgroup per such tile finds the depth
+//                           range, counts the keys into PLAN_BUCKETS fine buckets (the linear, monotone bucket function of
+//                           bucket_sort), assigns bucket b to part floor(exclusive_prefix(b) / PLAN_PART), counts every part's
+//                           entries per quad list (so that a part knows where its compacted entries go) and appends one
+//                           record per part to a device list.  Parts are contiguous in depth, so the concatenation of the
+//                           sorted parts IS the sorted tile.  A tile whose depths pile up in a bucket (more than
+//                           PLAN_BUCKET_MAX keys) is left to the one-workgroup fallback.
+//   tile_sort_mid_kernel    one 512-thread workgroup per item: a long tile of at most SORT_CAP_MID entries, or one PART of a
+//                           longer one (the part's keys are picked out of the tile's segment into LDS first); bucket_sort,
+//                           sorted list, compacted lists.  48 KB of LDS: two workgroups per CU.
+//   tile_sort_large_kernel  the fallback for what the plan left (97 KB of LDS, one workgroup per CU, the CAP-sized chunk path
+//                           for lists beyond LDS).
+// f(i, key, valid) for every i < round_up(n, NT), NT threads, B independent loads in flight per thread: a plain `for (i = tid;
+// i < n; i += NT)` around an LDS atomic or a ballot waits out one global-load latency per trip (measured: 20 us to plan a
+// 3 400-entry tile with three such sweeps).  Every thread of the workgroup calls f the same number of times (ballots inside).
+template <int B, int NT, typename F>
+__device__ __forceinline__ void for_each_key(const uint64_t* __restrict__ k, uint32_t n, F f)
+{
+    for (uint32_t i0 = 0; i0 < n; i0 += (uint32_t)(B * NT)) {
+        uint64_t v[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * NT + threadIdx.x;
+            v[u] = i < n ? k[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * NT + threadIdx.x;
+            if (i0 + (uint32_t)u * NT < n) f(i, v[u], i < n);   // (uniform condition)
+        }
+    }
+}
+constexpr int PLAN_THREADS = 1024, PLAN_BUCKETS = 4096;
+constexpr uint32_t PLAN_PART = 3072, PLAN_BUCKET_MAX = SORT_CAP_MID - PLAN_PART, PLAN_MAX_PARTS = 512;
+constexpr uint32_t ACT_COUNT_FALLBACK = 0xFFFFFFFFu;   // act_count[tile][0] of a tile the plan left to the fallback kernel
+struct SortPart {   // 64 bytes
+    uint32_t tile, b_lo, b_hi, out_off, count, carry[NUM_LISTS], dmin;
+    float scale;
+    uint32_t pad[4];
+};
+static_assert(sizeof(SortPart) == 64, "SortPart layout");
+__device__ __forceinline__ uint32_t plan_bucket_of(uint64_t key, uint32_t dmin, float scale)
+{
+    return min((uint32_t)((float)((uint32_t)(key >> 32) - dmin) * scale), (uint32_t)PLAN_BUCKETS - 1u);
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS)
+long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint32_t* __restrict__ act_count,
+                      const uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ n_total, SortPart* __restrict__ parts,
+                      uint32_t max_parts)
+{
+    __shared__ uint32_t hist[PLAN_BUCKETS];          // bucket sizes, then their exclusive prefix
+    __shared__ uint16_t part_of[PLAN_BUCKETS];
+    __shared__ uint32_t part_b0[PLAN_MAX_PARTS + 1], part_off[PLAN_MAX_PARTS + 1];
+    __shared__ uint32_t qcnt[PLAN_MAX_PARTS][NUM_LISTS];
+    __shared__ uint32_t red[3 * (PLAN_THREADS / 64)];
+    __shared__ uint32_t base_slot;
+    if (n_total[1] || n_total[6] == 0u) return;  // gate; no list beyond SORT_CAP_MID entries on this frame (counted by the scan)
+    const uint32_t threshold = max(n_total[4], (uint32_t)SORT_CAP_MID);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    constexpr uint32_t NW = PLAN_THREADS / 64, PER = PLAN_BUCKETS / PLAN_THREADS;
+    for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
+        const uint32_t tile = large_tiles[li];
+        const uint2 rg = ranges[tile];
+        const uint32_t s = rg.x, n = rg.y - rg.x;
+        if (n <= threshold) continue;
+        // depth range of the tile
+        uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+        for_each_key<8, PLAN_THREADS>(keys + s, n, [&](uint32_t, uint64_t key, bool valid) {
+            const uint32_t d = (uint32_t)(key >> 32);
+            if (valid) dmin = min(dmin, d), dmax = max(dmax, d);
+        });
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
+            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
+        }
+        if (lane == 0) red[w] = dmin, red[NW + w] = dmax;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) hist[tid * PER + k] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < NW; ++k) dmin = min(dmin, red[k]), dmax = max(dmax, red[NW + k]);
+        const float scale = (float)PLAN_BUCKETS / ((float)(dmax - dmin) + 1.0f);
+        for_each_key<8, PLAN_THREADS>(keys + s, n, [&](uint32_t, uint64_t key, bool valid) {
+            if (valid) atomicAdd(&hist[plan_bucket_of(key, dmin, scale)], 1u);
+        });
+        __syncthreads();
+        // exclusive prefix of the bucket sizes (PER consecutive buckets per thread), largest bucket
+        uint32_t cnt[PER], mine = 0, biggest = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) cnt[k] = hist[tid * PER + k], mine += cnt[k], biggest = max(biggest, cnt[k]);
+        const uint32_t incl = wave_inclusive_scan(mine);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, d, 64));
+        __syncthreads();   // (everybody has read the min / max partials)
+        if (lane == 63) red[w] = incl;
+        if (lane == 0) red[2 * NW + w] = biggest;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < NW; ++k) {
+            if (k < w) before += red[k];
+            biggest = max(biggest, red[2 * NW + k]);
+        }
+        const uint32_t num_parts = (n - 1u) / PLAN_PART + 1u;   // (an upper bound: part ids are floor(prefix / PLAN_PART))
+        if (biggest > PLAN_BUCKET_MAX || num_parts > PLAN_MAX_PARTS) {   // (workgroup-uniform) depths pile up: the fallback kernel
+            if (tid == 0) act_count[tile * NUM_LISTS] = ACT_COUNT_FALLBACK, atomicAdd(&n_total[7], 1u);
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t k = tid; k <= num_parts; k += PLAN_THREADS) part_b0[k] = 0xFFFFFFFFu, part_off[k] = n;
+        for (uint32_t k = tid; k < num_parts * NUM_LISTS; k += PLAN_THREADS) (&qcnt[0][0])[k] = 0u;
+        __syncthreads();
+        uint32_t run = before + incl - mine, prev_p = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t b = tid * PER + k, p = run / PLAN_PART;
+            hist[b] = run;
+            part_of[b] = (uint16_t)p;
+            // first NON-EMPTY bucket of a part: where the part's entries start (a part id is only ever taken by a non-empty
+            // bucket or shared with the next non-empty one, and prefixes grow by at most PLAN_BUCKET_MAX < PLAN_PART per bucket)
+            // (only a bucket that can be its part's first non-empty one tries: the thread's first non-empty bucket, or one whose
+            //  part differs from the thread's previous non-empty bucket's -- every lane trying cost 64-way conflicts)
+            if (cnt[k] && p != prev_p) atomicMin(&part_b0[p], b), atomicMin(&part_off[p], run);
+            if (cnt[k]) prev_p = p;
+            run += cnt[k];
+        }
+        __syncthreads();
+        // every part's entries per quad list.  With a handful of parts every lane of a wave would hit the same few LDS counters
+        // (same-address atomics of one instruction are serialised: 8 us for a 3 400-entry tile): the wave counts with ballots,
+        // part by part, and adds once per (part, list); with many parts the direct atomics spread by themselves.
+        for_each_key<8, PLAN_THREADS>(keys + s, n, [&](uint32_t, uint64_t key, bool valid) {
+            const uint32_t p = valid ? part_of[plan_bucket_of(key, dmin, scale)] : 0xFFFFFFFFu, mask = valid ? (uint32_t)key & 15u : 0u;
+            if (num_parts <= 8u) {
+                unsigned long long todo = __ballot(valid);
+                while (todo) {   // (wave-uniform)
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)__builtin_ctzll(todo));
+                    const bool mine_p = valid && p == p0;
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int q = 0; q < NUM_LISTS; ++q) {
+                        const uint32_t cq = (uint32_t)__popcll(__ballot(mine_p && (q < 4 ? ((mask >> q) & 1u) != 0u : mask != 0u)));
+                        if (lane == (uint32_t)q) c = cq;
+                    }
+                    if (lane < (uint32_t)NUM_LISTS && c) atomicAdd(&qcnt[p0][lane], c);
+                    todo &= ~__ballot(mine_p);
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((mask >> q) & 1u) atomicAdd(&qcnt[p][q], 1u);
+                if (mask) atomicAdd(&qcnt[p][4], 1u);
+            }
+        });
+        if (tid == 0) base_slot = atomicAdd(&n_total[5], num_parts);
+        __syncthreads();
+        // exclusive prefix over the parts, one wave per list (parts without entries -- ids no bucket took -- count as empty)
+        if (w < (uint32_t)NUM_LISTS) {
+            uint32_t carry = 0;
+            for (uint32_t p0 = 0; p0 < num_parts; p0 += 64u) {
+                const uint32_t p = p0 + lane, c = p < num_parts ? qcnt[p][w] : 0u;
+                const uint32_t inc = wave_inclusive_scan(c);
+                if (p < num_parts) qcnt[p][w] = carry + inc - c;
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+            if (lane == 0) act_count[tile * NUM_LISTS + w] = carry;
+        }
+        __syncthreads();
+        const uint32_t slot0 = base_slot;
+        for (uint32_t p = tid; p < num_parts; p += PLAN_THREADS) {
+            if (slot0 + p >= max_parts) continue;   // (cannot happen: the list is sized for N / PLAN_PART + tiles)
+            SortPart r;
+            r.tile = tile, r.dmin = dmin, r.scale = scale;
+            r.out_off = min(part_off[p], n);
+            // the part ends where the next part that HAS entries begins
+            uint32_t nxt = p + 1u;
+            while (nxt < num_parts && part_b0[nxt] == 0xFFFFFFFFu) ++nxt;
+            const uint32_t end_off = nxt < num_parts ? part_off[nxt] : n;
+            r.b_lo = part_b0[p] == 0xFFFFFFFFu ? 0u : part_b0[p];
+            r.b_hi = part_b0[p] == 0xFFFFFFFFu ? 0u : (nxt < num_parts ? part_b0[nxt] : (uint32_t)PLAN_BUCKETS);
+            r.count = part_b0[p] == 0xFFFFFFFFu ? 0u : end_off - r.out_off;
+#pragma unroll
+            for (int q = 0; q < NUM_LISTS; ++q) r.carry[q] = qcnt[p][q];
+            r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0u;
+            parts[slot0 + p] = r;
+        }
+        __syncthreads();   // LDS is reused by the next tile
     }
 }
 
-// Long tiles (more than SORT_CAP_SMALL entries; from LONG_MIN_SPARSE on sparse frames), up to CAP entries: bucket_sort
-// above with 1 024 threads (the bitonic network in registers when the depths pile up in one bucket); beyond CAP entries:
-// chunks sorted in LDS + brute-force ranking through global scratch (slow, but only for absurdly dense tiles).
-constexpr int SORT_LARGE_THREADS = 1024;  // a long tile is one workgroup's job: make it a big one
-template <int CAP>
-__global__ void __launch_bounds__(SORT_LARGE_THREADS)
-tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,
-                       uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
-                       uint32_t* __restrict__ act_count, const uint32_t* __restrict__ large_tiles,
-                       const uint32_t* __restrict__ n_total)
+// Sorts ONE item with a workgroup of NT threads: `n` keys delivered by load_key(i), i < n (n <= CAP, or any n when the item is
+// a whole tile and CAP > SORT_CAP_SMALL: the chunk path); the sorted entries go to list[s_dst + i] with positions pos_base + i + 1,
+// the compacted entries behind carry[] in the tile's list slots (segment start s_tile).  Returns the final carry[] through
+// `carry`.  sh: CAP keys, bucket_start: CAP + 1 words, red: 3 NT / 64 words.
+template <int CAP, int NT, typename LoadKey>
+__device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t s_tile, uint32_t s_dst, uint32_t pos_base,
+                                          uint32_t (&carry)[NUM_LISTS], uint64_t* __restrict__ list, uint64_t* __restrict__ act,
+                                          size_t stride, uint64_t* sh, uint32_t* bucket_start, uint32_t* red)
 {
-    __shared__ uint64_t sh[CAP];
-    __shared__ uint32_t bucket_start[CAP + 1];  // bucket sizes, then (in place) their exclusive scan
-    __shared__ uint32_t red[3 * (SORT_LARGE_THREADS / 64)];
-    if (n_total[1]) return;  // gate
-    const uint32_t threshold = n_total[4];
-    // a fixed, small grid walks the (usually empty) list of long-tile candidates that tile_scan_kernel made
-    for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
-    const uint32_t tile = large_tiles[li];
-    const uint2 rg = ranges[tile];
-    const uint32_t s = rg.x, n = rg.y - rg.x;
-    bool sorted_in_lds = false;  // (workgroup-uniform)
-    if (n <= threshold) continue;  // (a candidate that is not long on this -- dense -- frame: the small-tile kernel sorts it)
-    // bitonic sort of up to CAP keys in LDS; `count` keys from `src`, result left in sh[0..count)
-    auto sort_in_lds = [&](const uint64_t* src, uint32_t count) {
+    bool sorted_in_lds = true;  // (workgroup-uniform)
+    // the register network of the small tiles with NT threads: lane distances below 64 by DPP, only distances 64..NT/2 through
+    // LDS -- a fifth of the barriers of an all-LDS bitonic sort
+    auto in_registers = [&](auto e_tag) {
+        constexpr int E = decltype(e_tag)::value;
+        uint64_t key[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = (uint32_t)e * NT + threadIdx.x;
+            key[e] = i < n ? load_key(i) : ~0ull;
+        }
+        bitonic_in_registers<E, NT>(key, sh);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = (uint32_t)e * NT + threadIdx.x;
+            if (i < n) list[s_dst + i] = list_entry(key[e], pos_base + i + 1u);
+        }
+    };
+    // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket), with as many
+    // keys -- and buckets -- per thread as the list needs: a 1 100-entry list does not pay for 8 192 buckets ----
+    auto by_buckets = [&](auto e_tag) {
+        constexpr int E = decltype(e_tag)::value;
+        uint64_t key[E];
+        uint32_t pos[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = (uint32_t)e * NT + threadIdx.x;
+            key[e] = i < n ? load_key(i) : ~0ull;
+        }
+        if (!bucket_sort<E, NT>(key, pos, n, sh, bucket_start, red)) return false;
+        __syncthreads();  // every thread has ranked its keys: the bucketed copy in LDS may be overwritten ...
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((uint32_t)e * NT + threadIdx.x < n) {
+                const uint64_t entry = list_entry(key[e], pos_base + pos[e] + 1u);
+                list[s_dst + pos[e]] = entry;
+                sh[pos[e]] = entry;  // ... by the sorted list itself: the compaction below reads it from here
+            }
+        return true;
+    };
+    bool done;
+    constexpr int EMAX = CAP / NT;
+    if (n <= 1u * NT) done = by_buckets(std::integral_constant<int, 1>{});
+    else if (EMAX >= 2 && n <= 2u * NT) done = by_buckets(std::integral_constant<int, (EMAX >= 2 ? 2 : 1)>{});
+    else if (EMAX >= 4 && n <= 4u * NT) done = by_buckets(std::integral_constant<int, (EMAX >= 4 ? 4 : 1)>{});
+    else done = by_buckets(std::integral_constant<int, EMAX>{});
+    if (!done) {
+        sorted_in_lds = false;
+        if (EMAX >= 4 && n <= 4u * NT) in_registers(std::integral_constant<int, (EMAX >= 4 ? 4 : EMAX)>{});
+        else in_registers(std::integral_constant<int, EMAX>{});
+    }
+    // the item is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it chunk by
+    // chunk (the bucket array is free by now: the compaction's scratch)
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t entry = i < n ? (sorted_in_lds ? sh[i] : __builtin_nontemporal_load(&list[s_dst + i])) : 0ull;
+        compact_chunk<NT / 64>(entry, i < n, carry, s_tile, act, stride, bucket_start);
+    }
+}
+
+// A list LONGER than a workgroup's LDS, by ONE workgroup (the slow way out: the plan kernel normally splits such lists into parts
+// for many workgroups): CAP-sized chunks are sorted in LDS into `scratch`, then every key finds its final position as its index
+// in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are distinct: they embed the
+// Gaussian index).  O(n (n/CAP) log CAP) instead of a global merge network.  Then the compaction, from global memory.
+template <int CAP, int NT>
+__device__ __forceinline__ void sort_in_chunks(const uint64_t* __restrict__ src, uint32_t n, uint32_t s, uint64_t* __restrict__ list,
+                                               uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride,
+                                               uint32_t (&carry)[NUM_LISTS], uint64_t* sh, uint32_t* sh32)
+{
+    auto sort_in_lds = [&](const uint64_t* from, uint32_t count) {
         uint32_t m = 2;
         while (m < count) m <<= 1;
-        for (uint32_t i = threadIdx.x; i < m; i += SORT_LARGE_THREADS) sh[i] = i < count ? src[i] : ~0ull;
+        for (uint32_t i = threadIdx.x; i < m; i += NT) sh[i] = i < count ? from[i] : ~0ull;
         __syncthreads();
         for (uint32_t k = 2; k <= m; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t c = threadIdx.x; c < (m >> 1); c += SORT_LARGE_THREADS) {
+                for (uint32_t c = threadIdx.x; c < (m >> 1); c += NT) {
                     const uint32_t l = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), r = l | j;
                     const uint64_t a = sh[l], b = sh[r];
                     if ((a > b) == ((l & k) == 0u)) sh[l] = b, sh[r] = a;
@@ -890,118 +1240,158 @@ tile_sort_large_kernel(const uint2* __restrict__ ranges, const uint64_t* __restr
                 __syncthreads();
             }
     };
-    if (n <= (uint32_t)CAP) {
-        // the register network of the small tiles with 1024 threads (4 or 8 keys each): lane distances below 64 by DPP,
-        // only distances 64..512 through LDS -- a fifth of the barriers of an all-LDS bitonic sort
-        auto in_registers = [&](auto e_tag) {
-            constexpr int E = decltype(e_tag)::value;
-            uint64_t key[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                key[e] = i < n ? keys[s + i] : ~0ull;
-            }
-            bitonic_in_registers<E, SORT_LARGE_THREADS>(key, sh);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                if (i < n) list[s + i] = list_entry(key[e], i + 1u);
-            }
-        };
-        // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket), with as many
-        // keys -- and buckets -- per thread as the list needs: a 1 100-entry list does not pay for 8 192 buckets ----
-        auto by_buckets = [&](auto e_tag) {
-            constexpr int E = decltype(e_tag)::value;
-            uint64_t key[E];
-            uint32_t pos[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t i = (uint32_t)e * SORT_LARGE_THREADS + threadIdx.x;
-                key[e] = i < n ? keys[s + i] : ~0ull;
-            }
-            if (!bucket_sort<E, SORT_LARGE_THREADS>(key, pos, n, sh, bucket_start, red)) return false;
-            __syncthreads();  // every thread has ranked its keys: the bucketed copy in LDS may be overwritten ...
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if ((uint32_t)e * SORT_LARGE_THREADS + threadIdx.x < n) {
-                    const uint64_t entry = list_entry(key[e], pos[e] + 1u);
-                    list[s + pos[e]] = entry;
-                    sh[pos[e]] = entry;  // ... by the sorted list itself: the compaction below reads it from here
-                }
-            return true;
-        };
-        sorted_in_lds = true;
-        const bool done = n <= 2u * SORT_LARGE_THREADS   ? by_buckets(std::integral_constant<int, 2>{})
-                          : n <= 4u * SORT_LARGE_THREADS ? by_buckets(std::integral_constant<int, 4>{})
-                                                         : by_buckets(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
-        if (!done) {
-            sorted_in_lds = false;
-            if (n <= 4u * SORT_LARGE_THREADS) in_registers(std::integral_constant<int, 4>{});
-            else in_registers(std::integral_constant<int, CAP / SORT_LARGE_THREADS>{});
-        }
-    } else {
-        // Longer than LDS: sort CAP-sized chunks in LDS into `scratch`, then every key finds its final position as its
-        // index in its own chunk plus, by binary search, the number of smaller keys in every other chunk (keys are
-        // distinct: they embed the Gaussian index).  O(n (n/CAP) log CAP) instead of a global merge network.
-        const uint32_t chunks = (n + CAP - 1u) / CAP;
+    const uint32_t chunks = (n + CAP - 1u) / CAP;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        const uint32_t c0 = c * CAP, cn = min((uint32_t)CAP, n - c0);
+        sort_in_lds(src + c0, cn);
+        for (uint32_t i = threadIdx.x; i < cn; i += NT) scratch[s + c0 + i] = sh[i];
+        __syncthreads();
+    }
+    __threadfence_block();
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
+        const uint64_t ki = __builtin_nontemporal_load(&scratch[s + i]);
+        const uint32_t own = i / CAP;
+        uint32_t rank = i - own * CAP;
         for (uint32_t c = 0; c < chunks; ++c) {
-            const uint32_t c0 = c * CAP, cn = min((uint32_t)CAP, n - c0);
-            sort_in_lds(keys + s + c0, cn);
-            for (uint32_t i = threadIdx.x; i < cn; i += SORT_LARGE_THREADS) scratch[s + c0 + i] = sh[i];
-            __syncthreads();
-        }
-        __threadfence_block();
-        for (uint32_t i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) {
-            const uint64_t ki = __builtin_nontemporal_load(&scratch[s + i]);
-            const uint32_t own = i / CAP;
-            uint32_t rank = i - own * CAP;
-            for (uint32_t c = 0; c < chunks; ++c) {
-                if (c == own) continue;
-                const uint64_t* ch = scratch + s + c * CAP;
-                uint32_t lo = 0, hi = min((uint32_t)CAP, n - c * CAP);  // first index whose key is >= ki
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (__builtin_nontemporal_load(&ch[mid]) < ki) lo = mid + 1; else hi = mid;
-                }
-                rank += lo;
+            if (c == own) continue;
+            const uint64_t* ch = scratch + s + c * CAP;
+            uint32_t lo = 0, hi = min((uint32_t)CAP, n - c * CAP);  // first index whose key is >= ki
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (__builtin_nontemporal_load(&ch[mid]) < ki) lo = mid + 1; else hi = mid;
             }
-            list[s + rank] = list_entry(ki, rank + 1u);
+            rank += lo;
         }
+        list[s + rank] = list_entry(ki, rank + 1u);
     }
-    // the segment is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it
-    // chunk by chunk (the bucket array is free by now: the compaction's scratch)
     __syncthreads();
-    uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
-    for (uint32_t base = 0; base < n; base += SORT_LARGE_THREADS) {
+    for (uint32_t base = 0; base < n; base += NT) {
         const uint32_t i = base + threadIdx.x;
-        const uint64_t entry = i < n ? (sorted_in_lds ? sh[i] : __builtin_nontemporal_load(&list[s + i])) : 0ull;
-        compact_chunk<SORT_LARGE_THREADS / 64>(entry, i < n, carry, s, act, stride, bucket_start);
+        const uint64_t entry = i < n ? __builtin_nontemporal_load(&list[s + i]) : 0ull;
+        compact_chunk<NT / 64>(entry, i < n, carry, s, act, stride, sh32);
     }
+}
+
+constexpr int SORT_MID_THREADS = 512;     // two or three such workgroups per CU whatever registers the body takes
+constexpr int SORT_LARGE_THREADS = 1024;  // the fallback: a long tile is one workgroup's job, make it a big one
+#define LARGE_SORT_ARGS const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ list,            \
+                        uint64_t* __restrict__ scratch, uint64_t* __restrict__ act, size_t stride, uint32_t* __restrict__ act_count, \
+                        const uint32_t* __restrict__ large_tiles, const uint32_t* __restrict__ n_total, const SortPart* __restrict__ parts, \
+                        int planned
+
+__global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_per_eu(4))) tile_sort_mid_kernel(LARGE_SORT_ARGS)   // (<= 128 VGPRs: two workgroups per CU)
+{
+    constexpr int CAP = SORT_CAP_MID, NT = SORT_MID_THREADS;
+    __shared__ uint64_t sh[CAP];
+    __shared__ uint32_t bucket_start[CAP + 1];  // bucket sizes, then (in place) their exclusive scan
+    __shared__ uint32_t red[3 * (NT / 64)];
+    __shared__ uint32_t picked;
+    if (n_total[1]) return;  // gate
+    const uint32_t threshold = n_total[4], n_cand = n_total[2], n_items = n_cand + (planned ? n_total[5] : 0u);
+    // a fixed grid walks the candidate tiles that tile_scan_kernel listed, then the parts the plan kernel made
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
+        if (it < n_cand) {
+            const uint32_t tile = large_tiles[it];
+            const uint2 rg = ranges[tile];
+            const uint32_t s = rg.x, n = rg.y - rg.x;
+            if (n <= threshold || (planned && n > (uint32_t)CAP)) continue;   // (not long on this frame / the plan's or the fallback's)
+            // (!planned: the plan and fallback kernels were not launched -- the stream's last frame had no list beyond CAP entries --
+            //  and this frame has one after all: sorted here, slowly, this once)
+            if (n > (uint32_t)CAP) sort_in_chunks<CAP, NT>(keys + s, n, s, list, scratch, act, stride, carry, sh, bucket_start);
+            else sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red);
 #pragma unroll
-    for (int q = 0; q < NUM_LISTS; ++q)
-        if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
-    __syncthreads();  // sh is reused by the next tile
+            for (int q = 0; q < NUM_LISTS; ++q)
+                if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
+        } else {
+            const SortPart r = parts[it - n_cand];
+            if (r.count == 0u) continue;
+            const uint2 rg = ranges[r.tile];
+            const uint32_t s = rg.x, n_tile = rg.y - rg.x;
+            // pick the part's keys out of the tile's segment (any order: they are sorted next)
+            if (threadIdx.x == 0) picked = 0u;
+            __syncthreads();
+            for_each_key<8, NT>(keys + s, n_tile, [&](uint32_t, uint64_t k, bool valid) {   // (one LDS atomic per wave, not per key: they all hit one counter)
+                const uint32_t b = plan_bucket_of(k, r.dmin, r.scale);
+                const bool take = valid && b >= r.b_lo && b < r.b_hi;
+                const unsigned long long m = __ballot(take);
+                uint32_t at0 = 0;
+                if ((threadIdx.x & 63u) == 0u && m) at0 = atomicAdd(&picked, (uint32_t)__popcll(m));
+                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                const uint32_t at = at0 + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                if (take && at < (uint32_t)CAP) sh[at] = k;
+            });
+            __syncthreads();
+            const uint32_t n = min(r.count, (uint32_t)CAP);   // (== picked)
+#pragma unroll
+            for (int q = 0; q < NUM_LISTS; ++q) carry[q] = r.carry[q];
+            sort_item<CAP, NT>([&](uint32_t i) { return sh[i]; }, n, s, s + r.out_off, r.out_off, carry, list, act, stride, sh, bucket_start, red);
+        }
+        __syncthreads();  // sh is reused by the next item
+    }
+}
+
+// fallback: the tiles the plan kernel flagged (depths piling up in one of its buckets, or more parts than it can describe)
+__global__ void __launch_bounds__(SORT_LARGE_THREADS) tile_sort_large_kernel(LARGE_SORT_ARGS)
+{
+    constexpr int CAP = SORT_CAP_LARGE, NT = SORT_LARGE_THREADS;
+    __shared__ uint64_t sh[CAP];
+    __shared__ uint32_t bucket_start[CAP + 1];
+    __shared__ uint32_t red[3 * (NT / 64)];
+    if (n_total[1] || n_total[7] == 0u) return;  // gate; the plan left nothing
+    const uint32_t threshold = max(n_total[4], (uint32_t)SORT_CAP_MID);
+    for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
+        const uint32_t tile = large_tiles[li];
+        const uint2 rg = ranges[tile];
+        const uint32_t s = rg.x, n = rg.y - rg.x;
+        if (n <= threshold || act_count[tile * NUM_LISTS] != ACT_COUNT_FALLBACK) continue;
+        uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
+        if (n <= (uint32_t)CAP)
+            sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red);
+        else
+            sort_in_chunks<CAP, NT>(keys + s, n, s, list, scratch, act, stride, carry, sh, bucket_start);
+#pragma unroll
+        for (int q = 0; q < NUM_LISTS; ++q)
+            if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
+        __syncthreads();  // sh is reused by the next tile
     }
 }
 
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, bool small_tiles, bool long_tiles, const FusedBlend* fb, hipStream_t st)
+                      uint32_t* n_total, void* parts, uint32_t max_parts, bool small_tiles, bool long_tiles, const FusedBlend* fb,
+                      const FrameHistory& hist, hipStream_t st)
 {
+    const bool plan_huge = hist.n_huge != 0;   // (-1: unknown)
     // The long-tile kernel goes FIRST: the small-tile kernel then blends (fused) the long tiles too, from the lists this
     // one wrote.  It walks a device-built list that is empty on most frames: the caller skips its launch when the previous
     // frame of this shape had no long tile, and runs it (and the long tiles' forward blend) later when that guess was wrong.
-    if (long_tiles)
-        hipLaunchKernelGGL(tile_sort_large_kernel<SORT_CAP_LARGE>, dim3(num_tiles < 256 ? num_tiles : 256), dim3(SORT_LARGE_THREADS), 0, st, ranges,
-                           keys, list, scratch, act, stride, act_count, large_tiles, n_total);
+    if (long_tiles) {
+        // Lists beyond SORT_CAP_MID entries are rare: the plan and fallback kernels are launched only when the stream's last frame
+        // had one (or nothing is known); a frame that has one unannounced is sorted by the mid kernel's slow path, this once.
+        const int wgs = num_tiles < 256 ? num_tiles : 256;
+        if (plan_huge)
+            hipLaunchKernelGGL(long_tile_plan_kernel, dim3(wgs), dim3(PLAN_THREADS), 0, st, ranges, keys, act_count, large_tiles, n_total,
+                               (SortPart*)parts, max_parts);
+        hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(512), dim3(SORT_MID_THREADS), 0, st, ranges, keys, list, scratch, act, stride,
+                           act_count, large_tiles, n_total, (const SortPart*)parts, plan_huge ? 1 : 0);
+        if (plan_huge)
+            hipLaunchKernelGGL(tile_sort_large_kernel, dim3(wgs), dim3(SORT_LARGE_THREADS), 0, st, ranges, keys, list, scratch, act, stride,
+                               act_count, large_tiles, n_total, (const SortPart*)parts, 1);
+    }
     if (small_tiles) {
-        if (fb)
-            hipLaunchKernelGGL(tile_sort_small_kernel<true>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                               n_total + 1, fb->cam, fb->lastg, fb->splats, fb->bg, fb->out_color, fb->final_T, fb->n_contrib, fb->clamp_output,
-                               long_tiles ? 1 : 0, fb->ck);
-        else
-            hipLaunchKernelGGL(tile_sort_small_kernel<false>, dim3(num_tiles), dim3(256), 0, st, ranges, keys, list, act, stride, act_count,
-                               n_total + 1, Camera{}, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0, long_tiles ? 1 : 0, Ckpt{});
+        FusedKernelArgs ka{ranges, keys, list, act, stride, act_count, n_total + 1, Camera{}, 0u, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           0, long_tiles ? 1 : 0, Ckpt{}, large_tiles, 0u};
+        if (fb) {
+            // one worker workgroup per (long tile, quad) of the stream's last frame, and a quarter more: workgroups without an item
+            // still occupy a slot while they find that out, in front of the tiles' workgroups
+            uint32_t workers = long_tiles && deep_forward_enabled() ? deep_workers_for(num_tiles) : 0u;
+            if (workers && hist.n_long >= 0) workers = min(workers, (uint32_t)(5 * hist.n_long + 64 + 7) & ~7u);
+            ka.cam = fb->cam, ka.lastg = fb->lastg, ka.splats = fb->splats, ka.bg = fb->bg, ka.out_color = fb->out_color, ka.final_T = fb->final_T;
+            ka.n_contrib = fb->n_contrib, ka.clamp_output = fb->clamp_output, ka.ck = fb->ck, ka.num_workers = workers;
+            hipLaunchKernelGGL(tile_sort_small_kernel<true>, dim3(workers + num_tiles), dim3(256), 0, st, ka);
+        } else
+            hipLaunchKernelGGL(tile_sort_small_kernel<false>, dim3(num_tiles), dim3(256), 0, st, ka);
     }
 }
 

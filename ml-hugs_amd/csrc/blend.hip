@@ -33,39 +33,81 @@
 
 namespace hgs {
 
-// Stand-alone forward: workgroup b = tile b (all tiles), or -- tile_list != nullptr -- a fixed grid walking the device-built
-// list of LONG tiles (more than 2048 entries: the fused sort + blend kernel of binning.hip leaves those to the long-tile
-// sort and this kernel).
+// Stand-alone forward (HGS_FUSED_SORT_BLEND=0, and the repair of a wrong "no long tiles" guess): the first `num_workers`
+// workgroups blend the LONG tiles' quads split by depth (deep_forward_worker, blend_fwd.h: the same code path as in the fused
+// sort + blend kernel of binning.hip, so a frame's image does not depend on which kernel blended it); behind them -- all_tiles --
+// workgroup b = tile b, one wave per quad, for every tile that is not long.
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
                      size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats, const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ gate,
-                     int clamp_output, const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ tile_list_len, Ckpt ck)
+                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ n_total,
+                     int clamp_output, const uint32_t* __restrict__ large_tiles, uint32_t num_workers, int long_sorted, Ckpt ck)
 {
-    if (*(const_u32p)gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t count = tile_list ? *(const_u32p)tile_list_len : (uint32_t)(cam.gx * cam.gy);
-    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        const int tile = tile_list ? (int)((const_u32p)tile_list)[k] : (int)k;
-        const v2u range = ((const_u2p)ranges)[tile];
-        const uint32_t n = range.y > range.x ? ((const_u32p)act_count)[tile * NUM_LISTS + w] : 0u;
-        float4* ck_tile = ckpt_begin(ck, (uint32_t)tile, range.y > range.x ? range.y - range.x : 0u);
-        blend_forward_wave(cam, lastg, tile % cam.gx, tile / cam.gx, w, n, act + (size_t)w * act_stride + range.x, splats, bg, out_color,
-                           final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + (uint32_t)tile * 4u + (uint32_t)w);
+    __shared__ DeepShared deep;
+    if (((const_u32p)n_total)[1]) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
+    const bool deep_blend = num_workers != 0u && ((const_u32p)n_total)[8] != 0u;   // (the scan's decision: binning.hip)
+    if (blockIdx.x < num_workers) {
+        if (!deep_blend) {
+            // a shallow sparse frame: one wave per quad blends the long tiles too -- in the repair pass (workers only in the
+            // grid) the workers take them that way, four waves = four quads of one tile each
+            if (gridDim.x != num_workers) return;
+            const uint32_t count = ((const_u32p)n_total)[2], threshold = ((const_u32p)n_total)[4];
+            const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            for (uint32_t li = blockIdx.x; li < count; li += num_workers) {
+                const uint32_t tile = ((const_u32p)large_tiles)[li];
+                const v2u range = ((const_u2p)ranges)[tile];
+                if (range.y - range.x <= threshold) continue;
+                float4* ck_tile = ckpt_begin(ck, tile, range.y - range.x);
+                blend_forward_wave(cam, lastg, (int)(tile % (uint32_t)cam.gx), (int)(tile / (uint32_t)cam.gx), w,
+                                   ((const_u32p)act_count)[tile * NUM_LISTS + w], act + (size_t)w * act_stride + range.x, splats, bg, out_color,
+                                   final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + tile * 4u + (uint32_t)w);
+            }
+            return;
+        }
+        deep_forward_worker(blockIdx.x, num_workers, cam, lastg, ranges, act, act_stride, act_count, splats, bg, out_color, final_T,
+                            n_contrib, clamp_output, ck, large_tiles, n_total, deep, gridDim.x == num_workers);
+        return;
     }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (int)(blockIdx.x - num_workers);
+    const v2u range = ((const_u2p)ranges)[tile];
+    const uint32_t n_tile = range.y > range.x ? range.y - range.x : 0u;
+    if (n_tile > ((const_u32p)n_total)[4]) {
+        // a long tile: the workers have it -- or, when the long-tile sort was skipped on the caller's guess, nobody yet (its
+        // pixels stay unwritten until the caller has repaired the guess)
+        if (!long_sorted) return;
+        if (deep_blend) {
+            ckpt_begin(ck, (uint32_t)tile, n_tile);
+            return;
+        }
+    }
+    else if (long_sorted == 2) return;  // (only the long tiles: the repair pass without workers)
+    const uint32_t n = n_tile ? ((const_u32p)act_count)[tile * NUM_LISTS + w] : 0u;
+    float4* ck_tile = ckpt_begin(ck, (uint32_t)tile, n_tile);
+    blend_forward_wave(cam, lastg, tile % cam.gx, tile / cam.gx, w, n, act + (size_t)w * act_stride + range.x, splats, bg, out_color,
+                       final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + (uint32_t)tile * 4u + (uint32_t)w);
 }
 
+// all_tiles: every tile (long ones through the workers when long_sorted); else only the long tiles (the repair)
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output,
-                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, const Ckpt& ck, hipStream_t st)
+                          float* final_T, uint32_t* n_contrib, const uint32_t* n_total, bool clamp_output,
+                          const uint32_t* large_tiles, bool all_tiles, bool long_sorted, const Ckpt& ck, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;
-    // (over the long-tile list the grid is still one workgroup per tile of the frame -- the host does not know how many are
-    // long; workgroups beyond the list's length leave at once)
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1),
-                       ranges, act, act_stride, act_count, splats, bg, out_color, final_T, n_contrib, gate, clamp_output ? 1 : 0,
-                       long_tiles, n_long_tiles, ck);
+    const bool deep = deep_forward_enabled();
+    const uint32_t workers = long_sorted && deep ? deep_workers_for(tiles) : 0u;
+    if (!all_tiles && !deep) {
+        // the repair of a wrong "no long tiles" guess without the depth-parallel path: every tile's workgroup starts and those
+        // of the tiles that are not long leave at once (the host does not know which tiles are long)
+        hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act, act_stride, act_count,
+                           splats, bg, out_color, final_T, n_contrib, n_total, clamp_output ? 1 : 0, large_tiles, 0u, 2, ck);
+        return;
+    }
+    if (workers + (all_tiles ? tiles : 0) == 0) return;
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(workers + (all_tiles ? tiles : 0)), dim3(256), 0, st, cam, (uint32_t)(P - 1),
+                       ranges, act, act_stride, act_count, splats, bg, out_color, final_T, n_contrib, n_total, clamp_output ? 1 : 0,
+                       large_tiles, workers, long_sorted ? 1 : 0, ck);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -266,6 +266,35 @@ int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, TileCoun
     return HGS_OK;
 }
 
+// Launch-size memory per (device, stream, frame shape): a small direct-mapped table, overwritten on collision (hints only).
+// (The shape belongs to the key: a HUGS step renders the joint frame and the human-only frame in turn on one stream.)
+struct HistKey {
+    int dev; hipStream_t st; int P, H, W;
+    bool operator==(const HistKey& o) const { return dev == o.dev && st == o.st && P == o.P && H == o.H && W == o.W; }
+};
+struct HistEntry { HistKey k{-1, nullptr, 0, 0, 0}; FrameHistory h; };
+std::mutex g_hist_mu;
+HistEntry g_hist[128];
+size_t hist_slot(const HistKey& k)
+{
+    size_t h = std::hash<const void*>()((const void*)k.st);
+    for (int v : {k.dev, k.P, k.H, k.W}) h = h * 1000003u + (size_t)v;
+    return h % 128u;
+}
+FrameHistory history_get(const HistKey& k)
+{
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    const HistEntry& e = g_hist[hist_slot(k)];
+    return e.k == k ? e.h : FrameHistory{};
+}
+void history_put(const HistKey& k, const HostSlot& hs)
+{
+    FrameHistory h;
+    h.n_long = (int32_t)hs.word[1], h.n_huge = (int32_t)hs.word[2];   // (written by tile_scan_kernel before the word that carries the ticket)
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    g_hist[hist_slot(k)] = HistEntry{k, h};
+}
+
 // 1: N and flags read; 0: not there yet; -1: expired
 int slot_ready(const HostSlot& hs, uint32_t* n_out, bool* sparse_out, bool* long_out)
 {
@@ -424,6 +453,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     const int num_tiles = cam.gx * cam.gy;
     const int Ptot = a.P + a.seg2.P;  // Gaussian indices run over both segments
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const HistKey hkey{dev, st, Ptot, cam.H, cam.W};
+    FrameHistory hist = history_get(hkey);   // (refreshed below when this frame's own counts arrive before it is enqueued)
     GeomLayout gl(Ptot, num_tiles);
     ImageLayout il(cam.H, cam.W);
     // caller-provided scratch when it suffices, else the allocation callback
@@ -508,11 +541,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, (uint64_t*)(bin + bl.keys), (uint64_t*)(bin + bl.list), (uint64_t*)(bin + bl.scratch), act,
-                           bl.act_stride, act_count, large_tiles, n_total, false, true, nullptr, st); }
+                           bl.act_stride, act_count, large_tiles, n_total, bin + bl.parts, (uint32_t)bl.max_parts, false, true, nullptr, FrameHistory{}, st); }
         STAGE_CHECK(dbg, st, "tile_sort (long tiles)");
         { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-          launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
-                               a.clamp_output != 0, large_tiles, n_total + 2, fb.ck, st); }
+          launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, n_total,
+                               a.clamp_output != 0, large_tiles, false, true, fb.ck, st); }
         STAGE_CHECK(dbg, st, "blend_forward (long tiles)");
         return HGS_OK;
     };
@@ -530,13 +563,13 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         STAGE_CHECK(dbg, st, "emit");
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total,
-                           true, with_long_tiles, fused ? &fb : nullptr, st); }
+                           bin + bl.parts, (uint32_t)bl.max_parts, true, with_long_tiles, fused ? &fb : nullptr, hist, st); }
         STAGE_CHECK(dbg, st, fused ? "tile_sort + blend_forward" : "tile_sort");
         if (!fused) {
             // (when the long-tile sort was skipped, long tiles read as empty here: they are blended by the repair)
             { ProfScope ps(HGS_STAGE_BLEND_FORWARD, st);
-              launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, gate,
-                                   a.clamp_output != 0, nullptr, nullptr, fb.ck, st); }
+              launch_blend_forward(cam, Ptot, ranges, act, bl.act_stride, act_count, splats, a.s.bg, a.out_color, final_T, n_contrib, n_total,
+                                   a.clamp_output != 0, large_tiles, true, with_long_tiles, fb.ck, st); }
             STAGE_CHECK(dbg, st, "blend_forward");
         }
         return HGS_OK;
@@ -557,6 +590,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t n32 = 0;
     bool sparse = false, has_long = false;
     if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long)) return rc;
+    history_put(hkey, slot);
+    hist = history_get(hkey);
     if (n32 == 0xFFFFFFFFu) return too_many_pairs();  // (every kernel behind the scan was gated off)
     const int64_t N = (int64_t)n32;
     state->num_rendered = N;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hgs_rasterizer.h"
 
@@ -158,8 +159,10 @@ struct CkptLayout {
     }
 };
 struct BinningLayout {
-    size_t keys, list, scratch, act, total;
+    size_t keys, list, scratch, act, parts, total;
     size_t act_stride;  // entries between consecutive compacted-list arrays
+    size_t max_parts;   // 64-byte records of the long-tile plan (binning.hip): a list beyond 4 096 entries is sorted in parts of
+                        // 3 072 .. 4 096 entries by several workgroups
     explicit BinningLayout(int64_t N) {
         size_t n = (size_t)(N < 1 ? 1 : N);
         size_t o = 0;
@@ -171,6 +174,8 @@ struct BinningLayout {
         // between arrays and at both ends: the blend kernels prefetch a few entries past either end of a list.
         act_stride = n + ACT_PAD;
         act = o;        o = align_up(o + 8 * (NUM_LISTS * act_stride + 2 * ACT_PAD));
+        max_parts = n / 2048 + 64;   // (a part holds > 2 048 entries but for a tile's last one: at most n / 4096 of those)
+        parts = o;      o = align_up(o + 64 * max_parts);
         total = o;
     }
 };
@@ -209,14 +214,22 @@ struct FusedBlend {
     Camera cam; uint32_t lastg; const Splat* splats; const float* bg; float* out_color; float* final_T; uint32_t* n_contrib; int clamp_output;
     Ckpt ck;
 };
+// What the library remembers of a stream's last frame (hgs_api.hip): launch-size hints only -- results never depend on them.
+struct FrameHistory { int32_t n_long = -1, n_huge = -1; };   // lists that were long / beyond 4 096 entries; -1: unknown
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
-                      const uint32_t* n_total, bool small_tiles, bool long_tiles, const FusedBlend* fb, hipStream_t st);
+                      uint32_t* n_total, void* parts, uint32_t max_parts, bool small_tiles, bool long_tiles, const FusedBlend* fb,
+                      const FrameHistory& hist, hipStream_t st);
 
+// Workgroups that blend the long tiles' quads by depth (blend_fwd.h): at the FRONT of the grid of the kernel that blends the
+// other tiles (a multiple of 8: the tile -> XCD mapping behind them stays what it is without them).
+inline uint32_t deep_workers_for(int num_tiles) { const uint32_t w = 4u * (uint32_t)num_tiles; return (w < 2048u ? w : 2048u) + 7u & ~7u; }
+// HGS_DEEP_FORWARD=0: long tiles are blended by one wave per quad like any other tile (A/B measurements, parity tests)
+inline bool deep_forward_enabled() { const char* e = getenv("HGS_DEEP_FORWARD"); return !(e && e[0] == '0'); }
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
-                          float* final_T, uint32_t* n_contrib, const uint32_t* gate, bool clamp_output,
-                          const uint32_t* long_tiles, const uint32_t* n_long_tiles, const Ckpt& ck, hipStream_t st);
+                          float* final_T, uint32_t* n_contrib, const uint32_t* n_total, bool clamp_output,
+                          const uint32_t* large_tiles, bool all_tiles, bool long_sorted, const Ckpt& ck, hipStream_t st);
 // grad_accum: [P][12] floats, zero on entry: mean2D.x, mean2D.y, conic xx, xy, yy, opacity, r, g, b, pad x3
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,

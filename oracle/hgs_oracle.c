@@ -379,9 +379,11 @@ void oracle_blend_forward(int H, int W, const uint32_t *ranges, const uint32_t *
     }
 }
 
-/* K7: back-to-front pixel backward (A.5 pixel part).  Sums are accumulated in double
-   (per-thread partials, combined in thread order) so the checker is as order-insensitive
-   as possible; outputs are rounded to `real` once. Outputs are OVERWRITTEN.
+/* K7: back-to-front pixel backward (A.5 pixel part).  Sums are accumulated in double so the checker is as
+   order-insensitive as possible; outputs are rounded to `real` once.  A tile sums its 256 pixels' contributions per LIST
+   ENTRY in a tile-local array first and then adds each entry's nine sums to the Gaussian's shared double accumulator with
+   `omp atomic` -- one P x 9 array whatever the thread count (round 3 kept one per thread: 461 MB at 32 threads, which is
+   what capped the CPU baseline at 32 of the host's cores).  Outputs are OVERWRITTEN.
    dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (slots x,y,.,w), dL_dopacity [P], dL_dcolor [P,3] */
 void oracle_blend_backward(int P, int H, int W, const uint32_t *ranges, const uint32_t *values,
                            const real *xy, const real *conic_opacity, const real *rgb, const real *bg,
@@ -389,73 +391,86 @@ void oracle_blend_backward(int P, int H, int W, const uint32_t *ranges, const ui
                            real *dL_dmean2D, real *dL_dconic, real *dL_dopacity, real *dL_dcolor)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    int nthreads = 1;
-#ifdef _OPENMP
-    nthreads = omp_get_max_threads();
-#endif
-    const size_t stride = (size_t)P * 9;
-    double *acc = (double *)calloc(stride * (size_t)nthreads, sizeof(double));
+    double *acc = (double *)calloc((size_t)P * 9 + 1, sizeof(double));
     const real ddelx_dx = R_(0.5) * (real)W, ddely_dy = R_(0.5) * (real)H;
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int tile = 0; tile < gx * gy; ++tile) {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        double *A = acc + stride * (size_t)tid;
-        const int tx = tile % gx, ty = tile / gx;
-        const uint32_t s = ranges[2 * tile];
-        for (int ly = 0; ly < TILE; ++ly)
-            for (int lx = 0; lx < TILE; ++lx) {
-                const int px = tx * TILE + lx, py = ty * TILE + ly;
-                if (px >= W || py >= H) continue;
-                const size_t pix = (size_t)py * W + px;
-                const real T_final = final_T[pix];
-                real T = T_final;
-                const real g0 = dL_dpix[pix], g1 = dL_dpix[(size_t)H * W + pix], g2 = dL_dpix[2 * (size_t)H * W + pix];
-                const real bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-                real ar0 = 0, ar1 = 0, ar2 = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_alpha = 0;
-                for (int64_t j = (int64_t)s + (int64_t)n_contrib[pix] - 1; j >= (int64_t)s; --j) {
-                    const uint32_t g = values[j];
-                    const real dx = xy[2 * g] - (real)px, dy = xy[2 * g + 1] - (real)py;
-                    const real *co = conic_opacity + 4 * g;
-                    const real power = R_(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0) continue;
-                    const real G = rexp_(power);
-                    const real alpha = rmin(R_(0.99), co[3] * G);
-                    if (alpha < R_(1.0) / R_(255.0)) continue;
-                    T = T / (R_(1) - alpha);
-                    const real dch = alpha * T;
-                    const real c0 = rgb[3 * g], c1 = rgb[3 * g + 1], c2 = rgb[3 * g + 2];
-                    ar0 = last_alpha * lc0 + (R_(1) - last_alpha) * ar0;
-                    ar1 = last_alpha * lc1 + (R_(1) - last_alpha) * ar1;
-                    ar2 = last_alpha * lc2 + (R_(1) - last_alpha) * ar2;
-                    lc0 = c0, lc1 = c1, lc2 = c2;
-                    real dL_dalpha = (c0 - ar0) * g0 + (c1 - ar1) * g1 + (c2 - ar2) * g2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (R_(1) - alpha)) * bg_dot;
-                    const real dL_dG = co[3] * dL_dalpha;
-                    const real gdx = G * dx, gdy = G * dy;
-                    const real dG_ddelx = -gdx * co[0] - gdy * co[1];
-                    const real dG_ddely = -gdy * co[2] - gdx * co[1];
-                    double *a = A + (size_t)g * 9;
-                    a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-                    a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
-                    a[2] += (double)(R_(-0.5) * gdx * dx * dL_dG);
-                    a[3] += (double)(R_(-0.5) * gdx * dy * dL_dG);
-                    a[4] += (double)(R_(-0.5) * gdy * dy * dL_dG);
-                    a[5] += (double)(G * dL_dalpha);
-                    a[6] += (double)(dch * g0);
-                    a[7] += (double)(dch * g1);
-                    a[8] += (double)(dch * g2);
-                }
+#pragma omp parallel
+    {
+        double *loc = NULL;   /* this thread's tile-local sums: [entries of the tile][9], grown on demand */
+        size_t loc_cap = 0;
+#pragma omp for schedule(dynamic, 4)
+        for (int tile = 0; tile < gx * gy; ++tile) {
+            const int tx = tile % gx, ty = tile / gx;
+            const uint32_t s = ranges[2 * tile], e = ranges[2 * tile + 1];
+            if (e <= s) continue;
+            const size_t n_tile = (size_t)(e - s);
+            if (n_tile > loc_cap) {
+                free(loc);
+                loc_cap = n_tile + n_tile / 2;
+                loc = (double *)malloc(loc_cap * 9 * sizeof(double));
             }
+            memset(loc, 0, n_tile * 9 * sizeof(double));
+            uint32_t deepest = 0;   /* entries beyond the deepest n_contrib of the tile received nothing */
+            for (int ly = 0; ly < TILE; ++ly)
+                for (int lx = 0; lx < TILE; ++lx) {
+                    const int px = tx * TILE + lx, py = ty * TILE + ly;
+                    if (px >= W || py >= H) continue;
+                    const size_t pix = (size_t)py * W + px;
+                    const real T_final = final_T[pix];
+                    real T = T_final;
+                    const real g0 = dL_dpix[pix], g1 = dL_dpix[(size_t)H * W + pix], g2 = dL_dpix[2 * (size_t)H * W + pix];
+                    const real bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+                    real ar0 = 0, ar1 = 0, ar2 = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_alpha = 0;
+                    if (n_contrib[pix] > deepest) deepest = n_contrib[pix];
+                    for (int64_t j = (int64_t)s + (int64_t)n_contrib[pix] - 1; j >= (int64_t)s; --j) {
+                        const uint32_t g = values[j];
+                        const real dx = xy[2 * g] - (real)px, dy = xy[2 * g + 1] - (real)py;
+                        const real *co = conic_opacity + 4 * g;
+                        const real power = R_(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0) continue;
+                        const real G = rexp_(power);
+                        const real alpha = rmin(R_(0.99), co[3] * G);
+                        if (alpha < R_(1.0) / R_(255.0)) continue;
+                        T = T / (R_(1) - alpha);
+                        const real dch = alpha * T;
+                        const real c0 = rgb[3 * g], c1 = rgb[3 * g + 1], c2 = rgb[3 * g + 2];
+                        ar0 = last_alpha * lc0 + (R_(1) - last_alpha) * ar0;
+                        ar1 = last_alpha * lc1 + (R_(1) - last_alpha) * ar1;
+                        ar2 = last_alpha * lc2 + (R_(1) - last_alpha) * ar2;
+                        lc0 = c0, lc1 = c1, lc2 = c2;
+                        real dL_dalpha = (c0 - ar0) * g0 + (c1 - ar1) * g1 + (c2 - ar2) * g2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (R_(1) - alpha)) * bg_dot;
+                        const real dL_dG = co[3] * dL_dalpha;
+                        const real gdx = G * dx, gdy = G * dy;
+                        const real dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const real dG_ddely = -gdy * co[2] - gdx * co[1];
+                        double *a = loc + (size_t)(j - (int64_t)s) * 9;
+                        a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                        a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                        a[2] += (double)(R_(-0.5) * gdx * dx * dL_dG);
+                        a[3] += (double)(R_(-0.5) * gdx * dy * dL_dG);
+                        a[4] += (double)(R_(-0.5) * gdy * dy * dL_dG);
+                        a[5] += (double)(G * dL_dalpha);
+                        a[6] += (double)(dch * g0);
+                        a[7] += (double)(dch * g1);
+                        a[8] += (double)(dch * g2);
+                    }
+                }
+            for (uint32_t k = 0; k < deepest; ++k) {
+                const double *a = loc + (size_t)k * 9;
+                double *dst = acc + (size_t)values[s + k] * 9;
+                for (int c = 0; c < 9; ++c)
+                    if (a[c] != 0.0) {
+#pragma omp atomic
+                        dst[c] += a[c];
+                    }
+            }
+        }
+        free(loc);
     }
     for (int i = 0; i < P; ++i) {
-        double t[9] = {0};
-        for (int th = 0; th < nthreads; ++th)
-            for (int k = 0; k < 9; ++k) t[k] += acc[stride * (size_t)th + (size_t)i * 9 + k];
+        const double *t = acc + (size_t)i * 9;
         dL_dmean2D[3 * i] = (real)t[0], dL_dmean2D[3 * i + 1] = (real)t[1], dL_dmean2D[3 * i + 2] = 0;
         dL_dconic[4 * i] = (real)t[2], dL_dconic[4 * i + 1] = (real)t[3], dL_dconic[4 * i + 2] = 0;
         dL_dconic[4 * i + 3] = (real)t[4];

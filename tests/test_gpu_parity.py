@@ -602,8 +602,12 @@ def _stacked_scene(P, H, W, seed, spread_px):
     return sc
 
 
-@pytest.mark.parametrize("P,longest_at_least,longest_at_most", [(2000, 1025, 2048), (6000, 2049, 8192), (20000, 8193, 10 ** 9)])
+@pytest.mark.parametrize("P,longest_at_least,longest_at_most", [(2000, 1025, 2048), (6000, 2049, 8192), (20000, 8193, 10 ** 9),
+                                                                (64000, 40000, 10 ** 9)])
 def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, longest_at_most, device):
+    """(round 4: lists beyond 2 048 entries are split by depth into parts that several workgroups sort -- binning.hip,
+    long_tile_plan_kernel -- up to a 40 000-entry tile here: 20-odd parts; scenes grow to max_n_gaussians 2 097 152,
+    cfg_files/release/neuman/hugs_scene.yaml:117)"""
     from diff_gaussian_rasterization import _debug_forward_state
     sc = _stacked_scene(P, 64, 64, seed=40 + P, spread_px=6.0)
     inp = oracle_inputs(sc)
@@ -1029,6 +1033,8 @@ def test_scale_gradient_convention_switch(upstream, binding, device, monkeypatch
     (900, 257, 1024, "equal"),        # every depth equal: one bucket -- the fallback to the bitonic network
     (40000, 1025, 8192, "spread"),    # >= 16 lists beyond 1024 entries on a sparse frame: the long-tile kernel's bucket sort
     (40000, 1025, 8192, "equal"),     # ... and its fallback
+    (40000, 1025, 8192, "ties"),      # (round 4) the depth-split of the lists beyond 2 048 entries with exact ties: a tie never straddles two parts
+    (6000, 2049, 8192, "equal"),      # (round 4) every depth equal in a list beyond 2 048 entries: the plan leaves it to the one-workgroup fallback
 ])
 def test_bucket_sort_paths_give_the_oracle_order(P, lo, hi, depths, device):
     """The per-tile sort of mid-length and long lists is a bucket sort (depth-linear buckets, ranking inside the bucket by the
@@ -1172,3 +1178,64 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device
         assert rel_l2(grads[True][k], grads[False][k]) <= 1e-5, k
         if k in refg:
             assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame", ["sparse", "dense"])
+def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monkeypatch):
+    """Round 4: the quads of LONG tiles are blended by four waves each, split by depth (blend_fwd.h: compose from T = 1 in
+    parallel, a per-pixel scan over the segments, the stop segment walked again with the exact rule); HGS_DEEP_FORWARD=0
+    keeps one wave per quad.  A stacked scene whose tiles are 600 and more entries deep (the HUGS human renders,
+    hugs/renderer/gs_renderer.py:56-82), with opacities high enough that pixels saturate well inside the lists, as a sparse
+    frame and as a dense one (a scene behind the stack, long-tile threshold lowered so that its tiles count as long):
+    the same sorted lists; images within 1e-6 and n_contrib equal on >= 99.98 % of the pixels (the products are rounded in
+    another order: a pixel whose T lands within 1e-7 of 1e-4 may stop one entry earlier or later), both within the oracle's
+    bar; gradients -- through the checkpoints the depth-parallel path leaves for the segmented backward -- within 1e-5 of
+    each other and within the oracle's bar."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    from hugs_amd import synthetic as syn
+    if frame == "sparse":
+        sc = _stacked_scene(2500, 64, 64, seed=77, spread_px=9.0)
+    else:
+        H = W = 1088
+        sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+        bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+        for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+            sc[k] = np.concatenate([sc[k], np.asarray(bgd[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    # (every tile list beyond 256 entries counts as long, whatever the frame: the sparse 16-tile frame has too few long tiles
+    #  for the sparse-frame threshold to apply)
+    monkeypatch.setenv("HGS_LONG_MIN_DENSE", "256")
+    monkeypatch.setenv("HGS_LONG_MIN_SPARSE", "256")
+    sc["opacities"] = np.clip(sc["opacities"] * 3.0, 0.0, 0.95).astype(np.float32)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    depth = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert depth.max() > 600 and ((depth > 0).sum() >= 4096) == (frame == "dense")
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    out = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("HGS_DEEP_FORWARD", deep)
+        t = gpu_tensors(sc, device, grad=False)
+        for _ in range(2):   # (the second frame runs on the first one's hints: the long-tile sort + workers in front of the tile kernel)
+            color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                                    scales=t["scales"], rotations=t["rotations"])
+            torch.cuda.synchronize()
+        assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+        assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+        tg, cg, _ = run_gpu(sc, device)
+        cg.backward(to_dev(sc["dL_dpix"], device))
+        assert torch.equal(cg.detach(), color)    # (forward is deterministic, with and without a backward to come)
+        out[deep] = dict(color=color.cpu().numpy(), final_T=st["final_T"].cpu().numpy(), n_contrib=st["n_contrib"].cpu().numpy(),
+                         grads={k: tg[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")})
+        check_image(out[deep]["color"], ref["color"], f"{frame}, HGS_DEEP_FORWARD={deep}")
+        check_image(out[deep]["final_T"], ref["final_T"], f"{frame} final_T, HGS_DEEP_FORWARD={deep}")
+        for k, r in refg.items():
+            if k in out[deep]["grads"]:
+                assert rel_l2(out[deep]["grads"][k].reshape(r.shape), r) <= GRAD_REL_TOL, (k, deep)
+    a, b = out["1"], out["0"]
+    d = np.abs(a["color"].astype(np.float64) - b["color"]).max(axis=0)
+    assert float((d <= 1e-6).mean()) >= 0.9998 and d.max() <= COLOR_TOL, f"deep vs one-wave image: max {d.max():.3e}, {(d > 1e-6).sum()} pixels beyond 1e-6"
+    assert float((a["n_contrib"] == b["n_contrib"]).mean()) >= 0.9998
+    assert not np.array_equal(a["color"], b["color"]), "the depth-parallel path did not run"
+    for k in a["grads"]:
+        assert rel_l2(a["grads"][k], b["grads"][k]) <= 1e-5, k

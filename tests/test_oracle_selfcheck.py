@@ -9,7 +9,7 @@ import torch
 
 from oracle import hgs_oracle as ho
 from oracle import torch_oracle as to
-from scenes import make_scene, oracle_inputs
+from scenes import CASES, make_scene, oracle_inputs
 
 SMALL = {
     "sh3_rot": dict(P=48, H=40, W=56, seed=0, D=3, rotated_camera=True),
@@ -202,3 +202,24 @@ def test_upstream_scale_gradient_switch_of_the_oracle():
     np.testing.assert_allclose(g1["scales"] * 0.7, g0["scales"], rtol=1e-12, atol=0)
     for k in ("means3D", "opacities", "shs", "rotations", "means2D"):
         assert np.array_equal(g0[k], g1[k]), k
+
+
+def test_backward_does_not_depend_on_the_number_of_threads():
+    """The pixel backward adds tile-local double sums into ONE shared double accumulator with atomics (round 4: the per-thread
+    accumulators of round 3 capped the CPU baseline at 32 host threads): whatever the thread count and the order the tiles
+    arrive in, the fp64 build agrees to ~1e-15 and the fp32 build -- rounded once from the double sums -- to the last bit but
+    for a sum that lands on a rounding boundary."""
+    sc = make_scene(**CASES["opaque_earlystop"])
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-7)):
+        inp = oracle_inputs(sc, dtype) if dtype is np.float64 else oracle_inputs(sc)
+        out = {}
+        for n in (1, 8):
+            ho.set_threads(n, dtype)
+            f = ho.forward(inp)
+            out[n] = ho.backward(inp, f, sc["dL_dpix"].astype(dtype))
+        for k in out[1]:
+            a, b = np.asarray(out[1][k], np.float64), np.asarray(out[8][k], np.float64)
+            scale = max(np.abs(a).max(), 1e-300)
+            assert np.abs(a - b).max() <= tol * scale, (dtype.__name__, k)
+    ho.set_threads(1)
+    ho.set_threads(1, np.float64)

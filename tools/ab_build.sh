@@ -8,7 +8,7 @@ while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   objs=""
   for f in hgs_api preprocess binning blend densify knn lbs loss scene_forward rotations; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $flags -c $f.hip -o /tmp/ab_${name}_$f.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $([ $f = binning ] && echo "-mllvm -disable-machine-sink") $flags -c $f.hip -o /tmp/ab_${name}_$f.o &
     objs="$objs /tmp/ab_${name}_$f.o"
   done
   wait

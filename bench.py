@@ -48,14 +48,20 @@ def alg_bytes(P, Pv, N, S, T, K, M=16):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    # (HGS_BENCH_STEPS: short runs under the PMC passes of profiles/collect_workload.sh)
+    ap.add_argument("--steps", type=int, default=int(os.environ.get("HGS_BENCH_STEPS", 1000)))
+    ap.add_argument("--warmup", type=int, default=3 if os.environ.get("HGS_BENCH_STEPS") else 50)
     ap.add_argument("--gaussians", type=int, default=200_000)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--cluster", type=float, default=0.0, help="fraction of the Gaussians in a central blob (not the headline workload)")
+    ap.add_argument("--profile", choices=("uniform", "trained"), default="uniform",
+                    help="uniform: SURVEY.md 8d's synthetic scene (the headline workload); trained: a scene shaped like what HUGS renders "
+                         "after some thousand steps -- surfaces, heavy-tailed sizes, post-reset opacities, a 110 210-Gaussian human in "
+                         "front (hugs_amd.synthetic.trained_scene_gaussians; --gaussians = the SCENE's count, SH degree 0 as the joint "
+                         "render uses) -- not the headline workload")
     ap.add_argument("--spatial-order", action="store_true", help="store the Gaussians in 3-D Morton order (not the headline workload)")
     ap.add_argument("--frames-per-rank", type=int, default=1,
                     help="cameras each rank renders per step (frame f of rank r = camera r * K + f).  BASELINE configs[4] -- 8 frames x "
@@ -271,7 +277,12 @@ def main():
 
     P, H, W, D = args.gaussians, args.height, args.width, args.sh_degree
     cam0 = syn.pinhole_camera(H, W)
-    g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0, cluster=args.cluster)
+    if args.profile == "trained":
+        g = syn.trained_scene_gaussians(P, cam0, seed=0)
+        P = g["means3D"].shape[0]   # scene + human
+        D = 0                       # (render_human_scene takes the HUMAN model's active degree: 0 in the release configs)
+    else:
+        g = syn.scene_gaussians(P, cam0, seed=0, sigma_px=4.0, cluster=args.cluster)
     if args.spatial_order:   # not the headline workload: the same Gaussians stored in 3-D Morton order
         from hugs_amd.spatial import morton_order
         order = morton_order(g["means3D"])
@@ -403,7 +414,7 @@ def main():
         "rank_devices": [int(x) for x in frames[:, 2].tolist()],
         "per_rank_N": [int(x) for x in frames[:, 0].tolist()],
         "per_rank_fps": [round(float(x), 2) for x in frames[:, 4].tolist()],   # each rank's own clock: a straggler is visible here
-        "config": {"workload": f"{'configs[1]' if (P, KF) == (200_000, 1) else ('configs[4] (frame batch)' if P == 300_000 else 'sweep point')}: "
+        "config": {"workload": f"{'trained-scene profile (not a BASELINE config)' if args.profile == 'trained' else 'configs[1]' if (P, KF) == (200_000, 1) else ('configs[4] (frame batch)' if P == 300_000 else 'sweep point')}: "
                                f"{P} scene Gaussians, {W}x{H}, SH degree {D} on [P,16,3], "
                                f"{'forward only' if args.forward_only else 'forward+backward'} through "
                                f"GaussianRasterizer (drop-in API), {KF} camera(s) per GPU and step",
@@ -488,9 +499,9 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
     """The oracle (a CPU port of the same algorithm -- the reference has no CPU path) timed on
     this box's host cores on a bounded sample of the same workload. Baseline only."""
     from oracle import hgs_oracle as ho
-    # the port keeps one double-precision gradient accumulator per thread: beyond ~32 threads that costs more than it buys
-    # (`cores` = threads actually used; the box's core count and CPU model are reported beside it)
-    cores = min(os.cpu_count() or 1, 32)
+    # all host cores (round 4: the port's pixel backward adds tile-local sums into ONE shared double accumulator; the
+    # per-thread accumulators of round 3 capped it at 32 threads).  `cores` = threads actually used.
+    cores = os.cpu_count() or 1
     ho.set_threads(cores)
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
                     cam["camera_center"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), H, W,

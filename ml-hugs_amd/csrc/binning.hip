@@ -63,7 +63,11 @@ constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long t
 constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
 constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
 constexpr uint32_t DEEP_MEAN_MIN = 384;
-constexpr int LONG_MIN_DENSE = 2048;            // dense frames: what the one-workgroup-per-tile sort cannot hold
+// dense frames: 2 048, what the one-workgroup-per-tile sort holds.  (1 024 was measured: the all-rows step's joint render -- a
+// person in front of a scene, hundreds of tiles between 1 024 and 2 048 entries -- fused kernel 237 -> 192 us; but "has long
+// tiles" is also what makes the bindings offer a checkpoint buffer, and C4's joint render, whose deepest tile has 1 900 entries
+// and whose backward is throughput- not chain-bound, then pays 78 us for the segmented backward of its 512+-entry tiles.)
+constexpr int LONG_MIN_DENSE = 2048;
 constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
@@ -75,15 +79,17 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
                  uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ seg_first, uint32_t capacity,
                  unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense)
 {
+    __shared__ uint32_t n_long_sh;
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t n_large, n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
+    __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
-    if (threadIdx.x == 0) n_large = 0, n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
+    if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
     for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0;
+    uint32_t my_huge = 0, my_sparse = 0, my_shallow = 0, my_dense = 0;   // this thread's lists beyond each threshold
     for (int base = 0; base < num_tiles; base += 1024 * SCAN_ITEMS) {
         const int t0 = base + threadIdx.x * SCAN_ITEMS;
         uint32_t c[SCAN_ITEMS];
@@ -129,13 +135,10 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         for (int k = 0; k < SCAN_ITEMS; ++k) {
             st[k] = start;
             start += c[k];
-            // (candidates: which of them ARE long depends on the sparse-frame decision at the end of this kernel)
-            if (c[k] > min(long_min_sparse, long_min_dense) && t0 + k < num_tiles) {
-                large_tiles[atomicAdd(&n_large, 1u)] = (uint32_t)(t0 + k);  // rare
-                if (c[k] > (uint32_t)SORT_CAP_MID) atomicAdd(&n_huge, 1u);
-                if (c[k] > long_min_sparse) atomicAdd(&n_large_sparse, 1u);
-                if (c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW) atomicAdd(&n_large_shallow, 1u);
-                if (c[k] > long_min_dense) atomicAdd(&n_large_dense, 1u);
+            // (which lists are long depends on what kind of frame this is, known at the end: count for every threshold it may choose)
+            if (t0 + k < num_tiles) {
+                my_huge += c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u, my_sparse += c[k] > long_min_sparse ? 1u : 0u;
+                my_shallow += c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW ? 1u : 0u, my_dense += c[k] > long_min_dense ? 1u : 0u;
             }
         }
         if (t0 + SCAN_ITEMS <= num_tiles) {
@@ -164,46 +167,99 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         }
         carry += total;
     }
+    // Which lists ARE long depends on what kind of frame this is, known only now.  Every thread takes the decision for itself from
+    // the workgroup's counters (no broadcast, no barrier for it); a frame WITH long lists then collects them into the list the
+    // long tiles' kernels and the deep workers walk (large_tiles, n_total[2]); one without (the bench workload) pays four adds
+    // per tile and a wave reduction for all this.
+    {
+        uint32_t v[4] = {my_huge, my_sparse, my_shallow, my_dense};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // wave sum in lane 63: DPP row shifts + row broadcasts
+            uint32_t x = v[q];
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+            v[q] = x;
+        }
+        if (lane == 63) {
+            if (v[0]) atomicAdd(&n_huge, v[0]);
+            if (v[1]) atomicAdd(&n_large_sparse, v[1]);
+            if (v[2]) atomicAdd(&n_large_shallow, v[2]);
+            if (v[3]) atomicAdd(&n_large_dense, v[3]);
+        }
+        if (threadIdx.x == 0) n_long_sh = 0u;
+    }
     __syncthreads();
+    // more pairs than 32-bit positions can address (N_TOO_MANY and above are reserved): the gate closes whatever the
+    // capacity, and the host is told N = 0xFFFFFFFF, which it turns into HGS_ERR_OVERFLOW
+    if (total64 >= (unsigned long long)N_TOO_MANY) carry = 0xFFFFFFFFu;
+    // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
+    // the backward blend then splits long tiles over four waves
+    const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
+    // this frame's long-tile threshold (n_total[4]).  Sparse frames: lists from long_min_sparse entries on are long (sorted
+    // ahead, blended split by depth) when the frame's lists are deep on average -- depth parallelism pays for its compose +
+    // re-walk overhead only where one wave per quad would walk hundreds of entries -- and from LONG_MIN_SPARSE_SHALLOW on
+    // otherwise; in either case only if enough of them exist
+    const bool deep_lists = sparse && n_nonempty && total64 >= (unsigned long long)DEEP_MEAN_MIN * n_nonempty;
+    const uint32_t n_sparse_long = deep_lists ? n_large_sparse : n_large_shallow;
+    const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
+    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : long_min_dense;
+    const uint32_t any_long = (use_sparse ? n_sparse_long : n_large_dense) ? 1u : 0u;
+    const uint32_t huge = n_huge;
     if (threadIdx.x == 0) {
-        // more pairs than 32-bit positions can address (N_TOO_MANY and above are reserved): the gate closes whatever the
-        // capacity, and the host is told N = 0xFFFFFFFF, which it turns into HGS_ERR_OVERFLOW
-        if (total64 >= (unsigned long long)N_TOO_MANY) carry = 0xFFFFFFFFu;
-        n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u, n_total[2] = n_large;
+        n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;
+        n_total[3] = sparse, n_total[4] = threshold;
         // [5] parts of the lists beyond SORT_CAP_MID entries (long_tile_plan_kernel appends), [6] how many such lists there are,
         // [7] lists the plan leaves to the one-workgroup fallback
-        n_total[5] = 0u, n_total[6] = n_huge, n_total[7] = 0u;
-        if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
-        // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
-        // the backward blend then splits long tiles over four waves
-        const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
-        n_total[3] = sparse;
-        // (sparse << 63 | has-long-tiles << 62 | 30-bit ticket << 32 | N)
-        // this frame's long-tile threshold (n_total[4]): read by both sort kernels
-        // sparse frames: lists from long_min_sparse entries on are long (sorted ahead, blended split by depth) when the frame's lists
-        // are deep on average -- depth parallelism pays for its compose + re-walk overhead only where one wave per quad would walk
-        // hundreds of entries -- and from LONG_MIN_SPARSE_SHALLOW on otherwise; in either case only if enough of them exist
-        const bool deep_lists = sparse && n_nonempty && total64 >= (unsigned long long)DEEP_MEAN_MIN * n_nonempty;
-        const uint32_t n_sparse_long = deep_lists ? n_large_sparse : n_large_shallow;
-        const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
-        const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : long_min_dense;
-        n_total[4] = threshold;
+        n_total[5] = 0u, n_total[6] = huge, n_total[7] = 0u;
         // [8]: the long tiles' quads are blended split by depth (the deep workers of the fused kernel) -- on dense frames, and on
         // sparse frames with deep lists; on a shallow sparse frame (the SMPL template: 25 lists beyond 1 024 entries, composited
         // depth <= 430) one wave per quad does as well and the workers' workgroups only stand in the way (measured: +2 us)
         n_total[8] = (!sparse || deep_lists) ? 1u : 0u;
-        const uint32_t any_long = (use_sparse ? n_sparse_long : n_large_dense) ? 1u : 0u;
+        if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
+    }
+    uint32_t n_long = 0;
+    if (any_long) {   // (workgroup-uniform) the frame has long lists: collect them
+        for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {   // (eight loads in flight per thread: a 1080p frame is one trip)
+            uint2 rg8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + u * 1024 + (int)threadIdx.x;
+                rg8[u] = t < num_tiles ? ranges[t] : make_uint2(0u, 0u);   // (written by this workgroup before the barriers above)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + u * 1024 + (int)threadIdx.x;
+                const bool is_long = rg8[u].y - rg8[u].x > threshold;
+                const unsigned long long m = __ballot(is_long);
+                if (m) {   // (wave-uniform; one atomic per wave)
+                    uint32_t at = 0;
+                    if (lane == (int)__builtin_ctzll(m)) at = atomicAdd(&n_long_sh, (uint32_t)__popcll(m));
+                    at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)__builtin_ctzll(m));
+                    if (is_long) large_tiles[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)t;
+                }
+            }
+        }
+        __syncthreads();
+        n_long = n_long_sh;
+    }
+    if (threadIdx.x == 0) {
+        n_total[2] = n_long;
+        // (sparse << 63 | has-long-tiles << 62 | 30-bit ticket << 32 | N); words 1 and 2 of the slot: how many lists are long /
+        // beyond SORT_CAP_MID entries -- the host sizes the next frame's launches by them
         const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)any_long << 30);
-        // (words 1 and 2 of the slot: how many lists are long / beyond SORT_CAP_MID -- the host sizes the next frame's launches by them)
-        __hip_atomic_store(host_slot + 1, (unsigned long long)(use_sparse ? n_sparse_long : n_large_dense), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_slot + 2, (unsigned long long)n_huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 1, (unsigned long long)n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 2, (unsigned long long)huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
-                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot,
-                      uint32_t ticket, hipStream_t st)
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
 {
     // (both at most SORT_CAP_SMALL: that is what the one-workgroup-per-tile sort holds)
     // (read on every call: the tests switch them between frames)
@@ -655,10 +711,15 @@ __device__ __forceinline__ void bitonic_in_registers(uint64_t (&key)[E], uint64_
 // position e NT + tid and pos[e] its FINAL position in the sorted order (only for e NT + tid < n).  Returns false -- keys
 // untouched -- when the depths pile up in one bucket (more than BUCKET_MAX keys in it, e.g. all depths equal): the caller
 // takes the bitonic network.  sh_keys: E NT keys of LDS; bstart: E NT + 1 words; red: 3 NT / 64 words.
+// EQ (round 4): EQUALISED buckets, for the lists whose depths cluster -- a person in front of a scene: nine keys in ten inside
+// 3 % of the tile's depth range, where linear buckets overflow and the caller used to fall back to the bitonic network (70 us
+// for a 4 000-entry list).  A coarse histogram (NT linear bins) is taken first; coarse bin b then owns as many fine buckets
+// as it has keys, dealt linearly inside the bin: still monotone in the depth bits, n buckets in all.  The callers try the
+// linear buckets first (no extra pass on the common path), then these, then the network.  coarse: 2 NT words of LDS.
 constexpr uint32_t BUCKET_MAX = 48;
-template <int E, uint32_t NT>
+template <int E, uint32_t NT, bool EQ = false>
 __device__ __forceinline__ bool bucket_sort(uint64_t (&key)[E], uint32_t (&pos)[E], uint32_t n, uint64_t* sh_keys, uint32_t* bstart,
-                                            uint32_t* red)
+                                            uint32_t* red, uint32_t* coarse = nullptr)
 {
     constexpr uint32_t NB = (uint32_t)E * NT, NW = NT / 64u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -669,6 +730,7 @@ __device__ __forceinline__ bool bucket_sort(uint64_t (&key)[E], uint32_t (&pos)[
         if (i < n) dmin = min(dmin, (uint32_t)(key[e] >> 32)), dmax = max(dmax, (uint32_t)(key[e] >> 32));
         bstart[i] = 0u;
     }
+    if constexpr (EQ) coarse[tid] = 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
@@ -681,8 +743,30 @@ __device__ __forceinline__ bool bucket_sort(uint64_t (&key)[E], uint32_t (&pos)[
     for (uint32_t k = 0; k < NW; ++k) dmin = min(dmin, red[k]), dmax = max(dmax, red[NW + k]);
     // bucket of a key: monotone in its depth bits (unsigned -> float conversion, a positive factor and the truncation are all
     // monotone), so bucket order never contradicts key order; what it does to ties is the ranking's business
-    const float scale = (float)NB / ((float)(dmax - dmin) + 1.0f);
-    auto bucket_of = [&](uint64_t k) { return min((uint32_t)((float)((uint32_t)(k >> 32) - dmin) * scale), NB - 1u); };
+    const float scale = (float)(EQ ? NT : NB) / ((float)(dmax - dmin) + 1.0f);
+    if constexpr (EQ) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((uint32_t)e * NT + tid < n) atomicAdd(&coarse[min((uint32_t)((float)((uint32_t)(key[e] >> 32) - dmin) * scale), NT - 1u)], 1u);
+        __syncthreads();
+        const uint32_t c = coarse[tid], inc = wave_inclusive_scan(c);
+        if (lane == 63) red[2 * NW + w] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < NW; ++k)
+            if (k < w) before += red[2 * NW + k];
+        coarse[NT + tid] = before + inc - c;   // first fine bucket of coarse bin `tid`
+        __syncthreads();
+    }
+    auto bucket_of = [&](uint64_t k) {
+        const float f = (float)((uint32_t)(k >> 32) - dmin) * scale;
+        if constexpr (EQ) {
+            const uint32_t b = min((uint32_t)f, NT - 1u), c = coarse[b];
+            return coarse[NT + b] + min((uint32_t)((f - (float)b) * (float)c), c - 1u);   // (c >= 1: the key itself is in bin b)
+        } else
+            return min((uint32_t)f, NB - 1u);
+    };
     uint32_t slot[E], bkt[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -812,7 +896,9 @@ __device__ __forceinline__ uint32_t tile_sort_small(uint32_t tile, uint32_t s, u
     if constexpr (E == 2 || E == 4) {
         uint32_t pos[E];
         uint32_t* bstart = reinterpret_cast<uint32_t*>(sh + E * 256);
-        if (bucket_sort<E, 256u>(key, pos, n, sh, bstart, bstart + E * 256 + 4)) {
+        // (linear buckets; where the depths cluster, equalised ones; the bitonic network below when even those pile up)
+        if (bucket_sort<E, 256u>(key, pos, n, sh, bstart, bstart + E * 256 + 4) ||
+            bucket_sort<E, 256u, true>(key, pos, n, sh, bstart, bstart + E * 256 + 4, bstart + E * 256 + 4 + 16)) {
             __syncthreads();  // every thread has ranked its keys: the bucketed copy may be overwritten
 #pragma unroll
             for (int e = 0; e < E; ++e)
@@ -861,15 +947,12 @@ __device__ __forceinline__ uint32_t tile_sort_small(uint32_t tile, uint32_t s, u
 #ifndef FUSED_KERNEL_ATTR
 #define FUSED_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(7)))
 #endif
-// (the kernel's arguments as ONE struct: the tile path reads what only its epilogue needs -- output pointers, background, image
-//  size -- back from the kernarg segment AFTER the walk (below); as separate arguments they sat in SGPRs across the blend loop,
-//  and with the deep workers' state in the same kernel that pushed the loop's own values into spill lanes: +10 % on C4)
+// (the kernel's arguments as one struct)
 struct FusedKernelArgs {
     const uint2* ranges; const uint64_t* keys; uint64_t* list; uint64_t* act; size_t stride; uint32_t* act_count; const uint32_t* gate;
     Camera cam; uint32_t lastg; const Splat* splats; const float* bg; float* out_color; float* final_T; uint32_t* n_contrib;
     int clamp_output, long_sorted; Ckpt ck; const uint32_t* large_tiles; uint32_t num_workers;
 };
-typedef const __attribute__((address_space(4))) FusedKernelArgs* fused_args_p;
 
 template <bool FUSED>
 __global__ void __launch_bounds__(256) FUSED_KERNEL_ATTR
@@ -942,12 +1025,38 @@ tile_sort_small_kernel(FusedKernelArgs a)
         const bool inside = px < a.cam.W && py < a.cam.H;
         float4* ck_mine = ck_tile ? ck_tile + w * 64 + lane : nullptr;
         const uint64_t* my_list = a.act + (size_t)w * a.stride + s;
+        // What the epilogue needs is put into VECTOR registers per lane before the walk -- output addresses, background, flags:
+        // as scalar kernel arguments they sat in ~13 SGPRs across the blend loop, which this kernel (with the deep workers' state
+        // in it) no longer has to spare (spill code inside the loop: +10 % on C4); fetched after the walk instead, each wave ended
+        // with an exposed scalar-load round trip (+1.6 % on C2).  VGPRs are plentiful here: the sort's peak is elsewhere.
+        const size_t HW = (size_t)a.cam.H * a.cam.W, pix = inside ? (size_t)py * a.cam.W + px : 0;
+        float* o0 = a.out_color + pix;
+        float* oT = a.final_T + pix;
+        uint32_t* oN = a.n_contrib + pix;
+        uint32_t* oP = a.ck.quad_nproc + tile_id * 4u + (uint32_t)w;
+        float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+        uint32_t plane = (uint32_t)(HW * sizeof(float)), flags = (a.clamp_output ? 1u : 0u) | (inside ? 2u : 0u);
+        asm volatile("" : "+v"(o0), "+v"(oT), "+v"(oN), "+v"(oP), "+v"(bg0), "+v"(bg1), "+v"(bg2), "+v"(plane), "+v"(flags));
         const FwdWalk r = blend_forward_walk(a.lastg, (float)px, (float)py, inside, mine, my_list, a.splats, ck_mine);
-        // the epilogue's arguments, fetched now (the pointer is opaque to the optimiser: nothing below was live across the walk)
-        fused_args_p late = (fused_args_p)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(late));
-        blend_forward_finish(r, late->cam.W, late->cam.H, px, py, lane, ck_mine, late->ck.quad_nproc + tile_id * 4u + (uint32_t)w, late->bg,
-                             late->out_color, late->final_T, late->n_contrib, late->clamp_output);
+        if (ck_mine) {
+            const uint32_t segs = (r.walked + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT;
+            if (segs >= 2u) ck_mine[(size_t)(segs - 1u) * 256u] = make_float4(r.T, r.C0, r.C1, r.C2);
+            if (lane == 0) *oP = r.walked;
+        }
+        if (flags & 2u) {   // (the arithmetic of write_pixel, blend_fwd.h)
+            const float Tf = __builtin_fabsf(r.T);
+            *oT = Tf;
+            float c0 = __builtin_fmaf(Tf, bg0, r.C0), c1 = __builtin_fmaf(Tf, bg1, r.C1), c2 = __builtin_fmaf(Tf, bg2, r.C2);
+            uint32_t pass = 7u;
+            if (flags & 1u) {
+                pass = (c0 >= 0.0f && c0 <= 1.0f ? 1u : 0u) | (c1 >= 0.0f && c1 <= 1.0f ? 2u : 0u) | (c2 >= 0.0f && c2 <= 1.0f ? 4u : 0u);
+                c0 = fminf(fmaxf(c0, 0.0f), 1.0f), c1 = fminf(fmaxf(c1, 0.0f), 1.0f), c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
+            }
+            *oN = r.last | (pass << 29);
+            *o0 = c0;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(o0) + plane) = c1;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(o0) + 2u * (size_t)plane) = c2;
+        }
     }
     HGS_TRACE_PUT(2, wall_clock64());
 }
@@ -963,7 +1072,7 @@ tile_sort_small_kernel(FusedKernelArgs a)
 //                           sorted parts IS the sorted tile.  A tile whose depths pile up in a bucket (more than
 //                           PLAN_BUCKET_MAX keys) is left to the one-workgroup fallback.
 //   tile_sort_mid_kernel    one 512-thread workgroup per item: a long tile of at most SORT_CAP_MID entries, or one PART of a
-//                           longer one (the part's keys are picked out of the tile's segment into LDS first); bucket_sort,
+//                           longer one (whose keys the plan kernel has moved into the part's stretch of `scratch`); bucket_sort,
 //                           sorted list, compacted lists.  48 KB of LDS: two workgroups per CU.
 //   tile_sort_large_kernel  the fallback for what the plan left (97 KB of LDS, one workgroup per CU, the CAP-sized chunk path
 //                           for lists beyond LDS).
@@ -1002,10 +1111,11 @@ __device__ __forceinline__ uint32_t plan_bucket_of(uint64_t key, uint32_t dmin, 
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS)
-long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint32_t* __restrict__ act_count,
-                      const uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ n_total, SortPart* __restrict__ parts,
-                      uint32_t max_parts)
+long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys, uint64_t* __restrict__ scratch,
+                      uint32_t* __restrict__ act_count, const uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ n_total,
+                      SortPart* __restrict__ parts, uint32_t max_parts)
 {
+    __shared__ uint32_t fill[PLAN_MAX_PARTS];   // keys already moved to each part's stretch of `scratch`
     __shared__ uint32_t hist[PLAN_BUCKETS];          // bucket sizes, then their exclusive prefix
     __shared__ uint16_t part_of[PLAN_BUCKETS];
     __shared__ uint32_t part_b0[PLAN_MAX_PARTS + 1], part_off[PLAN_MAX_PARTS + 1];
@@ -1067,6 +1177,7 @@ long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restri
             continue;
         }
         for (uint32_t k = tid; k <= num_parts; k += PLAN_THREADS) part_b0[k] = 0xFFFFFFFFu, part_off[k] = n;
+        for (uint32_t k = tid; k < num_parts; k += PLAN_THREADS) fill[k] = 0u;
         for (uint32_t k = tid; k < num_parts * NUM_LISTS; k += PLAN_THREADS) (&qcnt[0][0])[k] = 0u;
         __syncthreads();
         uint32_t run = before + incl - mine, prev_p = 0xFFFFFFFFu;
@@ -1084,16 +1195,21 @@ long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restri
             run += cnt[k];
         }
         __syncthreads();
-        // every part's entries per quad list.  With a handful of parts every lane of a wave would hit the same few LDS counters
-        // (same-address atomics of one instruction are serialised: 8 us for a 3 400-entry tile): the wave counts with ballots,
-        // part by part, and adds once per (part, list); with many parts the direct atomics spread by themselves.
+        // every part's entries per quad list, and the keys MOVED part by part into `scratch` (the part's stretch of the tile's
+        // segment, any order inside it): the workgroup that sorts a part reads its keys contiguously instead of sweeping the
+        // whole tile for them.  With a handful of parts every lane of a wave would hit the same few LDS counters (same-address
+        // atomics of one instruction are serialised: 8 us for a 3 400-entry tile): the wave counts with ballots, part by part,
+        // and adds once per (part, list); with many parts the direct atomics spread by themselves.
         for_each_key<8, PLAN_THREADS>(keys + s, n, [&](uint32_t, uint64_t key, bool valid) {
             const uint32_t p = valid ? part_of[plan_bucket_of(key, dmin, scale)] : 0xFFFFFFFFu, mask = valid ? (uint32_t)key & 15u : 0u;
+            uint32_t dest = 0;
             if (num_parts <= 8u) {
                 unsigned long long todo = __ballot(valid);
                 while (todo) {   // (wave-uniform)
-                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)__builtin_ctzll(todo));
+                    const int first = (int)__builtin_ctzll(todo);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, first);
                     const bool mine_p = valid && p == p0;
+                    const unsigned long long m = __ballot(mine_p);
                     uint32_t c = 0;
 #pragma unroll
                     for (int q = 0; q < NUM_LISTS; ++q) {
@@ -1101,14 +1217,20 @@ long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restri
                         if (lane == (uint32_t)q) c = cq;
                     }
                     if (lane < (uint32_t)NUM_LISTS && c) atomicAdd(&qcnt[p0][lane], c);
-                    todo &= ~__ballot(mine_p);
+                    uint32_t base = 0;
+                    if ((int)lane == first) base = atomicAdd(&fill[p0], (uint32_t)__popcll(m));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                    if (mine_p) dest = part_off[p0] + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    todo &= ~m;
                 }
             } else if (valid) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if ((mask >> q) & 1u) atomicAdd(&qcnt[p][q], 1u);
                 if (mask) atomicAdd(&qcnt[p][4], 1u);
+                dest = part_off[p] + atomicAdd(&fill[p], 1u);
             }
+            if (valid) scratch[s + dest] = key;
         });
         if (tid == 0) base_slot = atomicAdd(&n_total[5], num_parts);
         __syncthreads();
@@ -1153,7 +1275,7 @@ long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restri
 template <int CAP, int NT, typename LoadKey>
 __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t s_tile, uint32_t s_dst, uint32_t pos_base,
                                           uint32_t (&carry)[NUM_LISTS], uint64_t* __restrict__ list, uint64_t* __restrict__ act,
-                                          size_t stride, uint64_t* sh, uint32_t* bucket_start, uint32_t* red)
+                                          size_t stride, uint64_t* sh, uint32_t* bucket_start, uint32_t* red, uint32_t* coarse)
 {
     bool sorted_in_lds = true;  // (workgroup-uniform)
     // the register network of the small tiles with NT threads: lane distances below 64 by DPP, only distances 64..NT/2 through
@@ -1184,7 +1306,7 @@ __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t
             const uint32_t i = (uint32_t)e * NT + threadIdx.x;
             key[e] = i < n ? load_key(i) : ~0ull;
         }
-        if (!bucket_sort<E, NT>(key, pos, n, sh, bucket_start, red)) return false;
+        if (!bucket_sort<E, NT>(key, pos, n, sh, bucket_start, red) && !bucket_sort<E, NT, true>(key, pos, n, sh, bucket_start, red, coarse)) return false;
         __syncthreads();  // every thread has ranked its keys: the bucketed copy in LDS may be overwritten ...
 #pragma unroll
         for (int e = 0; e < E; ++e)
@@ -1285,7 +1407,7 @@ __global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_
     __shared__ uint64_t sh[CAP];
     __shared__ uint32_t bucket_start[CAP + 1];  // bucket sizes, then (in place) their exclusive scan
     __shared__ uint32_t red[3 * (NT / 64)];
-    __shared__ uint32_t picked;
+    __shared__ uint32_t coarse[2 * NT];
     if (n_total[1]) return;  // gate
     const uint32_t threshold = n_total[4], n_cand = n_total[2], n_items = n_cand + (planned ? n_total[5] : 0u);
     // a fixed grid walks the candidate tiles that tile_scan_kernel listed, then the parts the plan kernel made
@@ -1299,33 +1421,19 @@ __global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_
             // (!planned: the plan and fallback kernels were not launched -- the stream's last frame had no list beyond CAP entries --
             //  and this frame has one after all: sorted here, slowly, this once)
             if (n > (uint32_t)CAP) sort_in_chunks<CAP, NT>(keys + s, n, s, list, scratch, act, stride, carry, sh, bucket_start);
-            else sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red);
+            else sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red, coarse);
 #pragma unroll
             for (int q = 0; q < NUM_LISTS; ++q)
                 if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
         } else {
             const SortPart r = parts[it - n_cand];
             if (r.count == 0u) continue;
-            const uint2 rg = ranges[r.tile];
-            const uint32_t s = rg.x, n_tile = rg.y - rg.x;
-            // pick the part's keys out of the tile's segment (any order: they are sorted next)
-            if (threadIdx.x == 0) picked = 0u;
-            __syncthreads();
-            for_each_key<8, NT>(keys + s, n_tile, [&](uint32_t, uint64_t k, bool valid) {   // (one LDS atomic per wave, not per key: they all hit one counter)
-                const uint32_t b = plan_bucket_of(k, r.dmin, r.scale);
-                const bool take = valid && b >= r.b_lo && b < r.b_hi;
-                const unsigned long long m = __ballot(take);
-                uint32_t at0 = 0;
-                if ((threadIdx.x & 63u) == 0u && m) at0 = atomicAdd(&picked, (uint32_t)__popcll(m));
-                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
-                const uint32_t at = at0 + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
-                if (take && at < (uint32_t)CAP) sh[at] = k;
-            });
-            __syncthreads();
-            const uint32_t n = min(r.count, (uint32_t)CAP);   // (== picked)
+            const uint32_t s = ranges[r.tile].x;
+            const uint32_t n = min(r.count, (uint32_t)CAP);
+            const uint64_t* src = scratch + s + r.out_off;   // (the plan kernel moved the part's keys here)
 #pragma unroll
             for (int q = 0; q < NUM_LISTS; ++q) carry[q] = r.carry[q];
-            sort_item<CAP, NT>([&](uint32_t i) { return sh[i]; }, n, s, s + r.out_off, r.out_off, carry, list, act, stride, sh, bucket_start, red);
+            sort_item<CAP, NT>([&](uint32_t i) { return src[i]; }, n, s, s + r.out_off, r.out_off, carry, list, act, stride, sh, bucket_start, red, coarse);
         }
         __syncthreads();  // sh is reused by the next item
     }
@@ -1338,6 +1446,7 @@ __global__ void __launch_bounds__(SORT_LARGE_THREADS) tile_sort_large_kernel(LAR
     __shared__ uint64_t sh[CAP];
     __shared__ uint32_t bucket_start[CAP + 1];
     __shared__ uint32_t red[3 * (NT / 64)];
+    __shared__ uint32_t coarse[2 * NT];
     if (n_total[1] || n_total[7] == 0u) return;  // gate; the plan left nothing
     const uint32_t threshold = max(n_total[4], (uint32_t)SORT_CAP_MID);
     for (uint32_t li = blockIdx.x; li < n_total[2]; li += gridDim.x) {
@@ -1347,7 +1456,7 @@ __global__ void __launch_bounds__(SORT_LARGE_THREADS) tile_sort_large_kernel(LAR
         if (n <= threshold || act_count[tile * NUM_LISTS] != ACT_COUNT_FALLBACK) continue;
         uint32_t carry[NUM_LISTS] = {0, 0, 0, 0, 0};
         if (n <= (uint32_t)CAP)
-            sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red);
+            sort_item<CAP, NT>([&](uint32_t i) { return keys[s + i]; }, n, s, s, 0u, carry, list, act, stride, sh, bucket_start, red, coarse);
         else
             sort_in_chunks<CAP, NT>(keys + s, n, s, list, scratch, act, stride, carry, sh, bucket_start);
 #pragma unroll
@@ -1371,7 +1480,7 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
         // had one (or nothing is known); a frame that has one unannounced is sorted by the mid kernel's slow path, this once.
         const int wgs = num_tiles < 256 ? num_tiles : 256;
         if (plan_huge)
-            hipLaunchKernelGGL(long_tile_plan_kernel, dim3(wgs), dim3(PLAN_THREADS), 0, st, ranges, keys, act_count, large_tiles, n_total,
+            hipLaunchKernelGGL(long_tile_plan_kernel, dim3(wgs), dim3(PLAN_THREADS), 0, st, ranges, keys, scratch, act_count, large_tiles, n_total,
                                (SortPart*)parts, max_parts);
         hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(512), dim3(SORT_MID_THREADS), 0, st, ranges, keys, list, scratch, act, stride,
                            act_count, large_tiles, n_total, (const SortPart*)parts, plan_huge ? 1 : 0);

@@ -140,7 +140,7 @@ struct ImageLayout {
         ranges = o;     o = align_up(o + 8 * T);
         act_count = o;  o = align_up(o + 4 * T * NUM_LISTS);   // entries in each tile's compacted lists
         cursor = o;     o = align_up(o + 4 * T);   // start of each tile's segment (the fallback emit path advances it with atomics)
-        large_tiles = o; o = align_up(o + 4 * T);  // tiles whose list is too long for the register sort
+        large_tiles = o; o = align_up(o + 4 * T);  // the frame's LONG tiles (sorted ahead of the fused kernel, blended by its deep workers)
         n_total = o;    o = align_up(o + 64);      // [0] N, [1] capacity-exceeded gate, [2] number of long-tile candidates, [3] sparse-frame flag, [4] long-tile threshold
         seg_first = o;  o = align_up(o + 4 * (T + 1));  // first checkpoint slot of each tile; [T] = number of slots
         quad_nproc = o; o = align_up(o + 16 * T);       // list entries the forward blend walked, per (tile, quad)
@@ -199,8 +199,8 @@ void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const 
                            uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
 // (re-zeroes tile_count, and cell_count if given, behind itself)
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
-                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot,
-                      uint32_t ticket, hipStream_t st);
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
                  const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)

@@ -103,6 +103,63 @@ def scene_gaussians(P, cam, seed=0, sh_coeffs=16, sigma_px=4.5, nonunit_quat=Fal
     return {"means3D": means, "scales": scales, "rotations": q.astype(np.float32), "opacities": opac, "shs": shs}
 
 
+def trained_scene_gaussians(P, cam, seed=0, sh_coeffs=16, human=110_210, median_px=1.6, ref_P=200_000):
+    """A scene shaped like what HUGS actually renders after some thousand steps, not like `scene_gaussians`' uniform
+    fog: the reference builds its scene with create_from_pcd from a COLMAP cloud -- points on SURFACES -- and then clones,
+    splits and prunes (/root/reference/hugs/models/scene.py:166-194,441-458), and resets opacities to <= 0.01 every
+    `opacity_reset_interval` steps (cfg_files/release/neuman/hugs_scene.yaml:112).  Here:
+      * depths clustered on a few surfaces -- a ground plane and five walls / objects, a few centimetres thick;
+      * heavy-tailed sizes: projected sigma ~ median_px * lognormal(1.2), so 1-2 % of the splats are 100 px and more across
+        (the big background splats every trained 3DGS scene keeps) while most are a pixel or two;
+      * 30 % of the opacities <= 0.02 (the population just after a reset), the rest sigmoid(N(0, 1.5));
+      * `human` Gaussians on a person-sized body SHELL 4-5 units in front of the camera (a thin surface, not a filled blob:
+        what the SMPL-initialised human model is), in front of it all.
+    Same dictionary as scene_gaussians; the human comes FIRST (the order render_human_scene concatenates in)."""
+    rng = np.random.default_rng(seed)
+    H, W = cam["image_height"], cam["image_width"]
+    tanx, tany = math.tan(cam["fovx"] / 2), math.tan(cam["fovy"] / 2)
+    f = W / (2.0 * tanx)
+    # ---- scene: surfaces
+    kind = rng.integers(0, 6, P)
+    u, v = rng.uniform(-1.1, 1.1, P), rng.uniform(-1.1, 1.1, P)
+    z = np.empty(P)
+    ground = kind == 0
+    z[ground] = rng.uniform(2.0, 20.0, ground.sum())                       # the ground: all depths, below the horizon
+    v[ground] = 0.25 + 0.85 * (2.0 / z[ground])                            # (a plane 0.5 units under the camera, roughly)
+    wall_z = np.array([6.0, 9.0, 12.0, 15.0, 19.0])
+    for k in range(1, 6):
+        m = kind == k
+        z[m] = wall_z[k - 1] + 0.03 * rng.standard_normal(m.sum())        # a wall: a few centimetres thick
+        u[m] = np.clip((k - 3) * 0.35 + 0.45 * rng.standard_normal(m.sum()), -1.1, 1.1)
+    x, y = u * z * tanx, v * z * tany
+    sig_px = median_px * np.exp(1.2 * rng.standard_normal(P)) / math.sqrt(max(P, 1) / ref_P)
+    base = z * sig_px / f
+    scales = base[:, None] * np.exp(0.35 * rng.standard_normal((P, 3)))
+    opac = 1.0 / (1.0 + np.exp(-1.5 * rng.standard_normal(P)))
+    reset = rng.uniform(size=P) < 0.30
+    opac[reset] = rng.uniform(0.004, 0.02, reset.sum())
+    # ---- human: a body shell (ellipsoid surface) ~1.7 units tall at depth 4.5
+    Ph = int(human)
+    th, ph = rng.uniform(0, 2 * math.pi, Ph), np.arccos(rng.uniform(-1, 1, Ph))
+    hx = 0.28 * np.sin(ph) * np.cos(th)
+    hy = 0.85 * np.cos(ph) + 0.05
+    hz = 4.5 + 0.18 * np.sin(ph) * np.sin(th) + 0.004 * rng.standard_normal(Ph)
+    h_sig = 0.0045 * np.exp(0.3 * rng.standard_normal((Ph, 3))) / math.sqrt(max(Ph, 1) / 110_210)
+    h_op = rng.uniform(0.3, 0.98, Ph)
+    n = P + Ph
+    means = np.concatenate([np.stack([hx, hy, hz], 1), np.stack([x, y, z], 1)], 0).astype(np.float32)
+    sc = np.concatenate([h_sig, scales], 0).astype(np.float32)
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= rng.uniform(0.9, 1.1, (n, 1))                                      # (HUGS does not normalise the human's quaternions)
+    shs = np.zeros((n, sh_coeffs, 3), np.float32)
+    shs[:, 0] = rng.standard_normal((n, 3))
+    if sh_coeffs > 1:
+        shs[:, 1:] = 0.1 * rng.standard_normal((n, sh_coeffs - 1, 3))
+    return {"means3D": means, "scales": sc, "rotations": q.astype(np.float32),
+            "opacities": np.concatenate([h_op, opac], 0).astype(np.float32)[:, None], "shs": shs, "n_human": Ph}
+
+
 def pixel_grad(H, W, seed=1):
     """dL/dcolor ~ N(0,1) / (3 H W)."""
     rng = np.random.default_rng(seed)

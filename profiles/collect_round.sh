@@ -13,6 +13,9 @@ bash profiles/collect_workload.sh ${TAG}_c3_110210 tools/bench_c3.py > /dev/null
 bash profiles/collect_workload.sh ${TAG}_c3_6890 tools/bench_c3.py 6890 > /dev/null 2>&1
 bash profiles/collect_workload.sh ${TAG}_c4 tools/bench_c4.py > /dev/null 2>&1
 HGS_CONCURRENT_RENDERS=0 bash profiles/collect_workload.sh ${TAG}_c4_serial tools/bench_c4.py > /dev/null 2>&1
+# (round 4) a trained-scene-like frame -- surfaces, heavy-tailed sizes, reset opacities, a human in front -- and the all-rows step
+bash profiles/collect_workload.sh ${TAG}_trained bench.py --profile trained --no-cpu-baseline --no-two-streams > /dev/null 2>&1
+bash profiles/collect_workload.sh ${TAG}_step tools/bench_step.py --only fused > /dev/null 2>&1
 OUT=$ROOT/gpurun_out/$TAG
 python3 tools/sweep.py > "$OUT/${TAG}_sweep.json" 2> "$OUT/sweep.err"
 python3 tools/bench_fwd.py > "$OUT/${TAG}_fwd.jsonl" 2> "$OUT/fwd.err"

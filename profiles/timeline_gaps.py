@@ -25,8 +25,16 @@ def main(path, skip=30):
     if not frames:
         print("no frames")
         return
-    n = max(set(len(f) for f in frames), key=[len(f) for f in frames].count)
-    frames = [f for f in frames if len(f) == n]
+    # (a step may hold several KINDS of frames -- the joint and the human-only render of a HUGS step: one table per kind,
+    #  most frequent first)
+    kinds = sorted(set(len(f) for f in frames), key=lambda k: -[len(f) for f in frames].count(k))
+    for n in kinds:
+        group = [f for f in frames if len(f) == n]
+        if len(group) >= 3:
+            report(path, group, n)
+
+
+def report(path, frames, n):
     acc = defaultdict(lambda: [0.0, 0.0, 0.0])
     order = []
     span = 0.0

@@ -1239,3 +1239,54 @@ def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monke
     assert not np.array_equal(a["color"], b["color"]), "the depth-parallel path did not run"
     for k in a["grads"]:
         assert rel_l2(a["grads"][k], b["grads"][k]) <= 1e-5, k
+
+
+@pytest.mark.gpu
+def test_trained_scene_profile_at_1080p(device):
+    """Round 4: the tracked numbers also hold a scene shaped like what HUGS renders after some thousand steps
+    (hugs_amd.synthetic.trained_scene_gaussians; /root/reference/hugs/models/scene.py:166-194,441-458,
+    cfg_files/release/neuman/hugs_scene.yaml:112): Gaussians on surfaces, heavy-tailed sizes (splats a hundred pixels across),
+    a third of the opacities just reset, a 110 210-Gaussian body shell in front -- 310 210 Gaussians at 1080p, SH degree 0
+    on [P,16,3] storage.  Sorted list, ranges and radii exact, image and every gradient within the oracle's bars; the frame
+    has long tiles (the deep workers and the long tiles' sort kernels run) and, rendered twice, is deterministic."""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _debug_forward_state
+    from hugs_amd import synthetic as syn
+    H, W, D = 1080, 1920, 0
+    cam = syn.pinhole_camera(H, W)
+    g = syn.trained_scene_gaussians(200_000, cam, seed=0)
+    P = g["means3D"].shape[0]
+    dL = syn.pixel_grad(H, W, seed=7) * np.float32(3 * H * W)
+    tfx, tfy = math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5)
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    settings = GaussianRasterizationSettings(H, W, tfx, tfy, to_dev(bg, device), 1.0, to_dev(cam["world_view_transform"], device),
+                                             to_dev(cam["full_proj_transform"], device), D, to_dev(cam["camera_center"], device), False, False)
+    t = {k: to_dev(g[k], device, True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+    images = []
+    for _ in range(2):   # (the second frame runs on the first one's hints)
+        for x in list(t.values()) + [means2D]:
+            x.grad = None
+        color, radii = GaussianRasterizer(settings)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                                                    scales=t["scales"], rotations=t["rotations"])
+        color.backward(to_dev(dL, device))
+        images.append(color.detach().clone())
+    assert torch.equal(images[0], images[1])
+    _, _, st = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
+                                    scales=t["scales"].detach(), rotations=t["rotations"].detach())
+    inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
+                    tfx, tfy, H, W, bg, shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
+    ho.set_threads(os.cpu_count() or 1)
+    ref = ho.forward(inp)
+    lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert lens.max() > 2048 and (ref["radii"] >= 100).mean() > 0.003     # long tiles; the tail of big splats is there
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"]) and st["N"] == ref["N"]
+    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    check_image(images[0].cpu().numpy(), ref["color"], "trained-scene colour")
+    refg = ho.backward(inp, ref, dL)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        r = refg[k]
+        assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+    assert rel_l2(means2D.grad.cpu().numpy(), refg["means2D"]) <= GRAD_REL_TOL

@@ -40,6 +40,12 @@ def main():
             row[mode]["whole_frame_GBps"] = d["whole_frame"]["GB_per_s"]
         out["points"].append(row)
         print(f"P={P}: fwd {row['fwd']['fps']:.0f} FPS, fwd+bwd {row['fwd_bwd']['fps']:.0f} FPS, N={row['num_rendered_N']}", file=sys.stderr)
+    # (round 4) the trained-scene profile: 200 000 scene + 110 210 human Gaussians, surfaces / heavy-tailed sizes / reset opacities
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--profile", "trained", "--steps", "300", "--warmup", "40",
+                        "--no-cpu-baseline", "--no-two-streams"], capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    out["trained_profile"] = {"fwd_bwd": {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]},
+                              "gaussians": d["config"]["gaussians"], "num_rendered_N": d["config"]["num_rendered_N"], "visible": d["config"]["visible"]}
     print(json.dumps(out, indent=1))
 
 

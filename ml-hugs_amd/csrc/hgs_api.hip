@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -183,7 +184,9 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
 //    stream has drained -- growth is rare, one synchronisation then is cheap.
 struct TileCounters {
     uint32_t* buf = nullptr; size_t tiles = 0; bool dirty = true;
+    uint64_t last_use = 0;   // (table clock: eviction takes the least recently used)
     std::mutex lease;
+    ~TileCounters() { if (buf) (void)hipFree(buf); }
 };
 struct TcKey {
     int dev; hipStream_t st;
@@ -194,18 +197,21 @@ struct TcHash {
 };
 constexpr size_t TC_MAX_ENTRIES = 64;
 std::mutex g_tc_mu;
-std::unordered_map<TcKey, std::unique_ptr<TileCounters>, TcHash> g_tc;
+uint64_t g_tc_clock = 0;
+// (shared_ptr: a caller PINS its entry while it holds it -- an eviction by another thread between the table lookup and the lease
+//  can then drop the table's reference but never the entry itself)
+std::unordered_map<TcKey, std::shared_ptr<TileCounters>, TcHash> g_tc;
 
 // RAII lease of a stream's counters (see above)
 struct TileCounterLease {
-    TileCounters* e = nullptr;
+    std::shared_ptr<TileCounters> e;
     bool scan_enqueued = false;
     void release()
     {
         if (!e) return;
         e->dirty = !scan_enqueued;
         e->lease.unlock();
-        e = nullptr;
+        e.reset();
     }
     ~TileCounterLease() { release(); }
 };
@@ -214,34 +220,34 @@ int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, TileCoun
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    TileCounters* e = nullptr;
+    std::shared_ptr<TileCounters> e;
     {
         std::lock_guard<std::mutex> lk(g_tc_mu);
         auto it = g_tc.find(TcKey{dev, st});
         if (it == g_tc.end()) {
             if (g_tc.size() >= TC_MAX_ENTRIES) {
-                // drop what is not in use: entries nobody holds whose stream has nothing pending (or no longer exists)
-                for (auto k = g_tc.begin(); k != g_tc.end();) {
-                    TileCounters* c = k->second.get();
-                    bool drop = false;
-                    if (k->first.dev == dev && c->lease.try_lock()) {
-                        drop = hipStreamQuery(k->first.st) != hipErrorNotReady;
-                        (void)hipGetLastError();  // (a destroyed stream's handle is an error here, not later)
-                        c->lease.unlock();
-                    }
-                    if (drop) {
-                        if (c->buf) (void)hipFree(c->buf);
-                        k = g_tc.erase(k);
-                    } else
-                        ++k;
+                // Drop the least recently used entries nobody holds (use_count 1 = the table's own reference), down to half
+                // the table.  Their streams may still have frames in flight that use the arrays -- and may no longer exist,
+                // so their handles are not probed: the device is drained once, then the arrays are freed.  (Rare: more than
+                // TC_MAX_ENTRIES streams have rendered on this device.)
+                std::vector<std::pair<uint64_t, TcKey>> idle;
+                for (auto& kv : g_tc)
+                    if (kv.first.dev == dev && kv.second.use_count() == 1) idle.push_back({kv.second->last_use, kv.first});
+                std::sort(idle.begin(), idle.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+                if (!idle.empty()) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipGetLastError();
+                    const size_t drop = std::min(idle.size(), g_tc.size() - TC_MAX_ENTRIES / 2);
+                    for (size_t k = 0; k < drop; ++k) g_tc.erase(idle[k].second);
                 }
             }
-            it = g_tc.emplace(TcKey{dev, st}, std::make_unique<TileCounters>()).first;
+            it = g_tc.emplace(TcKey{dev, st}, std::make_shared<TileCounters>()).first;
         }
-        e = it->second.get();
+        e = it->second;
+        e->last_use = ++g_tc_clock;
     }
     e->lease.lock();  // (outside the table lock: another thread may be between its preprocess kernel and its scan)
-    lease->e = e;
+    lease->e = e;   // (the lease holds the pin)
     const size_t want = (tiles + 7) / 8 * 8;  // the scan reads whole groups of eight
     if (e->tiles < want) {
         if (e->buf) {

@@ -369,7 +369,7 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // are written as zeros straight from registers.  Waves whose rows are not one block of one array (M != 16, a wave that
 // straddles the two segments) keep the per-thread path.
 constexpr int SH_ROW_F4 = 12;  // float4 per row at M = 16
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))   // (<= 128 VGPRs: four waves per SIMD hold 262 144 Gaussians at once)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                            const float* __restrict__ opacities_, const float* __restrict__ scales_, const float* __restrict__ rots_,
                            const float* __restrict__ cov3D_precomp_, SecondInputs in2, const float* __restrict__ V,
@@ -441,11 +441,28 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     float4 acc0 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i];
     float4 acc1 = reinterpret_cast<const float4*>(grad_accum)[3 * (size_t)i + 1];
     const float acc_b = grad_accum[12 * (size_t)i + 8];
+    // (round 4) the Gaussian's small inputs are fetched here, with the accumulator and the record and whether or not it turns
+    // out to be visible: one memory round trip instead of three dependent ones (record -> opacity -> mean / scale / rotation)
+    // in a kernel whose whole grid is resident at once, three waves per SIMD, and lasts as long as one wave's chain of loads:
+    // C2 28.4 -> 27.1 us, C4 22.4 -> 20.8, the 110k human 12.6 -> 11.3, the SMPL template 8.0 -> 6.9 (same box).
+    // (The forward kernel did NOT gain from the same change -- C2 18.0 us either way, the 110k human 13.9 -> 16.0 -- nor from
+    //  starting its cell-counter atomics before the SH row fetches so that the two round trips overlap: C2 18.1 -> 21.2 us.)
+    const float in_x = means3D[3 * j], in_y = means3D[3 * j + 1], in_z = means3D[3 * j + 2], in_op = opacities[j];
+    float in_sc[3] = {0.f, 0.f, 0.f}, in_q[4] = {0.f, 0.f, 0.f, 0.f}, in_S[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in_S[k] = cov3D_precomp[6 * j + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in_sc[k] = scales[3 * j + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in_q[k] = rots[4 * j + k];   // (scalar loads: the caller's tensor need not be 16-byte aligned)
+    }
     {
         const float4 hc = reinterpret_cast<const float4*>(splats + i)[3];   // the half-conic quarter of the record
         const bool live = __float_as_int(reinterpret_cast<const float4*>(splats + i)[2].z) > 0;  // else: record unset
         const float A = live ? hc.x * LN2 : 0.0f, B = live ? hc.y * LN2 : 0.0f, C = live ? hc.z * LN2 : 0.0f;
-        const float op = live ? opacities[j] : 0.0f;
+        const float op = live ? in_op : 0.0f;
         const float sx = acc0.x, sy = acc0.y;
         acc0.x = (0.5f * (float)cam.W) * (2.0f * A * sx + B * sy);
         acc0.y = (0.5f * (float)cam.H) * (2.0f * C * sy + B * sx);
@@ -477,7 +494,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     auto per_gaussian = [&]() {
     const uint32_t clamped = __float_as_uint(tail.w);
 
-    const float x = means3D[3 * j], y = means3D[3 * j + 1], z = means3D[3 * j + 2];
+    const float x = in_x, y = in_y, z = in_z;
     float pv[3];
     pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
     pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
@@ -485,9 +502,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     float S[6];
     if (cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) S[k] = cov3D_precomp[6 * j + k];
+        for (int k = 0; k < 6; ++k) S[k] = in_S[k];
     } else {
-        cov3d_from_scale_rot(scales + 3 * j, cam.mod, rots + 4 * j, S);
+        cov3d_from_scale_rot(in_sc, cam.mod, in_q, S);
     }
     Ewa e;
     ewa_project(pv, cam, V, S, e);
@@ -632,8 +649,8 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     // Sigma3D -> scale, quaternion (quaternion gradient w.r.t. the UN-normalised q)
     if (!cov3D_precomp) {
         const float mod = cam.mod;
-        const float r = rots[4 * j], qx = rots[4 * j + 1], qy = rots[4 * j + 2], qz = rots[4 * j + 3];
-        const float s[3] = {mod * scales[3 * j], mod * scales[3 * j + 1], mod * scales[3 * j + 2]};
+        const float r = in_q[0], qx = in_q[1], qy = in_q[2], qz = in_q[3];
+        const float s[3] = {mod * in_sc[0], mod * in_sc[1], mod * in_sc[2]};
         const float R[3][3] = {
             {1.0f - 2.0f * (qy * qy + qz * qz), 2.0f * (qx * qy - r * qz), 2.0f * (qx * qz + r * qy)},
             {2.0f * (qx * qy + r * qz), 1.0f - 2.0f * (qx * qx + qz * qz), 2.0f * (qy * qz - r * qx)},

@@ -10,7 +10,9 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 
+#include <algorithm>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <thread>
 #include <tuple>
@@ -23,9 +25,23 @@ using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-struct Hint { int64_t n; bool has_long; bool sparse; };
+struct Hint { int64_t n; bool has_long; bool sparse; uint64_t stamp = 0; };
+uint64_t g_hint_clock = 0;
+constexpr size_t HINT_SHAPES = 256;   // shapes remembered; the least recently used go first (round 3 cleared the table at 256)
 std::mutex g_mu;
 std::map<std::tuple<int, int64_t, int64_t, int64_t>, Hint> g_hints;   // (device, P, H, W) -> previous frame of this shape
+// (caller holds g_mu)
+void remember_hint(const std::tuple<int, int64_t, int64_t, int64_t>& key, Hint h)
+{
+    h.stamp = ++g_hint_clock;
+    g_hints[key] = h;
+    while (g_hints.size() > HINT_SHAPES) {   // densification changes P all the time: drop the least recently used quarter
+        std::vector<std::pair<uint64_t, std::tuple<int, int64_t, int64_t, int64_t>>> by_age;
+        for (auto& kv : g_hints) by_age.push_back({kv.second.stamp, kv.first});
+        std::sort(by_age.begin(), by_age.end());
+        for (size_t k = 0; k < HINT_SHAPES / 4; ++k) g_hints.erase(by_age[k].second);
+    }
+}
 bool g_use_hint = true;
 bool g_upstream_scale_grad = false;   // HGS_BWD_UPSTREAM_SCALE_GRAD on every backward (set_upstream_scale_grad)
 bool g_use_ckpt = true;   // leave checkpoints for the depth-segmented backward on sparse frames (HGS_BWD_SEGMENTED=0: off)
@@ -48,11 +64,23 @@ int64_t round_capacity(int64_t n)
 // is ordered, so the next frame on that stream may overwrite it.  (The Python binding keeps the same policy: _arena.)
 // Keyed by the host thread too: two threads issuing frames on one stream interleave their enqueues, and the second frame's
 // first kernel would overwrite scratch the first frame's later kernels have yet to read.
-std::map<std::tuple<int, void*, std::thread::id>, Tensor> g_arenas;
+struct Arena { Tensor t; uint64_t stamp = 0; };
+std::map<std::tuple<int, void*, std::thread::id>, Arena> g_arenas;
+uint64_t g_arena_clock = 0;
+constexpr size_t MAX_ARENAS = 32;   // threads and streams come and go: the least recently used arenas are let go
 Tensor arena_for(int dev, void* stream, size_t bytes, const at::TensorOptions& bopts)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    Tensor& t = g_arenas[std::make_tuple(dev, stream, std::this_thread::get_id())];
+    const auto key = std::make_tuple(dev, stream, std::this_thread::get_id());
+    Arena& a = g_arenas[key];
+    a.stamp = ++g_arena_clock;
+    while (g_arenas.size() > MAX_ARENAS) {
+        auto oldest = g_arenas.begin();
+        for (auto it = g_arenas.begin(); it != g_arenas.end(); ++it)
+            if (it->second.stamp < oldest->second.stamp) oldest = it;
+        g_arenas.erase(oldest);   // (never `a`: it carries the newest stamp)
+    }
+    Tensor& t = g_arenas[key].t;
     if (!t.defined() || (size_t)t.numel() < bytes) t = at::empty({(int64_t)(bytes + bytes / 4 + 4096)}, bopts);
     return t;
 }
@@ -104,11 +132,33 @@ void point_at_grads(hgs_backward_args& bw, float* base, const GradLayout& g, int
     bw.seg2_dL_dscales = base + g.off[14], bw.seg2_dL_drotations = base + g.off[15];
 }
 
+// (the second set goes to the kernels as raw pointers: a tensor on another device, of another dtype or with another row count
+//  than means3D would be read -- or its gradient written -- out of bounds instead of raising)
+void check_segment_tensor(const char* name, const Tensor& t, const Tensor& means3D, int64_t tail, bool three_d = false)
+{
+    if (!t.defined() || t.numel() == 0) return;
+    TORCH_CHECK(t.device() == means3D.device(), "second: ", name, " is on ", t.device(), ", means3D on ", means3D.device());
+    TORCH_CHECK(t.scalar_type() == at::kFloat, "second: ", name, " must be float32");
+    TORCH_CHECK(t.size(0) == means3D.size(0), "second: ", name, " has ", t.size(0), " rows, means3D has ", means3D.size(0));
+    if (three_d) {
+        TORCH_CHECK(t.dim() == 3 && t.size(2) == 3, "second: ", name, " must have dimensions (num_points, M, 3)");
+    } else if (tail > 0) {
+        TORCH_CHECK(t.numel() == means3D.size(0) * tail, "second: ", name, " must have dimensions (num_points, ", tail, ")");
+    }
+}
+
 void fill_segment(hgs_segment& g, const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac,
                   const Tensor& scales, const Tensor& rot, const Tensor& cov)
 {
     memset(&g, 0, sizeof g);
     if (!means3D.defined() || means3D.numel() == 0) return;
+    TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "second: means3D must have dimensions (num_points, 3)");
+    check_segment_tensor("shs", sh, means3D, 0, true);
+    check_segment_tensor("colors_precomp", colors, means3D, 3);
+    check_segment_tensor("opacities", opac, means3D, 1);
+    check_segment_tensor("scales", scales, means3D, 3);
+    check_segment_tensor("rotations", rot, means3D, 4);
+    check_segment_tensor("cov3D_precomp", cov, means3D, 6);
     g.P = (int32_t)means3D.size(0);
     g.M = sh.defined() && sh.numel() ? (int32_t)sh.size(1) : 0;
     g.means3D = fptr(means3D), g.shs = fptr(sh), g.colors_precomp = fptr(colors), g.opacities = fptr(opac);
@@ -153,6 +203,7 @@ public:
                scales_b = f32c(scales_b_), rot_b = f32c(rot_b_), cov_b = f32c(cov_b_);
         const int64_t P1 = means3D.size(0), P2 = means3D_b.defined() ? means3D_b.size(0) : 0;
         TORCH_CHECK(P2 == 0 || P1 > 0, "a second set of Gaussians needs a non-empty first one");
+        TORCH_CHECK(P2 == 0 || means3D_b.device() == dev, "second: means3D is on ", means3D_b.device(), ", the first set of Gaussians on ", dev);
         TORCH_CHECK(P2 == 0 || (means3D_b.dim() == 2 && means3D_b.size(1) == 3), "means3D must have dimensions (num_points, 3)");
         const int64_t P = P1 + P2;
         const auto fopts = at::TensorOptions().dtype(at::kFloat).device(dev);
@@ -182,6 +233,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(g_mu);
             auto it = g_hints.find(key);
+            if (it != g_hints.end()) it->second.stamp = ++g_hint_clock;   // (used: not the next one to go)
             // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
             a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse || it->second.has_long)) ? 1 : 0;
             if (g_use_hint && it != g_hints.end()) {
@@ -214,8 +266,7 @@ public:
         if (n < 0) raise_last("rasterize_gaussians");
         {
             std::lock_guard<std::mutex> lk(g_mu);
-            if (g_hints.size() > 256) g_hints.clear();
-            g_hints[key] = Hint{n, bw.state.has_long_tiles != 0, bw.state.sparse_frame != 0};
+            remember_hint(key, Hint{n, bw.state.has_long_tiles != 0, bw.state.sparse_frame != 0});
         }
         t_last_n = n, t_last_capacity = bw.state.binning_capacity;
         t_last_long = bw.state.has_long_tiles != 0, t_last_sparse = bw.state.sparse_frame != 0;
@@ -357,7 +408,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "(N, binning capacity, has long tiles, sparse) of this thread's last forward");
     m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse) {
         std::lock_guard<std::mutex> lk(g_mu);
-        g_hints[std::make_tuple(dev, P, H, W)] = Hint{n, has_long, sparse};
+        remember_hint(std::make_tuple(dev, P, H, W), Hint{n, has_long, sparse});
     }, py::arg("dev"), py::arg("P"), py::arg("H"), py::arg("W"), py::arg("n"), py::arg("has_long"), py::arg("sparse") = true);
     m.def("clear_hints", [] { std::lock_guard<std::mutex> lk(g_mu); g_hints.clear(); });
     m.def("use_hints", [](bool on) { g_use_hint = on; });

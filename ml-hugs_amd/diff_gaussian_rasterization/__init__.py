@@ -260,11 +260,18 @@ _last_sparse = {}
 _USE_CKPT = os.environ.get("HGS_BWD_SEGMENTED", "1") != "0"
 
 
+_HINT_SHAPES = 256   # shapes remembered (densification changes P all the time: do not grow without bound)
+
+
 def _remember(key, n, has_long, sparse=None, to_cpp=True):
-    if len(_last_num_rendered) > 256:   # densification changes P all the time: do not grow without bound
-        _last_num_rendered.clear()
-        _max_num_rendered.clear()
-        _last_sparse.clear()
+    # least recently used shapes go first -- not the whole table at once (round 3 wiped all three tables at 256 shapes: a
+    # densifying run then paid one blocking frame per live shape each time); dicts keep insertion order, re-inserting = touching
+    _last_num_rendered.pop(key, None)
+    while len(_last_num_rendered) >= _HINT_SHAPES:
+        old = next(iter(_last_num_rendered))
+        del _last_num_rendered[old]
+        _max_num_rendered.pop(old, None)
+        _last_sparse.pop(old, None)
     if sparse is not None:
         _last_sparse[key] = bool(sparse)
     if to_cpp and _cpp is not None:   # ... and what the Python paths learnt, the C++ node uses
@@ -337,16 +344,19 @@ def _align(n, a=256):
 # gs_trainer.py:448-684): one persistent arena per (device, stream) instead of three allocations per frame.  Work on a
 # stream is ordered, so the next frame on that stream may overwrite it.
 _arenas = {}
+_MAX_ARENAS = 32   # (device, stream, host thread) triples that keep a persistent scratch arena
 
 
 def _arena(dev, stream_id, nbytes):
     # (per host thread as well: two threads issuing frames on ONE stream interleave their enqueues, and the second frame's
     #  first kernel would overwrite scratch the first frame's later kernels have yet to read)
     key = (dev.index, stream_id, threading.get_ident())
-    t = _arenas.get(key)
+    t = _arenas.pop(key, None)   # (re-inserted below: the dict's order is the order of last use)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
-        _arenas[key] = t
+    _arenas[key] = t
+    while len(_arenas) > _MAX_ARENAS:   # threads and streams come and go: the least recently used arenas are let go
+        del _arenas[next(iter(_arenas))]
     return t
 
 
@@ -369,6 +379,31 @@ def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=No
     if ck:
         args.scratch[3], args.scratch_bytes[3] = base_al + g + im + b, ck
     return buf, (o, g, o + g, im, o + g + im, b)   # geom off/len, image off/len, binning off/len
+
+
+def _check_segment(device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp):
+    """The second set of Gaussians goes to the kernels as raw pointers: a tensor on another device, of another dtype or
+    with another row count than means3D would be read (or its gradient written) out of bounds instead of raising."""
+    P2 = int(means3D.shape[0])
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("second: means3D must have dimensions (num_points, 3)")
+    for name, t, tail in (("means3D", means3D, (3,)), ("shs", sh, None), ("colors_precomp", colors_precomp, (3,)),
+                          ("opacities", opacities, None), ("scales", scales, (3,)), ("rotations", rotations, (4,)),
+                          ("cov3D_precomp", cov3D_precomp, (6,))):
+        if t is None or t.numel() == 0:
+            continue
+        if t.device != device:
+            raise RuntimeError(f"second: {name} is on {t.device}, the first set of Gaussians on {device}")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"second: {name} must be float32, got {t.dtype}")
+        if int(t.shape[0]) != P2:
+            raise RuntimeError(f"second: {name} has {int(t.shape[0])} rows, means3D has {P2}")
+        if name == "shs" and (t.ndim != 3 or t.shape[2] != 3):
+            raise RuntimeError("second: shs must have dimensions (num_points, M, 3)")
+        if name == "opacities" and t.numel() != P2:
+            raise RuntimeError("second: opacities must have dimensions (num_points, 1)")
+        if tail is not None and tuple(t.shape[1:]) != tail:
+            raise RuntimeError(f"second: {name} must have dimensions (num_points, {tail[0]})")
 
 
 def _fill_segment(seg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp):
@@ -432,6 +467,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         args, state = bw.fwd, bw.state
         _fill_forward(args, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
         if sec is not None:
+            _check_segment(dev, *sec)
             _fill_segment(args.seg2, *sec)
         args.out_color, args.radii = color.data_ptr(), _ptr(radii)
         args.visible = _ptr(visible)

@@ -36,7 +36,9 @@ def _lib():
 
 
 class _SsimL1(torch.autograd.Function):
-    """(pred [C,H,W], gt [C,H,W]) -> (ssim mean, l1 mean, l1 sum): hgs_ssim_l1_forward / hgs_ssim_l1_backward."""
+    """(pred [C,H,W], gt [C,H,W]) -> ONE tensor [ssim mean, l1 mean, l1 sum]: hgs_ssim_l1_forward / hgs_ssim_l1_backward.
+    (One output: the terms the callers hand out are views of it, and a view keeps its base alive -- which is what lets the
+    shared-pass entry below hold a WEAK reference and still be found while any of the terms is in use.)"""
 
     @staticmethod
     def forward(ctx, pred, gt):
@@ -52,22 +54,20 @@ class _SsimL1(torch.autograd.Function):
         if rc < 0:
             _raise_last(lib, "ssim_l1_forward")
         ctx.save_for_backward(pred, gt, maps)
-        return out[0], out[1], out[2]
+        return out
 
     @staticmethod
-    def backward(ctx, g_ssim, g_l1_mean, g_l1_sum):
-        _LAST.pop("entry", None)                  # (this graph is spent: a later call on the same pair computes afresh)
+    def backward(ctx, g):
+        hit = _LAST.get("entry")                  # (THIS graph is spent: a later call on the same pair computes afresh;
+        if hit is not None and hit[4] == id(ctx):  #  an entry that belongs to another graph stays)
+            _LAST.pop("entry", None)
         pred, gt, maps = ctx.saved_tensors
         lib = _lib()
         Cn, H, W = pred.shape
         # d(l1 mean) = d(l1 sum) / (C H W): one device scalar for the kernel, no host round trip
-        g_l1 = None
-        if g_l1_mean is not None:
-            g_l1 = g_l1_mean / float(Cn * H * W)
-        if g_l1_sum is not None:
-            g_l1 = g_l1_sum if g_l1 is None else g_l1 + g_l1_sum
-        g_l1 = g_l1.to(torch.float32).contiguous() if g_l1 is not None else None
-        g_s = g_ssim.to(torch.float32).contiguous() if g_ssim is not None else None
+        g = g.to(torch.float32)
+        g_s = g[0:1].contiguous()
+        g_l1 = (g[1:2] / float(Cn * H * W) + g[2:3]).contiguous()
         grad = torch.empty_like(pred)
         with torch.cuda.device(pred.device):
             rc = lib.hgs_ssim_l1_backward(Cn, H, W, pred.data_ptr(), gt.data_ptr(), maps.data_ptr() if maps is not None else None,
@@ -90,8 +90,11 @@ def _prep(pred, gt):
     return pred.contiguous(), gt.contiguous()
 
 
-# ssim(a, b) followed by l1_loss(a, b) on the same tensors (loss.py:88-99) is one pass: the pair's result is kept while
-# both tensors are alive and unchanged (same objects, same version counters, same storage) and until its backward has run.
+# ssim(a, b) followed by l1_loss(a, b) on the same tensors (loss.py:88-99) is one pass: the pair's result is found again
+# while both tensors are alive and unchanged (same objects, same version counters, same storage), while the CALLER still
+# holds the first call's result -- the entry keeps only weak references to the three outputs, so a result nobody uses takes
+# its autograd node and the 3 x C x H x W partials (75 MB at 1080p) with it at once, not at the next call -- and until that
+# graph's backward has run (a backward of ANOTHER graph leaves the entry alone).  `l1_ssim` is the explicit form of the same.
 # HGS_LOSS_SHARE_PASS=0 turns the sharing off (every call computes afresh) -- for callers whose custom kernels rewrite a
 # tensor's memory behind autograd's back, which no version counter records.
 _LAST = {}
@@ -99,16 +102,18 @@ _SHARE = os.environ.get("HGS_LOSS_SHARE_PASS", "1") != "0"
 
 
 def _terms(pred, gt):
-    """(ssim mean, l1 mean, l1 sum) of one [C,H,W] pair, computed once per (pred, gt) pair and version."""
+    """[ssim mean, l1 mean, l1 sum] (one tensor) of one [C,H,W] pair, computed once per (pred, gt) pair and version."""
     key = (id(pred), id(gt), pred._version, gt._version, pred.data_ptr(), gt.data_ptr(), pred.requires_grad and torch.is_grad_enabled())
     hit = _LAST.get("entry")
     if _SHARE and hit is not None and hit[0] == key and hit[1]() is pred and hit[2]() is gt:
-        return hit[3]
+        out = hit[3]()
+        if out is not None:
+            return out
     out = _SsimL1.apply(pred, gt)
     if not _SHARE:
         return out
     try:
-        _LAST["entry"] = (key, weakref.ref(pred), weakref.ref(gt), out)
+        _LAST["entry"] = (key, weakref.ref(pred), weakref.ref(gt), weakref.ref(out), id(out.grad_fn))
     except TypeError:
         _LAST.pop("entry", None)
     return out

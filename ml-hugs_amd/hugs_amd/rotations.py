@@ -15,6 +15,17 @@ import torch
 from diff_gaussian_rasterization import _load, _raise_last, _require_gpu, _stream_ptr
 
 
+def _aligned(t):
+    """contiguous AND 16-byte aligned: the row kernels move float4s.  A contiguous view whose storage offset is not a
+    multiple of four floats -- a gradient that narrow / split / cat-backward carved out of a packed buffer -- is cloned
+    (`.contiguous()` alone returns such a view unchanged and the library then refuses its pointer)."""
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
+
 def _call(name, n, dev, *tensors):
     lib = _load()
     fn = getattr(lib, name)
@@ -38,7 +49,7 @@ class _MatrixToQuaternion(torch.autograd.Function):
     def backward(ctx, g):
         (matrix,) = ctx.saved_tensors
         grad = torch.empty_like(matrix)
-        _call("hgs_matrix_to_quaternion_backward", matrix.shape[0], matrix.device, matrix, g.contiguous(), grad)
+        _call("hgs_matrix_to_quaternion_backward", matrix.shape[0], matrix.device, matrix, _aligned(g), grad)
         return grad
 
 
@@ -54,7 +65,7 @@ class _Rotation6dToMatrix(torch.autograd.Function):
     def backward(ctx, g):
         (d6,) = ctx.saved_tensors
         grad = torch.empty_like(d6)
-        _call("hgs_rotation_6d_to_matrix_backward", d6.shape[0], d6.device, d6, g.contiguous(), grad)
+        _call("hgs_rotation_6d_to_matrix_backward", d6.shape[0], d6.device, d6, _aligned(g), grad)
         return grad
 
 
@@ -70,7 +81,7 @@ def matrix_to_quaternion(matrix):
         raise ValueError(f"Invalid rotation matrix shape {matrix.shape}.")
     _check(matrix, "matrix")
     batch = matrix.shape[:-2]
-    return _MatrixToQuaternion.apply(matrix.reshape(-1, 9).contiguous()).reshape(batch + (4,))
+    return _MatrixToQuaternion.apply(_aligned(matrix.reshape(-1, 9))).reshape(batch + (4,))
 
 
 def rotation_6d_to_matrix(d6):
@@ -79,4 +90,4 @@ def rotation_6d_to_matrix(d6):
         raise ValueError(f"Invalid 6-D rotation shape {d6.shape}.")
     _check(d6, "d6")
     batch = d6.shape[:-1]
-    return _Rotation6dToMatrix.apply(d6.reshape(-1, 6).contiguous()).reshape(batch + (3, 3))
+    return _Rotation6dToMatrix.apply(_aligned(d6.reshape(-1, 6))).reshape(batch + (3, 3))

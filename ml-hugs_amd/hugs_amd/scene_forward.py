@@ -17,6 +17,17 @@ from diff_gaussian_rasterization import _load, _raise_last, _require_gpu, _strea
 _PROTO = False
 
 
+def _aligned(t):
+    """contiguous AND 16-byte aligned: the row kernels move float4s.  A contiguous view whose storage offset is not a
+    multiple of four floats -- a gradient that narrow / split / cat-backward carved out of a packed buffer -- is cloned
+    (`.contiguous()` alone returns such a view unchanged and the library then refuses its pointer)."""
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
+
 def _lib():
     global _PROTO
     lib = _load()
@@ -54,7 +65,7 @@ class _SceneActivations(torch.autograd.Function):
         rotation, scales, opac = ctx.saved_tensors
         lib = _lib()
         P, M, dev = scales.shape[0], ctx.M, scales.device
-        c = lambda g: None if g is None else g.contiguous()
+        c = _aligned
         g_scales, g_rotq, g_opac, g_shs = c(g_scales), c(g_rotq), c(g_opac), c(g_shs)
         new = lambda g, shape: torch.empty(shape, dtype=torch.float32, device=dev) if g is not None else None
         d_scaling, d_rot, d_op = new(g_scales, (P, 3)), new(g_rotq, (P, 4)), new(g_opac, (P, 1))
@@ -83,8 +94,7 @@ def scene_activations(scaling, rotation, opacity, features_dc, features_rest):
             raise RuntimeError(f"{name} must be a float32 tensor of shape [{P}, k, 3]")
     if features_dc.shape[1] != 1:
         raise RuntimeError("_features_dc must have one coefficient per Gaussian")
-    return _SceneActivations.apply(scaling.contiguous(), rotation.contiguous(), opacity.contiguous(), features_dc.contiguous(),
-                                   features_rest.contiguous())
+    return _SceneActivations.apply(_aligned(scaling), _aligned(rotation), _aligned(opacity), _aligned(features_dc), _aligned(features_rest))
 
 
 def scene_forward(xyz, scaling, rotation, opacity, features_dc, features_rest, active_sh_degree):

@@ -877,6 +877,31 @@ def test_second_segment_argument_errors(device):
                            "scales": t["scales"], "rotations": t["rotations"]})
 
 
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+def test_second_segment_tensors_are_validated(binding, device, monkeypatch):
+    """the second set of Gaussians reaches the kernels as raw pointers -- a tensor with another row count than its
+    means3D, or one that lives on the host, must raise in the binding, not be read (or have its gradient written) out of bounds."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = make_scene(**CASES["basic_d3"])
+    t = gpu_tensors(sc, device)
+    rast = GaussianRasterizer(gpu_settings(sc, device))
+    kw = dict(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    good = {"means3D": t["means3D"].detach(), "opacities": t["opacities"].detach(), "shs": t["shs"].detach(),
+            "scales": t["scales"].detach(), "rotations": t["rotations"].detach()}
+    with pytest.raises(RuntimeError, match="rows"):
+        rast(**kw, second=dict(good, scales=good["scales"][:-3].contiguous()))
+    with pytest.raises(RuntimeError, match="rows"):
+        rast(**kw, second=dict(good, shs=good["shs"][:10].contiguous()))
+    with pytest.raises(RuntimeError, match=r"is on|device"):
+        rast(**kw, second=dict(good, rotations=good["rotations"].cpu()))
+    with pytest.raises(RuntimeError, match="dimensions"):
+        rast(**kw, second=dict(good, rotations=good["rotations"][:, :3].contiguous()))
+    color, _ = rast(**kw, second=good)   # (and the well-formed call still renders)
+    assert torch.isfinite(color).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # robustness of the host side of the library (VERDICT r2 #6)
 def test_more_pairs_than_32_bit_positions_is_an_error_not_a_wrap(device):

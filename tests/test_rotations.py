@@ -96,3 +96,28 @@ def test_hip_rotation_errors(device):
     with pytest.raises(RuntimeError):
         rotation_6d_to_matrix(torch.zeros(4, 6, device=device, dtype=torch.float64))
     assert matrix_to_quaternion(torch.zeros(0, 3, 3, device=device)).shape == (0, 4)
+
+
+@pytest.mark.gpu
+def test_hip_rotations_take_gradients_and_inputs_at_odd_storage_offsets(device):
+    """a contiguous view whose storage offset is not a multiple of four floats -- what narrow / split / cat-backward
+    hand out of a packed buffer -- used to make the row kernels refuse the pointer ('not 16-byte aligned') in backward.  The
+    wrappers now realign such tensors: same values and gradients as with aligned ones."""
+    from hugs_amd.rotations import matrix_to_quaternion, rotation_6d_to_matrix
+    n = 1000
+    r = np.random.default_rng(3)
+    d6 = torch.from_numpy(r.standard_normal((n, 6)).astype(np.float32)).to(device)
+    gq = torch.from_numpy(r.standard_normal((n, 4)).astype(np.float32)).to(device)
+    out = {}
+    for odd in (False, True):
+        if odd:   # the same numbers, one float into a packed buffer: contiguous, data_ptr() % 16 == 4
+            src6 = torch.cat([torch.zeros(1, device=device), d6.reshape(-1)])[1:].view(n, 6)
+            g = torch.cat([torch.zeros(1, device=device), gq.reshape(-1)])[1:].view(n, 4)
+            assert src6.is_contiguous() and src6.data_ptr() % 16 != 0 and g.data_ptr() % 16 != 0
+        else:
+            src6, g = d6.clone(), gq.clone()
+        t6 = src6.detach().requires_grad_(True)
+        q = matrix_to_quaternion(rotation_6d_to_matrix(t6))
+        q.backward(g)
+        out[odd] = (q.detach().clone(), t6.grad.clone())
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])

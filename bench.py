@@ -261,14 +261,22 @@ def main():
     backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
     device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    # HGS_BENCH_FORCE_PG=1 (with HGS_SHARDING_FORCE_COLLECTIVES=1): a process group of ONE rank, collectives and all -- how the
+    # RCCL branch of this file gets executed on a one-GPU lease (tests/test_gpu_configs.py)
+    force_pg = world == 1 and os.environ.get("HGS_BENCH_FORCE_PG") == "1"
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_pg:
         import datetime
         tmo = datetime.timedelta(seconds=float(os.environ.get("HGS_BENCH_INIT_TIMEOUT_S", "300")))  # a dead sibling must not hang the rest
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
             dist.init_process_group(backend, timeout=tmo)
-    log(f"[rank {rank}] world_size {dist.get_world_size() if world > 1 else 1} ({backend if world > 1 else 'single process'}), "
+    log(f"[rank {rank}] world_size {dist.get_world_size() if (world > 1 or force_pg) else 1} ({backend if (world > 1 or force_pg) else 'single process'}), "
         f"device {device} = {torch.cuda.get_device_name(device)}")
 
     from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, profile_enable,
@@ -303,7 +311,7 @@ def main():
 
     dev = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
     t = {k: dev(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    if backend == "nccl":
+    if backend == "nccl" and (world > 1 or force_pg):
         sharding.broadcast_gaussians([v.data for v in t.values()])  # replicas of rank 0's Gaussians (same seed anyway)
     means2D = torch.zeros(P, 3, device=device, requires_grad=True)
     dLd = dev(dL)
@@ -328,7 +336,7 @@ def main():
         return color, radii
 
     def fence():
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -410,7 +418,8 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "ranks_seen": int(frames[:, 3].sum()), "expected_ranks": args.gpus, "backend": backend if world > 1 else "single process",
+        "ranks_seen": int(frames[:, 3].sum()), "expected_ranks": args.gpus,
+        "backend": backend if world > 1 else (backend + " (process group of one rank)" if force_pg else "single process"),
         "rank_devices": [int(x) for x in frames[:, 2].tolist()],
         "per_rank_N": [int(x) for x in frames[:, 0].tolist()],
         "per_rank_fps": [round(float(x), 2) for x in frames[:, 4].tolist()],   # each rank's own clock: a straggler is visible here
@@ -487,7 +496,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.barrier()
         dist.destroy_process_group()
     if out["ranks_seen"] != args.gpus:   # a line that LOOKS like an N-GPU number but is not one must not exit 0

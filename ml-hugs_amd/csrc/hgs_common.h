@@ -64,6 +64,7 @@ inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + T
 // Binning cells: BIN_CELL x BIN_CELL tiles.  On large frames the Gaussians are counting-sorted by the cell of their
 // rectangle's first tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
 constexpr int BIN_CELL = 4;
+constexpr uint32_t BIN_SPREAD_MIN = 256;  // splats of more tiles than this are spread over the cells instead of sorted by their first tile (preprocess.hip)
 constexpr int BIN_MAX_CELLS = 2048;  // cells whose populations one scatter workgroup prefix-sums (a 1080p frame has 510)
 inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL); }
 enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binning groups (preprocess.hip, binning.hip)

@@ -298,7 +298,15 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
     if (MODE == BIN_BY_CELL) {
         uint32_t* population = bin_lds;
         uint32_t* base = bin_lds + num_cells;
-        const int cell = touched ? (rect_miny / BIN_CELL) * cells_x + rect_minx / BIN_CELL : -1;
+        // the cell of the rectangle's first tile -- but a BIG splat (more than BIN_SPREAD_MIN tiles) is dealt to a pseudo-random
+        // cell instead: every splat that reaches the image's top-left corner has its first tile at (0, 0), and a trained scene
+        // keeps hundreds of background splats a hundred and more pixels across (some cover the whole frame); together in cell 0
+        // they made ONE binning group of 96 000 pairs where the mean is 6 700, and the count and emit kernels lasted as long
+        // as that group (43 + 98 us on the trained-scene profile).  Spread, each group gets a few; their tiles are all over the
+        // frame anyway, so the groups' locality -- what the cell order is for -- loses nothing.
+        const int cell = !touched ? -1
+                         : touched > BIN_SPREAD_MIN ? (int)((((uint32_t)i * 2654435761u) >> 12) % (uint32_t)num_cells)
+                                                    : (rect_miny / BIN_CELL) * cells_x + rect_minx / BIN_CELL;
         __syncthreads();  // population zeroed
         const uint32_t rank = cell >= 0 ? atomicAdd(&population[cell], 1u) : 0u;
         __syncthreads();

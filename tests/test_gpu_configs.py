@@ -256,3 +256,25 @@ def test_storage_order_changes_nothing_but_speed(device):
     for k in ("means3D", "opacities", "shs", "scales", "rotations", "means2D"):
         a, b = t0[k].grad[o], t1[k].grad
         assert float((a - b).norm() / a.norm().clamp_min(1e-30)) <= 1e-5, k
+
+
+@pytest.mark.gpu
+def test_rccl_branch_of_the_bench_runs_as_a_process_group_of_one(device):
+    """the RCCL branch of bench.py / hugs_amd.sharding (backend "nccl": process-group init with a device id,
+    broadcast of the Gaussians, all_gather / all_reduce of the per-frame scalars on device tensors, barrier) had never executed
+    on any box -- every recorded multi-rank run used gloo, because two ranks cannot share one GPU over RCCL.  A process group
+    of ONE rank with the collectives forced on runs that code on a one-GPU lease: RCCL initialises, the collectives complete,
+    the line carries the fields the scaling run is read by.  (configs[4]'s frames, gs_trainer.py:463,551,616.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HGS_BENCH_FORCE_PG="1", HGS_SHARDING_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--gaussians", "300000",
+                        "--no-cpu-baseline", "--no-two-streams"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"].startswith("nccl") and out["ranks_seen"] == 1 and out["expected_ranks"] == 1
+    assert out["per_rank_N"] == out["config"]["N_per_frame_all_ranks"] and out["per_rank_N"][0] > 0 and out["value"] > 100.0
+    assert "world_size 1 (nccl" in r.stderr

@@ -63,11 +63,16 @@ constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long t
 constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
 constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
 constexpr uint32_t DEEP_MEAN_MIN = 384;
-// dense frames: 2 048, what the one-workgroup-per-tile sort holds.  (1 024 was measured: the all-rows step's joint render -- a
-// person in front of a scene, hundreds of tiles between 1 024 and 2 048 entries -- fused kernel 237 -> 192 us; but "has long
-// tiles" is also what makes the bindings offer a checkpoint buffer, and C4's joint render, whose deepest tile has 1 900 entries
-// and whose backward is throughput- not chain-bound, then pays 78 us for the segmented backward of its 512+-entry tiles.)
-constexpr int LONG_MIN_DENSE = 2048;
+// dense frames: 1 024 (2 048 -- what the one-workgroup-per-tile sort holds -- until round 4).  A person in front of a scene puts
+// hundreds of tiles between 1 024 and 2 048 entries, whose one-wave walks were the tail of the fused kernel: the all-rows step's
+// joint render 237 -> 192 us.  ("Has long tiles" is also what makes the bindings offer a checkpoint buffer; whether a DENSE
+// frame uses it is decided by the library from its own history -- hgs_api.hip, FrameHistory::n_deep -- as before: lists beyond
+// 2 048 entries.  C4's joint render, deepest tile 1 900 entries and a throughput- not chain-bound backward, paid 78 us for the
+// segmented backward of its 512+-entry tiles when the lower threshold switched the buffer on.)
+// (Measured and dropped with it: the tiles between 512 entries and the threshold taken FIRST by workgroups behind the workers --
+// a per-workgroup trace had shown such tiles start after 110 us of a 190 us kernel and finish alone --: the all-rows step's
+// joint render unchanged (136 against 137 us per render), C2 168.6 -> 171.3, C4 140.2 -> 145.4 us.)
+constexpr int LONG_MIN_DENSE = 1024;
 constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
@@ -137,7 +142,8 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
             start += c[k];
             // (which lists are long depends on what kind of frame this is, known at the end: count for every threshold it may choose)
             if (t0 + k < num_tiles) {
-                my_huge += c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u, my_sparse += c[k] > long_min_sparse ? 1u : 0u;
+                my_huge += (c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u) + (c[k] > (uint32_t)SORT_CAP_SMALL ? 0x10000u : 0u);   // (two 16-bit counts)
+                my_sparse += c[k] > long_min_sparse ? 1u : 0u;
                 my_shallow += c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW ? 1u : 0u, my_dense += c[k] > long_min_dense ? 1u : 0u;
             }
         }
@@ -208,7 +214,7 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
     const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : long_min_dense;
     const uint32_t any_long = (use_sparse ? n_sparse_long : n_large_dense) ? 1u : 0u;
-    const uint32_t huge = n_huge;
+    const uint32_t huge = n_huge & 0xFFFFu, very_deep = n_huge >> 16;   // lists beyond SORT_CAP_MID / beyond SORT_CAP_SMALL entries
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;
         n_total[3] = sparse, n_total[4] = threshold;
@@ -252,7 +258,7 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         // beyond SORT_CAP_MID entries -- the host sizes the next frame's launches by them
         const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)any_long << 30);
         __hip_atomic_store(host_slot + 1, (unsigned long long)n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_slot + 2, (unsigned long long)huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 2, (unsigned long long)huge | ((unsigned long long)very_deep << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

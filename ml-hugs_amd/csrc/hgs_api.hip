@@ -296,7 +296,9 @@ FrameHistory history_get(const HistKey& k)
 void history_put(const HistKey& k, const HostSlot& hs)
 {
     FrameHistory h;
-    h.n_long = (int32_t)hs.word[1], h.n_huge = (int32_t)hs.word[2];   // (written by tile_scan_kernel before the word that carries the ticket)
+    // (written by tile_scan_kernel before the word that carries the ticket)
+    h.n_long = (int32_t)hs.word[1], h.n_huge = (int32_t)(hs.word[2] & 0xFFFFFFFFull), h.n_deep = (int32_t)(hs.word[2] >> 32);
+    h.sparse = (int32_t)(hs.word[0] >> 63);
     std::lock_guard<std::mutex> lk(g_hist_mu);
     g_hist[hist_slot(k)] = HistEntry{k, h};
 }
@@ -455,7 +457,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const bool dbg = a.s.debug != 0;
     // HGS_BWD_SEGMENTED=0: never leave checkpoints (backward then runs one wave per quad on sparse frames; A/B measurements)
     static const bool seg_allowed = [] { const char* e = getenv("HGS_BWD_SEGMENTED"); return !(e && e[0] == '0'); }();
-    const bool want_ckpt = a.backward_checkpoints != 0 && seg_allowed;
+    bool want_ckpt = a.backward_checkpoints != 0 && seg_allowed;
 
     const int num_tiles = cam.gx * cam.gy;
     const int Ptot = a.P + a.seg2.P;  // Gaussian indices run over both segments
@@ -463,6 +465,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     (void)hipGetDevice(&dev);
     const HistKey hkey{dev, st, Ptot, cam.H, cam.W};
     FrameHistory hist = history_get(hkey);   // (refreshed below when this frame's own counts arrive before it is enqueued)
+    // A DENSE frame uses the checkpoint buffer its caller offers only when the shape's last frame had lists beyond
+    // SORT_CAP_SMALL entries: the depth-segmented backward pays on a dense frame where such lists make the one-wave-per-tile
+    // kernel chain-bound, and costs (C4: +78 us) where the deepest lists are merely long.
+    if (hist.sparse == 0 && hist.n_deep == 0) want_ckpt = false;
     GeomLayout gl(Ptot, num_tiles);
     ImageLayout il(cam.H, cam.W);
     // caller-provided scratch when it suffices, else the allocation callback
@@ -607,7 +613,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         // exact size known now (and whether there are long tiles); after a too-small guess the gated kernels above did
         // nothing, so the frame is simply enqueued again
         if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
-        known_dense = !sparse && !has_long;  // (a dense frame WITH long tiles keeps its checkpoints: its deep tiles use them)
+        known_dense = !sparse && hist.n_deep == 0;  // (a dense frame WITH lists beyond SORT_CAP_SMALL entries keeps its checkpoints: its deep tiles use them)
         if (known_dense) state->ckpt = nullptr, state->ckpt_bytes = 0, fb.ck = Ckpt{};
         if (int rc = enqueue_frame(N, has_long)) return rc;
     } else if (has_long && !long_sort_done) {

@@ -216,7 +216,10 @@ struct FusedBlend {
     Ckpt ck;
 };
 // What the library remembers of a stream's last frame (hgs_api.hip): launch-size hints only -- results never depend on them.
-struct FrameHistory { int32_t n_long = -1, n_huge = -1; };   // lists that were long / beyond 4 096 entries; -1: unknown
+struct FrameHistory {   // -1: unknown
+    int32_t n_long = -1, n_huge = -1;   // lists that were long / beyond 4 096 entries
+    int32_t n_deep = -1, sparse = -1;   // lists beyond 2 048 entries; whether the frame was sparse
+};
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,
                       uint32_t* n_total, void* parts, uint32_t max_parts, bool small_tiles, bool long_tiles, const FusedBlend* fb,

@@ -19,18 +19,19 @@ from hugs_amd import synthetic as syn                                    # noqa:
 from hugs_amd.renderer import render_human_scene                         # noqa: E402
 
 
-def main_c2():
-    """the bench workload (200k / 1080p): residency of the fused kernel on a dense frame"""
+def main_c2(trained=False):
+    """the bench workload (200k / 1080p), or the trained-scene profile: residency and critical path of the fused kernel on a dense frame"""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device("cuda:0")
     lib = dgr._load()
     P, H, W = 200_000, 1080, 1920
     cam = syn.pinhole_camera(H, W)
-    g = syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+    g = syn.trained_scene_gaussians(P, cam, seed=0) if trained else syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+    P = g["means3D"].shape[0]
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     t = {k: d(g[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     st = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), torch.ones(3, device=dev), 1.0,
-                                       d(cam["world_view_transform"]), d(cam["full_proj_transform"]), 3, d(cam["camera_center"]), False, False)
+                                       d(cam["world_view_transform"]), d(cam["full_proj_transform"]), 0 if trained else 3, d(cam["camera_center"]), False, False)
     run = lambda: GaussianRasterizer(st)(means3D=t["means3D"], means2D=torch.zeros(P, 3, device=dev), opacities=t["opacities"], shs=t["shs"],
                                          scales=t["scales"], rotations=t["rotations"])
     for _ in range(5):
@@ -118,7 +119,7 @@ def report(r, nwg):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "c2":
-        main_c2()
+    if len(sys.argv) > 1 and sys.argv[1] in ("c2", "trained"):
+        main_c2(sys.argv[1] == "trained")
     else:
         main(int(sys.argv[1]) if len(sys.argv) > 1 else 110_210)

@@ -449,6 +449,14 @@ def main():
                         "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
         "stages_ms": stages,
+        # the two per-Gaussian kernels are the ones on the HBM roofline: their algorithmic bytes
+        # (K1 = P (44 + 12 K) + 8 P + 67 P_v, K8 = P_v (111 + 12 K) + P (40 + 12 M)) over the live event timings
+        "stage_rooflines": {name: {"algorithmic_bytes": int(b), "GB_per_s": round(b / (stages[name] * 1e-3) / 1e9, 1),
+                                   "frac_of_hbm_peak": round(b / (stages[name] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "frac_of_measured": round(b / (stages[name] * 1e-3) / 1e9 / copy_peak, 4)}
+                            for name, b in (("preprocess", P * (44 + 12 * K) + 8 * P + 67 * Pv),
+                                            ("preprocess_backward", Pv * (111 + 12 * K) + P * (40 + 12 * 16)))
+                            if stages.get(name) and not (args.forward_only and name == "preprocess_backward")},
         "stages_ms_note": "separate untimed pass with an event pair around EVERY stage: each pair costs a few microseconds of GPU "
                           "time, so the sum exceeds ms_per_step",
     }

@@ -125,7 +125,7 @@ typedef struct hgs_forward_args {
      * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
      * its autograd backward, without the five elementwise passes over the image they cost. */
     int32_t clamp_output;
-    /* !=0: the caller expects no long tile -- a list of more than 2048 entries, 1024 on a sparse frame -- (its previous frame of this shape had none, see
+    /* !=0: the caller expects no long tile -- a list of more than 1024 entries (256 on a sparse frame whose lists are deep on average; the scan kernel decides) -- (its previous frame of this shape had none, see
      * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
      * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
     int32_t expect_no_long_tiles;
@@ -142,8 +142,9 @@ typedef struct hgs_forward_args {
      * positions of its quad's list, and backward splits every list into 32-entry segments that run as independent waves
      * instead of one chain of dependent entries per quad.  On a dense frame only the DEEP tiles (512 entries and more: a
      * person in front of a scene) do that, the others go through the one-wave-per-tile backward as always; the library
-     * asks for the buffer on a dense frame only when the frame has long tiles (more than 2048 entries), so a caller that
-     * sets this flag for every frame pays for the buffer only where it helps.  Results are the same up to fp32 summation
+     * uses the buffer on a dense frame only when the shape's last frame on this stream had a tile list of more than 2048
+     * entries (its own record; without one it follows the flag), so a caller that sets this flag for every frame pays
+     * only where it helps.  Results are the same up to fp32 summation
      * order either way; 0 keeps the one-wave backward (a failed HGS_BUF_CKPT allocation is an error). */
     int32_t backward_checkpoints;
     /* Optional caller-provided scratch (e.g. persistent arenas for frames that need no backward): buffer k
@@ -166,7 +167,7 @@ typedef struct hgs_forward_state {
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
-    int32_t has_long_tiles;   /* !=0: some tile list is long -- more than 2048 entries, on a sparse frame more than 1024 (feeds the next frame's expect_no_long_tiles) */
+    int32_t has_long_tiles;   /* !=0: some tile list is long -- more than 1024 entries, on a sparse frame with deep lists more than 256 (feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
 } hgs_forward_state;
 

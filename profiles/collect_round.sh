@@ -29,6 +29,9 @@ bash profiles/collect_rows.sh $TAG > /dev/null 2>&1; cp "$ROOT"/gpurun_out/${TAG
 python3 tools/fuzz_rows.py --seconds 45 > "$OUT/${TAG}_fuzz_rows.txt" 2>&1
 SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
 python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1
+# (round 4) workgroups per CU against LDS / registers: the occupancy facts DESIGN.md 4.4 relies on
+make -C tools/microbench bin/occupancy_lds bin/occupancy_regs > /dev/null 2>&1
+./tools/microbench/bin/occupancy_lds > "$OUT/r4_occupancy_lds.txt" 2>&1; ./tools/microbench/bin/occupancy_regs > "$OUT/r4_occupancy_regs.txt" 2>&1
 rm -rf "$ROOT"/gpurun_out/${TAG}*/trace "$ROOT"/gpurun_out/${TAG}*/pmc_*
 tail -n 3 "$OUT/${TAG}_soak.txt" "$OUT/${TAG}_soak_churn.txt"
 cat "$OUT/${TAG}_bench.json"

@@ -63,16 +63,17 @@ constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long t
 constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
 constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
 constexpr uint32_t DEEP_MEAN_MIN = 384;
-// dense frames: 1 024 (2 048 -- what the one-workgroup-per-tile sort holds -- until round 4).  A person in front of a scene puts
+// dense frames: 768 (2 048 -- what the one-workgroup-per-tile sort holds -- until round 4).  A person in front of a scene puts
 // hundreds of tiles between 1 024 and 2 048 entries, whose one-wave walks were the tail of the fused kernel: the all-rows step's
-// joint render 237 -> 192 us.  ("Has long tiles" is also what makes the bindings offer a checkpoint buffer; whether a DENSE
+// joint render 237 -> 192 us.  768 against 1 024 (same box, kernel trace): the trained-scene profile's fused kernel 223 -> 205 us
+// for +1 us of long-tile sort, C4 and the step unchanged; 512 / 384 give the sort back what the blend gains (31 / 43 us).  ("Has long tiles" is also what makes the bindings offer a checkpoint buffer; whether a DENSE
 // frame uses it is decided by the library from its own history -- hgs_api.hip, FrameHistory::n_deep -- as before: lists beyond
 // 2 048 entries.  C4's joint render, deepest tile 1 900 entries and a throughput- not chain-bound backward, paid 78 us for the
 // segmented backward of its 512+-entry tiles when the lower threshold switched the buffer on.)
 // (Measured and dropped with it: the tiles between 512 entries and the threshold taken FIRST by workgroups behind the workers --
 // a per-workgroup trace had shown such tiles start after 110 us of a 190 us kernel and finish alone --: the all-rows step's
 // joint render unchanged (136 against 137 us per render), C2 168.6 -> 171.3, C4 140.2 -> 145.4 us.)
-constexpr int LONG_MIN_DENSE = 1024;
+constexpr int LONG_MIN_DENSE = 768;
 constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads

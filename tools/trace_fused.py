@@ -37,7 +37,48 @@ def main_c2(trained=False):
     for _ in range(5):
         run()
     torch.cuda.synchronize()
-    nwg = 2048 + 8 + 8160
+    nwg = 8160 + 24576
+    buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+    lib.hgs_debug_set_trace.argtypes = [ctypes.c_void_p]
+    assert lib.hgs_debug_set_trace(buf.data_ptr()) == 0
+    run()
+    torch.cuda.synchronize()
+    lib.hgs_debug_set_trace(None)
+    report(buf.cpu().numpy().reshape(nwg, 8), nwg)
+
+
+def main_joint(shell=False):
+    """C4's joint human + scene render (110 210 + 200 000 Gaussians, 1080p): a dense frame whose body tiles are deep;
+    shell: the human of tools/bench_step.py instead (a 1.2 m body SURFACE at 4 m: lists of several thousand entries)"""
+    dev = torch.device("cuda:0")
+    lib = dgr._load()
+    H, W = 1080, 1920
+    cam = syn.pinhole_camera(H, W)
+    rng = np.random.default_rng(7)
+    Ph, Ps = 110_210, 200_000
+    q = rng.standard_normal((Ph, 4))
+    hm = {"xyz": (rng.standard_normal((Ph, 3)) * np.array([0.22, 0.55, 0.14]) + np.array([0, 0, 4.0])).astype(np.float32),
+          "scales": (0.035 / math.sqrt(Ph / 6890.0) * np.exp(0.3 * rng.standard_normal((Ph, 3)))).astype(np.float32),
+          "rotq": (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32),
+          "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32), "opacity": rng.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
+    if shell:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_knn import body_surface
+        r = np.random.default_rng(3)
+        hm["xyz"] = (body_surface(Ph, r, noise=0.004) * 0.6 + np.array([0, 0, 4.0])).astype(np.float32)
+        hm["scales"] = (0.012 * np.exp(0.3 * r.standard_normal((Ph, 3)))).astype(np.float32)
+    g = syn.scene_gaussians(Ps, cam, seed=8, sigma_px=4.0)
+    sm = {"xyz": g["means3D"], "scales": g["scales"], "rotq": g["rotations"], "shs": g["shs"], "opacity": g["opacities"]}
+    t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
+    human, scene = {k: t(v, True) for k, v in hm.items()}, {k: t(v, True) for k, v in sm.items()}
+    human["active_sh_degree"], scene["active_sh_degree"] = 0, 3
+    data = {k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    bg = torch.ones(3, device=dev)
+    run = lambda: render_human_scene(data, human, scene, bg_color=bg, render_mode="human_scene")
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    nwg = 8160 + 24576
     buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     lib.hgs_debug_set_trace.argtypes = [ctypes.c_void_p]
     assert lib.hgs_debug_set_trace(buf.data_ptr()) == 0
@@ -119,7 +160,9 @@ def report(r, nwg):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("c2", "trained"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("joint", "step"):
+        main_joint(sys.argv[1] == "step")
+    elif len(sys.argv) > 1 and sys.argv[1] in ("c2", "trained"):
         main_c2(sys.argv[1] == "trained")
     else:
         main(int(sys.argv[1]) if len(sys.argv) > 1 else 110_210)

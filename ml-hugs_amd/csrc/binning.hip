@@ -143,7 +143,7 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
             start += c[k];
             // (which lists are long depends on what kind of frame this is, known at the end: count for every threshold it may choose)
             if (t0 + k < num_tiles) {
-                my_huge += (c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u) + (c[k] > (uint32_t)SORT_CAP_SMALL ? 0x10000u : 0u);   // (two 16-bit counts)
+                my_huge += (c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u) + (c[k] > DEEP_BWD_MIN ? 0x10000u : 0u);   // (two 16-bit counts)
                 my_sparse += c[k] > long_min_sparse ? 1u : 0u;
                 my_shallow += c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW ? 1u : 0u, my_dense += c[k] > long_min_dense ? 1u : 0u;
             }

@@ -403,16 +403,14 @@ blend_backward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ rang
 // [m CKPT_SEG, (m + 1) CKPT_SEG) of the quad's list from the state the forward had behind them -- the chain is at most
 // CKPT_SEG entries long and the frame's (quad, entry) pairs spread over all SIMDs.  Same per-entry arithmetic, skip rules,
 // reduction and atomics as the one-wave-per-quad kernel.
-__global__ void __launch_bounds__(256)
-blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
-                                size_t act_stride, const Splat* __restrict__ splats, const float* __restrict__ bg,
-                                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                                const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, Ckpt ck)
+__device__ __forceinline__ void
+blend_backward_slot(uint32_t slot, const Camera& cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                    size_t act_stride, const Splat* __restrict__ splats, const float* __restrict__ bg, const float* __restrict__ final_T,
+                    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, const Ckpt& ck)
 {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t slot = blockIdx.x;  // (the grid is the frame's slot count, (N >> CKPT_SHIFT) + tiles)
     const uint32_t tile = ((const_u32p)ck.slot_tile)[slot];
-    if (tile == CKPT_SLOT_NONE) return;  // (a dense frame's tile that left no checkpoints: blend_backward_kernel<4> has it)
+    if (tile == CKPT_SLOT_NONE) return;  // (a dense frame's tile that left no checkpoints: the one-wave-per-tile walk has it)
     const uint32_t first_slot = ((const_u32p)ck.seg_first)[tile];
     const uint32_t m = slot - first_slot;
     const uint32_t walked = ((const_u32p)ck.quad_nproc)[tile * 4u + (uint32_t)w];  // entries the forward wave walked
@@ -427,6 +425,39 @@ blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restr
                                  grad_accum, seg);
 }
 
+__global__ void __launch_bounds__(256)
+blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                                size_t act_stride, const Splat* __restrict__ splats, const float* __restrict__ bg,
+                                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, Ckpt ck)
+{
+    // (the grid is the frame's slot count, (N >> CKPT_SHIFT) + tiles)
+    blend_backward_slot(blockIdx.x, cam, lastg, ranges, act, act_stride, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
+}
+
+// A DENSE frame with deep tiles, both forms in ONE launch: the first dense_blocks workgroups are blend_backward_kernel<4>'s (four
+// tiles each, deep tiles skipped), the rest blend_backward_segmented_kernel's (one checkpoint slot each).  As two launches on one
+// stream the second waited for the first's last wave; both add into the same accumulator, so nothing orders them.  The long
+// one-wave-per-tile walks start first and the short segment walks fill the SIMDs their tail leaves.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+blend_backward_mixed_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ ranges, const uint64_t* __restrict__ act,
+                            size_t act_stride, const uint32_t* __restrict__ act_count, const Splat* __restrict__ splats,
+                            const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                            const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, Ckpt ck, uint32_t dense_blocks)
+{
+    if (blockIdx.x >= dense_blocks) {
+        blend_backward_slot(blockIdx.x - dense_blocks, cam, lastg, ranges, act, act_stride, splats, bg, final_T, n_contrib, dL_dpix,
+                            grad_accum, ck);
+        return;
+    }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (int)blockIdx.x * 4 + w;
+    if (tile >= cam.gx * cam.gy) return;
+    const v2u range = ((const_u2p)ranges)[tile];
+    if (range.y <= range.x || range.y - range.x >= CKPT_DEEP_MIN) return;
+    blend_backward_wave<4>(cam, lastg, tile, w, range, act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum);
+}
+
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
                            const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
@@ -439,11 +470,18 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
         // the forward left checkpoints: for every tile of a sparse frame, for the deep tiles (CKPT_DEEP_MIN) of a dense one --
         // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)
         const uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;
-        hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act, act_stride,
-                           splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
-        if (!sparse_frame)
+        static const bool two_launches = getenv("HGS_BWD_TWO_LAUNCHES") && getenv("HGS_BWD_TWO_LAUNCHES")[0] == '1';  // A/B measurements
+        if (sparse_frame || two_launches)
+            hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
+                               act_stride, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
+        if (!sparse_frame && two_launches)
             hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((num_tiles + 3) / 4), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
                                act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, CKPT_DEEP_MIN);
+        else if (!sparse_frame) {
+            const uint32_t dense_blocks = (uint32_t)(num_tiles + 3) / 4u;
+            hipLaunchKernelGGL(blend_backward_mixed_kernel, dim3(dense_blocks + slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges,
+                               act, act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck, dense_blocks);
+        }
     } else if (per_quad)
         hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(num_tiles), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                            act_stride, act_count, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, 0u);

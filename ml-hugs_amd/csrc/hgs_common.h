@@ -130,7 +130,16 @@ constexpr int CKPT_SHIFT = 5, CKPT_SEG = 1 << CKPT_SHIFT;
 // checkpoints too and go through the depth-segmented backward; the one-wave-per-tile kernel skips them.  A dense frame's
 // backward otherwise lasts as long as its deepest tile's chain -- a person in front of a scene (the joint render of HUGS).
 // slot_tile = CKPT_SLOT_NONE marks the slots of tiles that left none.
-constexpr uint32_t CKPT_DEEP_MIN = 512u, CKPT_SLOT_NONE = 0xFFFFFFFFu;
+#ifndef HGS_CKPT_DEEP_MIN   // (A/B builds: tools/ab_build.sh name -DHGS_CKPT_DEEP_MIN=...)
+#define HGS_CKPT_DEEP_MIN 512u
+#endif
+#ifndef HGS_DEEP_BWD_MIN
+#define HGS_DEEP_BWD_MIN 2048u
+#endif
+constexpr uint32_t CKPT_DEEP_MIN = HGS_CKPT_DEEP_MIN, CKPT_SLOT_NONE = 0xFFFFFFFFu;
+// a DENSE frame asks for checkpoints (and the segmented backward of its deep tiles) when its shape's last frame had a list beyond
+// this many entries (tile_scan_kernel counts them: FrameHistory::n_deep)
+constexpr uint32_t DEEP_BWD_MIN = HGS_DEEP_BWD_MIN;
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, act_count, cursor, large_tiles, n_total, seg_first, quad_nproc, total;
     ImageLayout(int H, int W) {

@@ -516,9 +516,11 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
     """The oracle (a CPU port of the same algorithm -- the reference has no CPU path) timed on
     this box's host cores on a bounded sample of the same workload. Baseline only."""
     from oracle import hgs_oracle as ho
-    # all host cores (round 4: the port's pixel backward adds tile-local sums into ONE shared double accumulator; the
-    # per-thread accumulators of round 3 capped it at 32 threads).  `cores` = threads actually used.
-    cores = os.cpu_count() or 1
+    # all cores this process may use (round 4: the port's pixel backward adds tile-local sums into ONE shared double accumulator --
+    # the per-thread accumulators of round 3 capped it at 32 threads -- and its per-Gaussian loops, key emission and radix sort
+    # run under OpenMP too).  `cores` = threads actually used = the affinity mask capped by the cgroup CPU quota: the GPU boxes
+    # show 256 CPUs under a 16-CPU quota, where 256 threads take 1.70 s per frame and 16 take 0.49 s.
+    cores = ho.usable_cpus()
     ho.set_threads(cores)
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
                     cam["camera_center"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), H, W,
@@ -534,9 +536,9 @@ def cpu_baseline(g, cam, dL, H, W, D, budget_s, with_backward):
             break
     log(f"[cpu_baseline] {n} frame(s) in {el:.2f} s on {cores} threads")
     model, host_cpus = host_cpu()
-    return {"value": round(n / el, 4), "unit": "frames/s", "cores": cores, "host_cpus": host_cpus, "cpu_model": model, "kind": "port",
+    return {"value": round(n / el, 4), "unit": "frames/s", "cores": cores, "host_cpus": host_cpus, "cpu_quota": cores if cores < host_cpus else None, "cpu_model": model, "kind": "port",
             "sample": f"{n} full frame(s) of the same workload ({'fwd+bwd' if with_backward else 'fwd'}), "
-                      "C oracle (oracle/hgs_oracle.c, fp32, OpenMP over tiles)"}
+                      "C oracle (oracle/hgs_oracle.c, fp32, OpenMP: per-Gaussian loops, chunked radix sort, blend kernels over tiles)"}
 
 
 if __name__ == "__main__":

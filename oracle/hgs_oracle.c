@@ -188,7 +188,8 @@ void oracle_preprocess(int P, int M, int D, int H, int W, real tanfovx, real tan
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const real fx = (real)W / (R_(2) * tanfovx), fy = (real)H / (R_(2) * tanfovy);
     const int K = (D + 1) * (D + 1);
-    for (int i = 0; i < P; ++i) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {   /* (independent per Gaussian: every output element has one writer) */
         radii[i] = 0;
         tiles_touched[i] = 0;
         depths[i] = 0;
@@ -284,7 +285,8 @@ void oracle_emit_keys(int P, int W, const real *depths, const int32_t *radii, co
                       const uint32_t *offsets, uint64_t *keys, uint32_t *values)
 {
     const int gx = (W + TILE - 1) / TILE;
-    for (int i = 0; i < P; ++i) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {   /* (every Gaussian writes its own slots [offsets[i-1], offsets[i])) */
         if (radii[i] <= 0) continue;
         uint32_t off = i == 0 ? 0 : offsets[i - 1];
         float df = (float)depths[i];
@@ -300,7 +302,9 @@ void oracle_emit_keys(int P, int W, const real *depths, const int32_t *radii, co
     }
 }
 
-/* K4: stable LSD radix sort on the full 64-bit key (8 passes of 8 bits). */
+/* K4: stable LSD radix sort on the full 64-bit key (8 passes of 8 bits).  With OpenMP every thread takes one contiguous
+   chunk of the array per pass: private digit counts, one prefix over (digit, thread) -- digit-major, so a digit's elements keep
+   chunk order = input order --, then each thread scatters its own chunk in order: the same permutation as the serial loop. */
 void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
 {
     if (N <= 1) return;
@@ -308,20 +312,46 @@ void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
     uint32_t *v2 = (uint32_t *)malloc((size_t)N * 4);
     uint64_t *ka = keys, *kb = k2;
     uint32_t *va = values, *vb = v2;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+    if (nt > 64) nt = 64;            /* (256 counters per thread and pass: more chunks than this only lengthen the prefix) */
+    if (N < ((int64_t)1 << 16)) nt = 1;
+#endif
+    size_t *cnt = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)nt);
     for (int pass = 0; pass < 8; ++pass) {
-        size_t cnt[257];
-        memset(cnt, 0, sizeof cnt);
-        int sh = 8 * pass;
-        for (int64_t i = 0; i < N; ++i) cnt[((ka[i] >> sh) & 255) + 1]++;
-        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
-        for (int64_t i = 0; i < N; ++i) {
-            size_t p = cnt[(ka[i] >> sh) & 255]++;
-            kb[p] = ka[i], vb[p] = va[i];
+        const int sh = 8 * pass;
+#pragma omp parallel num_threads(nt)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            const int64_t lo = N * t / nt, hi = N * (t + 1) / nt;
+            size_t *c = cnt + 256 * (size_t)t;
+            memset(c, 0, sizeof(size_t) * 256);
+            for (int64_t i = lo; i < hi; ++i) c[(ka[i] >> sh) & 255]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                size_t pos = 0;
+                for (int d = 0; d < 256; ++d)
+                    for (int u = 0; u < nt; ++u) {
+                        const size_t n = cnt[256 * (size_t)u + d];
+                        cnt[256 * (size_t)u + d] = pos;
+                        pos += n;
+                    }
+            } /* (implicit barrier) */
+            for (int64_t i = lo; i < hi; ++i) {
+                const size_t p = c[(ka[i] >> sh) & 255]++;
+                kb[p] = ka[i], vb[p] = va[i];
+            }
         }
         uint64_t *tk = ka; ka = kb; kb = tk;
         uint32_t *tv = va; va = vb; vb = tv;
     }
     /* 8 passes: data is back in the caller's arrays */
+    free(cnt);
     free(k2);
     free(v2);
 }
@@ -330,7 +360,8 @@ void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
 void oracle_tile_ranges(int64_t N, const uint64_t *keys, int num_tiles, uint32_t *ranges)
 {
     memset(ranges, 0, (size_t)num_tiles * 8);
-    for (int64_t i = 0; i < N; ++i) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {   /* (a tile's start / end is written by the one element that sees the boundary) */
         uint32_t t = (uint32_t)(keys[i] >> 32);
         if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
         if (i == N - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(i + 1);
@@ -498,7 +529,8 @@ void oracle_preprocess_backward(int P, int M, int D, int H, int W, real tanfovx,
     memset(dL_dscale, 0, sizeof(real) * 3 * (size_t)P);
     memset(dL_drot, 0, sizeof(real) * 4 * (size_t)P);
     memset(dL_dcov3D, 0, sizeof(real) * 6 * (size_t)P);
-    for (int i = 0; i < P; ++i) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {   /* (independent per Gaussian) */
         if (radii[i] <= 0) continue;
         const real x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
         real dmean[3] = {0, 0, 0};

@@ -32,6 +32,7 @@ def _lib(dtype):
         lib = C.CDLL(os.path.join(_HERE, name))
         lib.oracle_scan.restype = C.c_int64
         assert lib.oracle_real_size() == dtype.itemsize
+        lib.oracle_set_threads(usable_cpus())   # (OpenMP's own default is every CPU it can see, quota or not)
         _LIBS[dtype] = lib
     return _LIBS[dtype]
 
@@ -47,6 +48,31 @@ def _arr(a, dtype, shape=None):
     if shape is not None:
         a = a.reshape(shape)
     return a
+
+
+def usable_cpus():
+    """CPUs this process can actually run on at once: the affinity mask, capped by the cgroup's CPU quota (a container that
+    shows 256 CPUs with a 16-CPU quota runs 256 OpenMP threads SLOWER than 16 -- measured on the GPU boxes: 1.70 s against
+    0.49 s per frame)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):   # cgroup v2: "<quota|max> <period>"
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+    try:   # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, -(-q // per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def set_threads(n, dtype=np.float32):

@@ -59,7 +59,7 @@ def oracle_run(m, cam, bg, degree, dL):
     inp = ho.Inputs(m["xyz"], m["opacity"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
                     math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), cam["image_height"], cam["image_width"],
                     np.asarray(bg, np.float32), shs=m["shs"], scales=m["scales"], rotations=m["rotq"], sh_degree=degree)
-    ho.set_threads(min(os.cpu_count() or 1, 32))
+    ho.set_threads(ho.usable_cpus())
     f = ho.forward(inp)
     return f, ho.backward(inp, f, dL)
 

@@ -560,7 +560,7 @@ def test_full_size_workload_parity_and_properties(device):
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"],
                     cam["camera_center"], tfx, tfy, H, W, np.ones(3, np.float32), shs=g["shs"], scales=g["scales"],
                     rotations=g["rotations"], sh_degree=D)
-    ho.set_threads(min(os.cpu_count() or 1, 32))
+    ho.set_threads(ho.usable_cpus())
     ref = ho.forward(inp)
     assert np.array_equal(r1.cpu().numpy(), ref["radii"])
     assert st["N"] == ref["N"]
@@ -1301,7 +1301,7 @@ def test_trained_scene_profile_at_1080p(device):
                                     scales=t["scales"].detach(), rotations=t["rotations"].detach())
     inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
                     tfx, tfy, H, W, bg, shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
-    ho.set_threads(os.cpu_count() or 1)
+    ho.set_threads(ho.usable_cpus())
     ref = ho.forward(inp)
     lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
     assert lens.max() > 2048 and (ref["radii"] >= 100).mean() > 0.003     # long tiles; the tail of big splats is there

@@ -204,6 +204,22 @@ def test_upstream_scale_gradient_switch_of_the_oracle():
         assert np.array_equal(g0[k], g1[k]), k
 
 
+def test_forward_does_not_depend_on_the_number_of_threads():
+    """The per-Gaussian loops, key emission, the radix sort (chunked per thread, digit-major prefix) and the tile ranges run under
+    OpenMP for the all-core CPU baseline (bench.py): every forward output is the serial one, bit for bit -- also on a list long
+    enough for the sort to split into chunks (N >= 65 536)."""
+    sc = make_scene(P=4000, H=96, W=128, seed=12, D=2, sigma_px=9.0)
+    inp = oracle_inputs(sc)
+    out = {}
+    for n in (1, 7):
+        ho.set_threads(n)
+        out[n] = ho.forward(inp)
+    ho.set_threads(1)
+    assert out[1]["N"] >= 65536
+    for k, a in out[1].items():
+        assert np.array_equal(np.asarray(a), np.asarray(out[7][k])), k
+
+
 def test_backward_does_not_depend_on_the_number_of_threads():
     """The pixel backward adds tile-local double sums into ONE shared double accumulator with atomics (round 4: the per-thread
     accumulators of round 3 capped the CPU baseline at 32 host threads): whatever the thread count and the order the tiles

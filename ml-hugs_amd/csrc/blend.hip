@@ -470,7 +470,8 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
         // the forward left checkpoints: for every tile of a sparse frame, for the deep tiles (CKPT_DEEP_MIN) of a dense one --
         // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)
         const uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;
-        static const bool two_launches = getenv("HGS_BWD_TWO_LAUNCHES") && getenv("HGS_BWD_TWO_LAUNCHES")[0] == '1';  // A/B measurements
+        const char* two = getenv("HGS_BWD_TWO_LAUNCHES");   // (read per frame: A/B measurements and the equivalence test)
+        const bool two_launches = two && two[0] == '1';
         if (sparse_frame || two_launches)
             hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                                act_stride, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);

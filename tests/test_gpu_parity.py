@@ -1197,6 +1197,16 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device
         grads[seg] = {k: t[k].grad.cpu().numpy() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}
     if dgr._cpp is not None:
         dgr._cpp.use_checkpoints(True)
+    # the two backward forms of such a frame run as ONE launch (blend_backward_mixed_kernel); as two launches -- the same waves
+    # doing the same work in another order -- the gradients differ by the float atomics' order only
+    monkeypatch.setattr(dgr, "_USE_CKPT", True)
+    monkeypatch.setenv("HGS_BWD_TWO_LAUNCHES", "1")
+    t, color, _ = run_gpu(sc, device)
+    color.backward(to_dev(sc["dL_dpix"], device))
+    monkeypatch.delenv("HGS_BWD_TWO_LAUNCHES")
+    assert torch.equal(color.detach(), images[True])
+    for k in grads[True]:
+        assert rel_l2(t[k].grad.cpu().numpy(), grads[True][k]) <= 1e-5, k
     assert torch.equal(images[True], images[False])
     check_image(images[True].cpu().numpy(), ref["color"], "dense frame with deep tiles")
     for k in grads[True]:

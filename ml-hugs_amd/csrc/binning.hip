@@ -86,7 +86,7 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
                  unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense)
 {
     __shared__ uint32_t n_long_sh;
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
     if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
@@ -94,8 +94,11 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t carry = 0;
+    uint32_t carry = 0, carry2 = 0;
     uint32_t my_huge = 0, my_sparse = 0, my_shallow = 0, my_dense = 0;   // this thread's lists beyond each threshold
+    // (a frame of at most 8 192 tiles is ONE trip of this loop: the number of non-empty tiles -- dense frame or sparse -- is then
+    //  complete behind the trip's barrier, before the checkpoint slots are dealt)
+    const bool single_trip = num_tiles <= 1024 * SCAN_ITEMS;
     for (int base = 0; base < num_tiles; base += 1024 * SCAN_ITEMS) {
         const int t0 = base + threadIdx.x * SCAN_ITEMS;
         uint32_t c[SCAN_ITEMS];
@@ -117,6 +120,14 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         for (int k = 0; k < SCAN_ITEMS; ++k) mine += c[k], nonempty += c[k] ? 1u : 0u;
         const uint32_t inc = wave_inclusive_scan(mine);
         if (lane == 63) wsum[w] = inc;
+        // checkpoint slots of a DENSE frame: its deep tiles alone get them, ceil(length / CKPT_SEG) each, packed (see below)
+        uint32_t need[SCAN_ITEMS], mine2 = 0, inc2 = 0;
+        if (seg_first) {   // (uniform)
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) need[k] = c[k] >= CKPT_DEEP_MIN ? (c[k] + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT : 0u, mine2 += need[k];
+            inc2 = wave_inclusive_scan(mine2);
+            if (lane == 63) wsum2[w] = inc2;
+        }
         // non-empty tiles of the wave (for the sparse-frame decision)
         uint32_t ne = nonempty;
         unsigned long long m64 = mine;  // (eight counts below 2^26 each: `mine` itself cannot wrap)
@@ -127,13 +138,22 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         }
         if (lane == 0 && ne) atomicAdd(&n_nonempty, ne), atomicAdd(&total64, m64);
         __syncthreads();
-        uint32_t before = 0, total = 0;
+        uint32_t before = 0, total = 0, before2 = 0, total2 = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t v = wsum[k];
             if (k < w) before += v;
             total += v;
         }
+        if (seg_first) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = wsum2[k];
+                if (k < w) before2 += v;
+                total2 += v;
+            }
+        }
+        const bool dense_now = single_trip && n_nonempty >= 4096u;   // (the packed slot layout can be written right here)
         __syncthreads();
         uint32_t start = carry + before + inc - mine;
         uint32_t st[SCAN_ITEMS];
@@ -156,7 +176,13 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
                                        c[k + 1] ? st[k + 1] + c[k + 1] : 0u);
             reinterpret_cast<uint4*>(cursor + t0)[0] = make_uint4(st[0], st[1], st[2], st[3]);
             reinterpret_cast<uint4*>(cursor + t0)[1] = make_uint4(st[4], st[5], st[6], st[7]);
-            if (seg_first) {  // first checkpoint slot of each tile (hgs_common.h, CKPT_*)
+            if (seg_first && dense_now) {
+                uint32_t at = before2 + inc2 - mine2, sf[SCAN_ITEMS];
+#pragma unroll
+                for (int k = 0; k < SCAN_ITEMS; ++k) sf[k] = at, at += need[k];
+                reinterpret_cast<uint4*>(seg_first + t0)[0] = make_uint4(sf[0], sf[1], sf[2], sf[3]);
+                reinterpret_cast<uint4*>(seg_first + t0)[1] = make_uint4(sf[4], sf[5], sf[6], sf[7]);
+            } else if (seg_first) {  // first checkpoint slot of each tile (hgs_common.h, CKPT_*)
                 const uint32_t b = (uint32_t)t0;
                 reinterpret_cast<uint4*>(seg_first + t0)[0] = make_uint4((st[0] >> CKPT_SHIFT) + b, (st[1] >> CKPT_SHIFT) + b + 1u,
                                                                          (st[2] >> CKPT_SHIFT) + b + 2u, (st[3] >> CKPT_SHIFT) + b + 3u);
@@ -171,8 +197,16 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
                     cursor[t0 + k] = st[k];
                     if (seg_first) seg_first[t0 + k] = (st[k] >> CKPT_SHIFT) + (uint32_t)(t0 + k);
                 }
+            if (seg_first && dense_now) {   // (the ragged tail of the packed layout)
+                uint32_t at = before2 + inc2 - mine2;
+#pragma unroll
+                for (int k = 0; k < SCAN_ITEMS; ++k) {
+                    if (t0 + k < num_tiles) seg_first[t0 + k] = at;
+                    at += need[k];
+                }
+            }
         }
-        carry += total;
+        carry += total, carry2 += total2;
     }
     // Which lists ARE long depends on what kind of frame this is, known only now.  Every thread takes the decision for itself from
     // the workgroup's counters (no broadcast, no barrier for it); a frame WITH long lists then collects them into the list the
@@ -228,6 +262,48 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         n_total[8] = (!sparse || deep_lists) ? 1u : 0u;
         if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
     }
+    // A DENSE frame leaves checkpoints only on its deep tiles (CKPT_DEEP_MIN entries and more): they alone get slots --
+    // ceil(length / CKPT_SEG) each, packed -- so that the backward launches a workgroup per slot in use instead of one per slot of
+    // the (N >> CKPT_SHIFT) + T a sparse frame's layout has (the trained-scene profile: 98 000 workgroups that only found their
+    // slot idle, ~12 us of its backward -- measured by doubling them).
+    uint32_t dense_slots = 0xFFFFFFFFu;
+    if (seg_first && !sparse && single_trip) {   // (dealt inside the trip above)
+        if (threadIdx.x == 0) seg_first[num_tiles] = carry2;
+        dense_slots = carry2;
+    } else if (seg_first && !sparse) {   // (workgroup-uniform) more than 8 192 tiles: a second scan, over the ranges this workgroup wrote
+        carry2 = 0;
+        for (int base = 0; base < num_tiles; base += 1024 * SCAN_ITEMS) {
+            const int t0 = base + threadIdx.x * SCAN_ITEMS;
+            uint32_t need[SCAN_ITEMS], mine = 0;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) {
+                const uint2 rg = t0 + k < num_tiles ? ranges[t0 + k] : make_uint2(0u, 0u);
+                const uint32_t len = rg.y - rg.x;
+                need[k] = len >= CKPT_DEEP_MIN ? (len + (uint32_t)(CKPT_SEG - 1)) >> CKPT_SHIFT : 0u;
+                mine += need[k];
+            }
+            const uint32_t inc = wave_inclusive_scan(mine);
+            __syncthreads();   // (wsum's readers of the pass before are done)
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = wsum[k];
+                if (k < w) before += v;
+                total += v;
+            }
+            uint32_t at = carry2 + before + inc - mine;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) {
+                if (t0 + k < num_tiles) seg_first[t0 + k] = at;
+                at += need[k];
+            }
+            carry2 += total;
+        }
+        if (threadIdx.x == 0) seg_first[num_tiles] = carry2;
+        dense_slots = carry2;
+    }
     uint32_t n_long = 0;
     if (any_long) {   // (workgroup-uniform) the frame has long lists: collect them
         for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {   // (eight loads in flight per thread: a 1080p frame is one trip)
@@ -260,6 +336,8 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
         const unsigned long long flags = ((unsigned long long)sparse << 31) | ((unsigned long long)any_long << 30);
         __hip_atomic_store(host_slot + 1, (unsigned long long)n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot + 2, (unsigned long long)huge | ((unsigned long long)very_deep << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // word 3: checkpoint slots in use on a dense frame (0xFFFFFFFF: not a dense frame with checkpoints) -- the backward's grid
+        __hip_atomic_store(host_slot + 3, (unsigned long long)dense_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -409,6 +409,8 @@ blend_backward_slot(uint32_t slot, const Camera& cam, uint32_t lastg, const uint
                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, const Ckpt& ck)
 {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (a dense frame's slots are packed, deep tiles only -- tile_scan_kernel --, and the grid may cover the layout's upper bound)
+    if (slot >= ((const_u32p)ck.seg_first)[cam.gx * cam.gy]) return;
     const uint32_t tile = ((const_u32p)ck.slot_tile)[slot];
     if (tile == CKPT_SLOT_NONE) return;  // (a dense frame's tile that left no checkpoints: the one-wave-per-tile walk has it)
     const uint32_t first_slot = ((const_u32p)ck.seg_first)[tile];
@@ -446,6 +448,8 @@ blend_backward_mixed_kernel(Camera cam, uint32_t lastg, const uint2* __restrict_
                             const float* __restrict__ dL_dpix, float* __restrict__ grad_accum, Ckpt ck, uint32_t dense_blocks)
 {
     if (blockIdx.x >= dense_blocks) {
+        // (a dense frame's slots are packed, deep tiles only -- tile_scan_kernel --; the grid is their number when the host still
+        //  knew it, else the layout's upper bound)
         blend_backward_slot(blockIdx.x - dense_blocks, cam, lastg, ranges, act, act_stride, splats, bg, final_T, n_contrib, dL_dpix,
                             grad_accum, ck);
         return;
@@ -461,7 +465,7 @@ blend_backward_mixed_kernel(Camera cam, uint32_t lastg, const uint2* __restrict_
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
                            const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
-                           const Ckpt& ck, int64_t num_rendered, hipStream_t st)
+                           const Ckpt& ck, int64_t num_rendered, int64_t dense_slots, hipStream_t st)
 {
     const int num_tiles = cam.gx * cam.gy;
     static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
@@ -469,10 +473,11 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
     if (ck.state) {
         // the forward left checkpoints: for every tile of a sparse frame, for the deep tiles (CKPT_DEEP_MIN) of a dense one --
         // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)
-        const uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;
+        uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;   // (the sparse layout; a dense frame's upper bound)
+        if (!sparse_frame && dense_slots >= 0 && (uint64_t)dense_slots < slots) slots = (uint32_t)dense_slots;
         const char* two = getenv("HGS_BWD_TWO_LAUNCHES");   // (read per frame: A/B measurements and the equivalence test)
         const bool two_launches = two && two[0] == '1';
-        if (sparse_frame || two_launches)
+        if ((sparse_frame || two_launches) && slots)
             hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                                act_stride, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);
         if (!sparse_frame && two_launches)

@@ -687,11 +687,22 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     const char* bin = (const char*)a.state.binning;
     const Splat* splats = (const Splat*)(geom + gl.splats);
 
+    // A dense frame with checkpoints: how many slots its deep tiles use is word 3 of the frame's pinned result slot (tile_scan_kernel),
+    // still there unless the ring went round since (then the backward covers the layout's upper bound and its surplus workgroups leave)
+    int64_t dense_slots = -1;
+    if (ck.state && a.state.sparse_frame == 0 && g_slot_base) {
+        const uint32_t index = (uint32_t)(a.state.n_token >> 32), ticket = (uint32_t)a.state.n_token;
+        if (index < SLOT_RING && ticket != 0) {
+            const volatile unsigned long long* w = g_slot_base + 8 * index;
+            const unsigned long long before = w[0], v3 = w[3], after = w[0];   // (the slot may be handed to a later frame any time)
+            if (slot_state(before, ticket) == 1 && slot_state(after, ticket) == 1 && v3 != 0xFFFFFFFFull) dense_slots = (int64_t)v3;
+        }
+    }
     { ProfScope ps(HGS_STAGE_BLEND_BACKWARD, st);
       launch_blend_backward(cam, Ptot, (const uint2*)(image + il.ranges), (const uint64_t*)(bin + bl.act) + ACT_PAD,
                             bl.act_stride, (const uint32_t*)(image + il.act_count), a.state.sparse_frame != 0, splats,
                             f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
-                            a.grad_accum, ck, a.state.num_rendered, st); }
+                            a.grad_accum, ck, a.state.num_rendered, dense_slots, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");

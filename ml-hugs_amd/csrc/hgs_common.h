@@ -247,6 +247,6 @@ void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const u
 void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                            const uint32_t* act_count, bool sparse_frame, const Splat* splats, const float* bg,
                            const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* grad_accum,
-                           const Ckpt& ck, int64_t num_rendered, hipStream_t st);
+                           const Ckpt& ck, int64_t num_rendered, int64_t dense_slots, hipStream_t st);   // dense_slots < 0: not known
 
 }  // namespace hgs

@@ -440,6 +440,7 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     if (!strcmp(name, "final_T")) return im.final_T;
     if (!strcmp(name, "n_contrib")) return im.n_contrib;
     if (!strcmp(name, "ranges")) return im.ranges;
+    if (!strcmp(name, "seg_first")) return im.seg_first;
     return (size_t)-1;
 }
 

@@ -821,6 +821,8 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         holder["final_T"] = sub(image, "final_T", 4 * H * W, torch.float32).view(H, W)
         holder["n_contrib"] = sub(image, "n_contrib", 4 * H * W, torch.int32).view(H, W) & 0x0FFFFFFF  # top bits: clamp mask
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
+        holder["seg_first"] = sub(image, "seg_first", 4 * (T + 1), torch.int32)   # checkpoint slots (meaningful when the frame left any)
+        holder["has_checkpoints"] = bool(getattr(fn, "bw", None) is not None and fn.bw.state.ckpt)
         lst = sub(binning, "list", 8 * N, torch.int64)                      # sorted: (pos1 << 32) | mask << 28 | gaussian
         raw = lst & 0xFFFFFFFF
         holder["values"] = (raw & 0x0FFFFFFF).to(torch.int32)               # sorted list: Gaussian index of entry i

@@ -1216,6 +1216,48 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device
 
 
 @pytest.mark.gpu
+def test_checkpoint_slots_of_a_dense_frame_are_packed_for_its_deep_tiles(device, monkeypatch):
+    """tile_scan_kernel deals the checkpoint slots: on a sparse frame tile t owns [(start >> 5) + t, (next start >> 5) + t + 1) --
+    at least ceil(length / 32) -- ; on a DENSE frame only the tiles of CKPT_DEEP_MIN (512) entries and more own any, exactly
+    ceil(length / 32) each, packed in tile order (the backward launches one workgroup per slot in use)."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _debug_forward_state
+    from hugs_amd import synthetic as syn
+    _force_ctypes_binding(monkeypatch)
+    H = W = 1088
+    sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+    bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        sc[k] = np.concatenate([sc[k], np.asarray(bgd[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    t = {k: to_dev(sc[k], device) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    for _ in range(2):   # (the second frame knows the shape has deep lists and asks for checkpoints)
+        _, _, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"], scales=t["scales"],
+                                        rotations=t["rotations"])
+    assert st["has_checkpoints"]
+    rg = st["ranges"].cpu().numpy().astype(np.int64)
+    length = rg[:, 1] - rg[:, 0]
+    assert (length > 0).sum() >= 4096 and (length >= 512).sum() >= 8 and (length > 2048).any()
+    sf = st["seg_first"].cpu().numpy().astype(np.int64)
+    want = np.where(length >= 512, (length + 31) // 32, 0)
+    assert np.array_equal(np.diff(sf), want)
+    assert sf[0] == 0 and sf[-1] == want.sum()
+
+    # ... and the sparse layout, on the stack alone (a few hundred non-empty tiles)
+    sp = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+    t = {k: to_dev(sp[k], device) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    _, _, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sp, device), shs=t["shs"], scales=t["scales"],
+                                    rotations=t["rotations"])
+    assert st["has_checkpoints"]
+    rg = st["ranges"].cpu().numpy().astype(np.int64)
+    length = rg[:, 1] - rg[:, 0]
+    assert 0 < (length > 0).sum() < 4096
+    sf = st["seg_first"].cpu().numpy().astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(length)])          # where every tile's list segment begins
+    assert np.array_equal(sf, (start >> 5) + np.arange(len(start)))
+    assert (np.diff(sf) >= (length + 31) // 32).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("frame", ["sparse", "dense"])
 def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monkeypatch):
     """Round 4: the quads of LONG tiles are blended by four waves each, split by depth (blend_fwd.h: compose from T = 1 in

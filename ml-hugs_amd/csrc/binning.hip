@@ -63,7 +63,8 @@ constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long t
 constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
 constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
 constexpr uint32_t DEEP_MEAN_MIN = 384;
-// dense frames: 768 (2 048 -- what the one-workgroup-per-tile sort holds -- until round 4).  A person in front of a scene puts
+// dense frames: 768 WHEN the frame holds a list beyond 2 048 entries (else 2 048: tile_scan_kernel, dense_min); until round 4: 2 048,
+// what the one-workgroup-per-tile sort holds.  A person in front of a scene puts
 // hundreds of tiles between 1 024 and 2 048 entries, whose one-wave walks were the tail of the fused kernel: the all-rows step's
 // joint render 237 -> 192 us.  768 against 1 024 (same box, kernel trace): the trained-scene profile's fused kernel 223 -> 205 us
 // for +1 us of long-tile sort, C4 and the step unchanged; 512 / 384 give the sort back what the blend gains (31 / 43 us).  ("Has long tiles" is also what makes the bindings offer a checkpoint buffer; whether a DENSE
@@ -83,8 +84,10 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
                  uint2* __restrict__ ranges, uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total,
                  uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ seg_first, uint32_t capacity,
-                 unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense)
+                 unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense_arg)
 {
+    // (bit 31: the dense threshold was given explicitly -- HGS_LONG_MIN_DENSE -- and applies whatever the frame's deepest list)
+    const uint32_t long_min_dense = long_min_dense_arg & 0x7FFFFFFFu, dense_unconditional = long_min_dense_arg >> 31;
     __shared__ uint32_t n_long_sh;
     __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
@@ -247,9 +250,15 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     const bool deep_lists = sparse && n_nonempty && total64 >= (unsigned long long)DEEP_MEAN_MIN * n_nonempty;
     const uint32_t n_sparse_long = deep_lists ? n_large_sparse : n_large_shallow;
     const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
-    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : long_min_dense;
-    const uint32_t any_long = (use_sparse ? n_sparse_long : n_large_dense) ? 1u : 0u;
     const uint32_t huge = n_huge & 0xFFFFu, very_deep = n_huge >> 16;   // lists beyond SORT_CAP_MID / beyond SORT_CAP_SMALL entries
+    // A dense frame takes the long-tile path (sorted ahead, blended by depth) from long_min_dense entries on only when it holds a list
+    // the one-workgroup-per-tile kernel cannot take or walks as a tail (beyond SORT_CAP_SMALL entries); a frame whose deepest lists
+    // are merely long (C4's joint render: 1 900) is throughput-bound in that kernel, and the detour cost it 40 us (mid sort 27 + a
+    // slower fused kernel, `profiles/r3j_c4_serial_timeline.txt` against round 4's first collection)
+    const bool dense_long = very_deep != 0u || dense_unconditional != 0u;
+    const uint32_t dense_min = dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
+    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : dense_min;
+    const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_long ? n_large_dense : 0u)) ? 1u : 0u;
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;
         n_total[3] = sparse, n_total[4] = threshold;
@@ -350,8 +359,9 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count,
     // (read on every call: the tests switch them between frames)
     auto from_env = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
     const uint32_t long_min_sparse = from_env("HGS_LONG_MIN_SPARSE", LONG_MIN_SPARSE), long_min_dense = from_env("HGS_LONG_MIN_DENSE", LONG_MIN_DENSE);
+    const uint32_t dense_arg = long_min_dense | (getenv("HGS_LONG_MIN_DENSE") ? 0x80000000u : 0u);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
-                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, long_min_sparse, long_min_dense);
+                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, long_min_sparse, dense_arg);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1049,18 +1049,21 @@ struct FusedKernelArgs {
     int clamp_output, long_sorted; Ckpt ck; const uint32_t* large_tiles; uint32_t num_workers;
 };
 
-template <bool FUSED>
+// WORKERS = false: the instance for launches WITHOUT deep workers (no long-tile sort ran in front: the frames without long lists --
+// the bench workload): the same tile path with the workers' code, LDS and registers compiled out.
+template <bool FUSED, bool WORKERS = FUSED>
 __global__ void __launch_bounds__(256) FUSED_KERNEL_ATTR
 tile_sort_small_kernel(FusedKernelArgs a)
 {
-    __shared__ uint64_t sh[FUSED ? DEEP_LDS_BYTES / 8 : (size_t)SORT_CAP_SMALL];  // (the deep workers' staging needs a little more than the sort)
+    __shared__ uint64_t sh[WORKERS ? DEEP_LDS_BYTES / 8 : (size_t)SORT_CAP_SMALL];  // (the deep workers' staging needs a little more than the sort)
     static_assert(DEEP_LDS_BYTES >= SORT_CAP_SMALL * 8, "sort buffer");
     const uint32_t* __restrict__ gate = a.gate;
     if (*gate) return;
+    if (!WORKERS) a.num_workers = 0u;
     HGS_TRACE_PUT(0, wall_clock64());
     HGS_TRACE_PUT(3, ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID, HW_ID
-    const bool deep_blend = a.num_workers != 0u && gate[7] != 0u;   // (gate[7] = n_total[8], decided by the scan: data, not launch sizes)
-    if (FUSED && blockIdx.x < a.num_workers) {
+    const bool deep_blend = WORKERS && a.num_workers != 0u && gate[7] != 0u;   // (gate[7] = n_total[8], decided by the scan: data, not launch sizes)
+    if (WORKERS && blockIdx.x < a.num_workers) {
         if (!deep_blend) return;
         // the first workgroups of the grid blend the long tiles -- sorted by the long tiles' kernels, which ran BEFORE this
         // kernel -- one (tile, quad) at a time, split by depth over their four waves (blend_fwd.h), beside the other tiles'
@@ -1593,7 +1596,8 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
             if (workers && hist.n_long >= 0) workers = min(workers, (uint32_t)(5 * hist.n_long + 64 + 7) & ~7u);
             ka.cam = fb->cam, ka.lastg = fb->lastg, ka.splats = fb->splats, ka.bg = fb->bg, ka.out_color = fb->out_color, ka.final_T = fb->final_T;
             ka.n_contrib = fb->n_contrib, ka.clamp_output = fb->clamp_output, ka.ck = fb->ck, ka.num_workers = workers;
-            hipLaunchKernelGGL(tile_sort_small_kernel<true>, dim3(workers + num_tiles), dim3(256), 0, st, ka);
+            if (workers) hipLaunchKernelGGL((tile_sort_small_kernel<true, true>), dim3(workers + num_tiles), dim3(256), 0, st, ka);
+            else hipLaunchKernelGGL((tile_sort_small_kernel<true, false>), dim3(num_tiles), dim3(256), 0, st, ka);
         } else
             hipLaunchKernelGGL(tile_sort_small_kernel<false>, dim3(num_tiles), dim3(256), 0, st, ka);
     }

@@ -125,7 +125,7 @@ typedef struct hgs_forward_args {
      * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
      * its autograd backward, without the five elementwise passes over the image they cost. */
     int32_t clamp_output;
-    /* !=0: the caller expects no long tile -- a list of more than 1024 entries (256 on a sparse frame whose lists are deep on average; the scan kernel decides) -- (its previous frame of this shape had none, see
+    /* !=0: the caller expects no long tile -- a list the scan kernel calls long: on a dense frame more than 768 entries when the frame holds one beyond 2048 (else none), on a sparse frame more than 256 when its lists are deep on average, else more than 1024 -- (its previous frame of this shape had none, see
      * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
      * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
     int32_t expect_no_long_tiles;
@@ -167,7 +167,7 @@ typedef struct hgs_forward_state {
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
-    int32_t has_long_tiles;   /* !=0: some tile list is long -- more than 1024 entries, on a sparse frame with deep lists more than 256 (feeds the next frame's expect_no_long_tiles) */
+    int32_t has_long_tiles;   /* !=0: some tile list is long by the scan kernel's rule (see expect_no_long_tiles; feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
 } hgs_forward_state;
 

@@ -346,14 +346,11 @@ __device__ __forceinline__ void blend_forward_deep_quad(const Camera& cam, uint3
         // ---- phase A: compose my segment from T = 1 -- but wave 0 knows the transmittance its pixels arrive with (T_run): it
         // walks its segment with the exact rule at once and publishes (P, C) = what the segment did to (T, colour) RELATIVE to
         // the start state, so that the scan below treats all segments alike; its pixels that stop inside are final here.
-        float w0_T = 0.0f, w0_c0 = 0.0f, w0_c1 = 0.0f, w0_c2 = 0.0f;
-        uint32_t w0_last = 0;
         if (cnt) {
             float P = (m == 0u) ? T_run : 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
             uint32_t ll = 0;
             if (m == 0u) {
                 walk_staged<true>(my_stage, cnt, pxf, pyf, P, c0, c1, c2, ll);
-                w0_T = P, w0_c0 = c0, w0_c1 = c1, w0_c2 = c2, w0_last = ll;
             } else
                 walk_staged<false>(my_stage, cnt, pxf, pyf, P, c0, c1, c2, ll);
             sh.comp[buf][m][lane] = make_float4(P, c0, c1, c2);   // (wave 0: absolute T after the segment, sign = stopped inside)

@@ -239,3 +239,23 @@ def test_backward_does_not_depend_on_the_number_of_threads():
             assert np.abs(a - b).max() <= tol * scale, (dtype.__name__, k)
     ho.set_threads(1)
     ho.set_threads(1, np.float64)
+
+
+def test_usable_cpus_respects_affinity_and_quota(tmp_path, monkeypatch):
+    """The CPU baseline's thread count: never more than the affinity mask, and capped by a cgroup quota when one is set (the GPU
+    boxes show 256 CPUs under a 16-CPU quota; 256 OpenMP threads ran the port 3.5x slower than 16)."""
+    import builtins
+    n = ho.usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("300000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert ho.usable_cpus() == min(3, len(os.sched_getaffinity(0)))
+

@@ -1166,8 +1166,8 @@ def test_segmented_backward_equals_the_one_wave_per_quad_backward(binding, devic
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
-def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device, monkeypatch):
+@pytest.mark.parametrize("binding,size", [("cpp", (1088, 1088)), ("ctypes", (1088, 1088)), ("cpp", (1152, 2048))])
+def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, size, device, monkeypatch):
     """A DENSE frame (every one of 68 x 68 tiles non-empty: a scene) with a stack of Gaussians in its middle (a person in front
     of it: tiles from a few hundred to several thousand entries deep).  With a checkpoint buffer the tiles of CKPT_DEEP_MIN
     entries and more leave checkpoints and go through the depth-segmented backward, the others through the one-wave-per-tile
@@ -1177,9 +1177,9 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, device
     from hugs_amd import synthetic as syn
     if binding == "ctypes":
         _force_ctypes_binding(monkeypatch)
-    H = W = 1088
+    H, W = size   # (1152 x 2048 = 9 216 tiles: more than the scan kernel takes in one trip -- its second-pass slot layout)
     sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
-    bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+    bgd = syn.scene_gaussians(20_000 if H * W < 2_000_000 else 40_000, sc["cam"], seed=32, sigma_px=2.0)
     for k, src in (("means3D", "means3D"), ("scales", "scales"), ("rotations", "rotations"), ("opacities", "opacities"), ("shs", "shs")):
         sc[k] = np.concatenate([sc[k], np.asarray(bgd[src], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
     inp = oracle_inputs(sc)

@@ -1220,6 +1220,33 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, size, 
 
 
 @pytest.mark.gpu
+def test_backward_long_after_its_forward_covers_the_slot_layouts_upper_bound(device):
+    """The backward of a dense frame with deep tiles learns how many checkpoint slots are in use from the frame's pinned result
+    slot; 1 024 forwards later the ring has handed that slot to another frame, and the backward launches the layout's upper bound
+    instead (surplus workgroups leave on the slot count the scan kernel left in device memory): same gradients."""
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd import synthetic as syn
+    H = W = 1088
+    sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+    bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        sc[k] = np.concatenate([sc[k], np.asarray(bgd[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    dL = to_dev(sc["dL_dpix"], device)
+    for _ in range(2):   # (the second frame asks for checkpoints)
+        t0, c0, _ = run_gpu(sc, device)
+        c0.backward(dL)
+    small = make_scene(**CASES["basic_d3"])
+    t1, c1, _ = run_gpu(sc, device)
+    ring = int(dgr._load().hgs_debug_stat(b"slot_ring"))
+    for _ in range(ring + 8):
+        run_gpu(small, device)
+    c1.backward(dL)
+    assert torch.equal(c1.detach(), c0.detach())
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+
+
+@pytest.mark.gpu
 def test_checkpoint_slots_of_a_dense_frame_are_packed_for_its_deep_tiles(device, monkeypatch):
     """tile_scan_kernel deals the checkpoint slots: on a sparse frame tile t owns [(start >> 5) + t, (next start >> 5) + t + 1) --
     at least ceil(length / 32) -- ; on a DENSE frame only the tiles of CKPT_DEEP_MIN (512) entries and more own any, exactly

@@ -732,6 +732,9 @@ def rasterize_deferred(means3D, opacities, raster_settings, shs=None, colors_pre
     return f
 
 
+_EMPTY = torch.Tensor([])
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -768,7 +771,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        empty = torch.Tensor([])
+        empty = _EMPTY   # (one shared empty CPU tensor, as upstream's torch.Tensor([]) per call)
         if shs is None:
             shs = empty
         if colors_precomp is None:

@@ -390,7 +390,9 @@ size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int
 
 /* Test/debug introspection of the library's own (host-side) state: "tile_counter_entries" (per-stream counter arrays it
  * currently keeps), "tile_counter_max_entries" (the bound beyond which idle streams' arrays are dropped), "slot_ring"
- * (result slots: forwards after which an unpolled deferred frame expires).  -1 for an unknown name. */
+ * (result slots: forwards after which an unpolled deferred frame expires); host-time accounting since the library was loaded:
+ * "forward_calls" / "forward_ns" (time inside hgs_rasterize_forward) / "forward_wait_ns" (the part of it spent waiting for N),
+ * "backward_calls" / "backward_ns".  -1 for an unknown name. */
 int64_t hgs_debug_stat(const char *name);
 
 #ifdef __cplusplus

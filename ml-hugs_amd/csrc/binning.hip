@@ -257,7 +257,9 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     // slower fused kernel, `profiles/r3j_c4_serial_timeline.txt` against round 4's first collection)
     const bool dense_long = very_deep != 0u || dense_unconditional != 0u;
     const uint32_t dense_min = dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
-    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense)) : dense_min;
+    // (a shallow sparse frame's threshold is the one n_large_shallow counted with; an explicit HGS_LONG_MIN_DENSE below it still applies)
+    const uint32_t shallow_min = dense_unconditional ? min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense) : (uint32_t)LONG_MIN_SPARSE_SHALLOW;
+    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : shallow_min) : dense_min;
     const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_long ? n_large_dense : 0u)) ? 1u : 0u;
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;

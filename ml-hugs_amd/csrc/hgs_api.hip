@@ -1,4 +1,6 @@
 // C ABI entry points (include/hgs_rasterizer.h): argument validation, scratch layout, stage sequencing.
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -102,12 +104,30 @@ struct ProfScope {
     }
 };
 
+// Host-time accounting (hgs_debug_stat): nanoseconds spent inside the two entry points and, of the forward's, spinning for N --
+// "host busy per frame" of a frame loop = (its wall time - forward_wait_ns) / frames.  Two clock reads per call.
+std::atomic<uint64_t> g_stat_fwd_calls{0}, g_stat_fwd_ns{0}, g_stat_wait_ns{0}, g_stat_bwd_calls{0}, g_stat_bwd_ns{0};
+inline uint64_t now_ns()
+{
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct StatScope {
+    std::atomic<uint64_t>&calls, &ns; uint64_t t0;
+    StatScope(std::atomic<uint64_t>& c, std::atomic<uint64_t>& n) : calls(c), ns(n), t0(now_ns()) {}
+    ~StatScope() { calls.fetch_add(1, std::memory_order_relaxed), ns.fetch_add(now_ns() - t0, std::memory_order_relaxed); }
+};
+
 // The host learns N from a pinned, host-coherent 64-bit slot that tile_scan_kernel writes -- (sparse-frame bit << 63 |
 // long-tiles bit << 62 | 30-bit ticket << 32 | N) -- and the host polls: a ring of slots so that calls from several
 // threads / streams do not collide.
 struct HostSlot { volatile unsigned long long* word; uint32_t ticket; uint32_t index; };
 constexpr unsigned SLOT_RING = 1024;  // deferred frames are polled later: far more slots than frames anyone keeps in flight
 unsigned long long* g_slot_base = nullptr;
+// (device, stream, shape) of the frame that holds each slot, for hgs_forward_poll: a deferred frame's counts feed the shape's
+// launch-size record there (the waiting path records them in hgs_rasterize_forward itself)
+struct SlotOwner { uint32_t ticket = 0; int dev = -1; void* st = nullptr; int P = 0, H = 0, W = 0; };
+SlotOwner g_slot_owner[SLOT_RING];
+std::mutex g_slot_owner_mu;
 HostSlot host_slot()
 {
     static std::mutex mu;
@@ -145,6 +165,7 @@ int expired()
 // (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
 int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out, bool* long_out)
 {
+    struct WaitTime { uint64_t t0 = now_ns(); ~WaitTime() { g_stat_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed); } } wt;
     for (unsigned spins = 1;; ++spins) {
         const unsigned long long v = *hs.word;
         const int state = slot_state(v, hs.ticket);
@@ -186,7 +207,9 @@ struct TileCounters {
     uint32_t* buf = nullptr; size_t tiles = 0; bool dirty = true;
     uint64_t last_use = 0;   // (table clock: eviction takes the least recently used)
     std::mutex lease;
-    ~TileCounters() { if (buf) (void)hipFree(buf); }
+    // (no hipFree here: the table is a namespace-scope static, and HIP calls from static destructors -- process exit, dlclose --
+    //  run after the runtime may have shut down.  Arrays are freed explicitly where entries are evicted or grow; what the table
+    //  still holds at exit goes with the process.)
 };
 struct TcKey {
     int dev; hipStream_t st;
@@ -221,30 +244,40 @@ int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, TileCoun
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::shared_ptr<TileCounters> e;
+    std::vector<std::shared_ptr<TileCounters>> evicted;
     {
         std::lock_guard<std::mutex> lk(g_tc_mu);
         auto it = g_tc.find(TcKey{dev, st});
         if (it == g_tc.end()) {
             if (g_tc.size() >= TC_MAX_ENTRIES) {
                 // Drop the least recently used entries nobody holds (use_count 1 = the table's own reference), down to half
-                // the table.  Their streams may still have frames in flight that use the arrays -- and may no longer exist,
-                // so their handles are not probed: the device is drained once, then the arrays are freed.  (Rare: more than
-                // TC_MAX_ENTRIES streams have rendered on this device.)
+                // the table.  They leave the table here, under the lock (nobody can look them up any more); their arrays are
+                // freed below, outside it.  (Rare: more than TC_MAX_ENTRIES streams have rendered on this device.)
                 std::vector<std::pair<uint64_t, TcKey>> idle;
                 for (auto& kv : g_tc)
                     if (kv.first.dev == dev && kv.second.use_count() == 1) idle.push_back({kv.second->last_use, kv.first});
                 std::sort(idle.begin(), idle.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-                if (!idle.empty()) {
-                    (void)hipDeviceSynchronize();
-                    (void)hipGetLastError();
-                    const size_t drop = std::min(idle.size(), g_tc.size() - TC_MAX_ENTRIES / 2);
-                    for (size_t k = 0; k < drop; ++k) g_tc.erase(idle[k].second);
+                const size_t drop = idle.empty() ? 0 : std::min(idle.size(), g_tc.size() - TC_MAX_ENTRIES / 2);
+                for (size_t k = 0; k < drop; ++k) {
+                    auto victim = g_tc.find(idle[k].second);
+                    evicted.push_back(std::move(victim->second));
+                    g_tc.erase(victim);
                 }
             }
             it = g_tc.emplace(TcKey{dev, st}, std::make_shared<TileCounters>()).first;
         }
         e = it->second;
         e->last_use = ++g_tc_clock;
+    }
+    if (!evicted.empty()) {
+        // The evicted streams may still have frames in flight that use the arrays -- and may no longer exist, so their handles
+        // are not probed: the device is drained once (no lock held: other threads' forwards go on), then the arrays are freed.
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        for (auto& d : evicted) {
+            if (d->buf) (void)hipFree(d->buf);
+            d->buf = nullptr, d->tiles = 0;
+        }
     }
     e->lease.lock();  // (outside the table lock: another thread may be between its preprocess kernel and its scan)
     lease->e = e;   // (the lease holds the pin)
@@ -272,7 +305,10 @@ int acquire_tile_counters(hipStream_t st, size_t tiles, uint32_t** out, TileCoun
     return HGS_OK;
 }
 
-// Launch-size memory per (device, stream, frame shape): a small direct-mapped table, overwritten on collision (hints only).
+// Launch-size memory per (device, stream, frame shape): a small direct-mapped table, overwritten on collision.  Hints: a frame's
+// image, radii and lists never depend on them.  What CAN depend on them is which of two equivalent backward forms runs (a dense
+// frame leaves checkpoints for the depth-segmented backward only when the shape's record shows lists beyond SORT_CAP_SMALL entries):
+// gradients then agree up to fp32 summation order, as they do between any two runs of the atomics-based backward.
 // (The shape belongs to the key: a HUGS step renders the joint frame and the human-only frame in turn on one stream.)
 struct HistKey {
     int dev; hipStream_t st; int P, H, W;
@@ -426,6 +462,11 @@ int64_t hgs_debug_stat(const char* name)
     }
     if (!strcmp(name, "tile_counter_max_entries")) return (int64_t)TC_MAX_ENTRIES;
     if (!strcmp(name, "slot_ring")) return (int64_t)SLOT_RING;
+    if (!strcmp(name, "forward_calls")) return (int64_t)g_stat_fwd_calls.load();
+    if (!strcmp(name, "forward_ns")) return (int64_t)g_stat_fwd_ns.load();
+    if (!strcmp(name, "forward_wait_ns")) return (int64_t)g_stat_wait_ns.load();
+    if (!strcmp(name, "backward_calls")) return (int64_t)g_stat_bwd_calls.load();
+    if (!strcmp(name, "backward_ns")) return (int64_t)g_stat_bwd_ns.load();
     return -1;
 }
 
@@ -448,6 +489,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
                               hgs_forward_state* state, void* stream)
 {
     if (!args || !alloc || !state) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
+    StatScope stat(g_stat_fwd_calls, g_stat_fwd_ns);
     const hgs_forward_args& a = *args;
     hipStream_t st = (hipStream_t)stream;
     Camera cam;
@@ -593,6 +635,10 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (a.defer_n) {
         // deferred frame: never waits; nothing can be repaired later, so the long-tile sort is always part of it
         if (int rc = enqueue_frame(hint, true)) return rc;
+        {
+            std::lock_guard<std::mutex> lk(g_slot_owner_mu);
+            g_slot_owner[slot.index] = SlotOwner{slot.ticket, dev, (void*)st, Ptot, cam.H, cam.W};
+        }
         state->num_rendered = -1;
         return 0;
     }
@@ -639,6 +685,14 @@ int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
         if (!block) return HGS_PENDING;
         if (int rc = wait_for_slot(hs, (hipStream_t)stream, &n32, &sparse, &has_long)) return rc;
     }
+    {   // the frame's counts feed its shape's launch-size record, as a waiting frame's do
+        SlotOwner o;
+        {
+            std::lock_guard<std::mutex> lk(g_slot_owner_mu);
+            o = g_slot_owner[index];
+        }
+        if (o.ticket == ticket && slot_state(*hs.word, ticket) == 1) history_put(HistKey{o.dev, (hipStream_t)o.st, o.P, o.H, o.W}, hs);
+    }
     if (n32 == 0xFFFFFFFFu) return too_many_pairs();
     state->sparse_frame = sparse ? 1 : 0, state->has_long_tiles = has_long ? 1 : 0;
     if ((int64_t)n32 > state->binning_capacity)
@@ -651,6 +705,7 @@ int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
 int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
 {
     if (!args) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
+    StatScope stat(g_stat_bwd_calls, g_stat_bwd_ns);
     const hgs_backward_args& a = *args;
     const hgs_forward_args& f = a.fwd;
     hipStream_t st = (hipStream_t)stream;

@@ -305,6 +305,8 @@ void oracle_emit_keys(int P, int W, const real *depths, const int32_t *radii, co
 /* K4: stable LSD radix sort on the full 64-bit key (8 passes of 8 bits).  With OpenMP every thread takes one contiguous
    chunk of the array per pass: private digit counts, one prefix over (digit, thread) -- digit-major, so a digit's elements keep
    chunk order = input order --, then each thread scatters its own chunk in order: the same permutation as the serial loop. */
+static int g_sort_chunks = 0;
+void oracle_set_sort_chunks(int n) { g_sort_chunks = n; }
 void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
 {
     if (N <= 1) return;
@@ -317,20 +319,25 @@ void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
     nt = omp_get_max_threads();
     if (nt > 64) nt = 64;            /* (256 counters per thread and pass: more chunks than this only lengthen the prefix) */
     if (N < ((int64_t)1 << 16)) nt = 1;
+    if (g_sort_chunks > 0) nt = g_sort_chunks > 64 ? 64 : g_sort_chunks;   /* (tests: more chunks than the team has threads) */
 #endif
     size_t *cnt = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)nt);
     for (int pass = 0; pass < 8; ++pass) {
         const int sh = 8 * pass;
 #pragma omp parallel num_threads(nt)
         {
-            int t = 0;
+            /* The array is cut into nt CHUNKS; the team may hold fewer threads than asked for (OMP_DYNAMIC, OMP_THREAD_LIMIT, a
+               cgroup cap, a nested region): every thread takes chunks t, t + team, t + 2 team, ... so that none is left out. */
+            int t = 0, team = 1;
 #ifdef _OPENMP
-            t = omp_get_thread_num();
+            t = omp_get_thread_num(), team = omp_get_num_threads();
 #endif
-            const int64_t lo = N * t / nt, hi = N * (t + 1) / nt;
-            size_t *c = cnt + 256 * (size_t)t;
-            memset(c, 0, sizeof(size_t) * 256);
-            for (int64_t i = lo; i < hi; ++i) c[(ka[i] >> sh) & 255]++;
+            for (int ch = t; ch < nt; ch += team) {
+                const int64_t lo = N * ch / nt, hi = N * (ch + 1) / nt;
+                size_t *c = cnt + 256 * (size_t)ch;
+                memset(c, 0, sizeof(size_t) * 256);
+                for (int64_t i = lo; i < hi; ++i) c[(ka[i] >> sh) & 255]++;
+            }
 #pragma omp barrier
 #pragma omp single
             {
@@ -342,9 +349,13 @@ void oracle_sort_pairs(int64_t N, uint64_t *keys, uint32_t *values)
                         pos += n;
                     }
             } /* (implicit barrier) */
-            for (int64_t i = lo; i < hi; ++i) {
-                const size_t p = c[(ka[i] >> sh) & 255]++;
-                kb[p] = ka[i], vb[p] = va[i];
+            for (int ch = t; ch < nt; ch += team) {
+                const int64_t lo = N * ch / nt, hi = N * (ch + 1) / nt;
+                size_t *c = cnt + 256 * (size_t)ch;
+                for (int64_t i = lo; i < hi; ++i) {
+                    const size_t p = c[(ka[i] >> sh) & 255]++;
+                    kb[p] = ka[i], vb[p] = va[i];
+                }
             }
         }
         uint64_t *tk = ka; ka = kb; kb = tk;

@@ -79,6 +79,11 @@ def set_threads(n, dtype=np.float32):
     _lib(dtype).oracle_set_threads(int(n))
 
 
+def set_sort_chunks(n, dtype=np.float32):
+    """Tests: cut the radix sort's array into n chunks whatever the thread count (0 = one chunk per thread, the default)."""
+    _lib(dtype).oracle_set_sort_chunks(int(n))
+
+
 def set_upstream_scale_grad(on):
     """True: dL/dscale WITHOUT the scale_modifier factor, as the published kernel computes it (the library's
     HGS_BWD_UPSTREAM_SCALE_GRAD switch); False (default): the true derivative."""

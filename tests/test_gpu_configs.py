@@ -255,7 +255,7 @@ def test_storage_order_changes_nothing_but_speed(device):
     o = torch.from_numpy(order).to(device)
     for k in ("means3D", "opacities", "shs", "scales", "rotations", "means2D"):
         a, b = t0[k].grad[o], t1[k].grad
-        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) <= 5e-5, k   # (float atomics in another order)
+        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) <= (5e-5 if k == "rotations" else 1e-5), k   # (float atomics in another order)
 
 
 @pytest.mark.gpu

@@ -25,9 +25,18 @@ pytestmark = pytest.mark.gpu
 COLOR_TOL, COLOR_OUTLIER_TOL, COLOR_INLIER_FRAC, COLOR_MEAN_TOL = 1e-4, 2.0 / 255.0, 0.9998, 2e-6
 GRAD_REL_TOL = 1e-3
 # Two GPU runs of the SAME arithmetic whose float atomics land in another order (another launch shape, another binding, one set of
-# Gaussians or two): not bit-equal; observed up to 1.2e-5 relative L2 on the rotation gradients of the opaque scene (cancelling
-# sums), typically 1e-7 .. 3e-6.  The oracle's bar above is 20 times wider.
-ATOMIC_ORDER_TOL = 5e-5
+# Gaussians or two): not bit-equal; typically 1e-7 .. 3e-6 relative L2, observed up to 1.2e-5 on the rotation gradients of the
+# opaque scene alone (cancelling sums) -- they get the wider bar, everything else 1e-5.
+ATOMIC_ORDER_TOL = 1e-5
+ATOMIC_ORDER_TOL_ROTATIONS = 5e-5
+# Two backward FORMS on the same frame (one wave per tile against the depth-segmented walk from the forward's checkpoints, the
+# depth-parallel forward's checkpoints against the one-wave forward's): the checkpoints' colour-prefix differences cancel in
+# another order on top of the atomics'.  The oracle's bar above is 20 times wider.
+ALT_BACKWARD_TOL = 5e-5
+
+
+def order_tol(key):
+    return ATOMIC_ORDER_TOL_ROTATIONS if key == "rotations" else ATOMIC_ORDER_TOL
 
 
 def to_dev(a, device, grad=False):
@@ -246,7 +255,7 @@ def test_binning_capacity_guess_never_changes_results(guess, device, monkeypatch
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         if t0[k] is not None and t0[k].grad is not None:   # float atomics: summation order differs run to run
-            assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+            assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= order_tol(k), k
 
 
 @pytest.mark.parametrize("name", ["basic_d3", "precomp_rgb", "precomp_cov", "deg0_M16"])
@@ -277,7 +286,7 @@ def test_cpp_binding_equals_ctypes_binding(name, device, monkeypatch):
         assert torch.equal(c, c0) and torch.equal(r, r0)
         for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
             if t0[k] is not None and t0[k].grad is not None:
-                assert rel_l2(t[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+                assert rel_l2(t[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= order_tol(k), k
             else:
                 assert t[k] is None or t[k].grad is None or float(t[k].grad.abs().max()) == 0.0
 
@@ -297,7 +306,7 @@ def test_second_backward_through_a_retained_graph(device):
     torch.cuda.synchronize()
     for k, v in first.items():
         assert torch.equal(held[k], v), f"{k}: the first backward's gradient was overwritten"
-        assert rel_l2(t[k].grad.cpu().numpy(), v.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(t[k].grad.cpu().numpy(), v.cpu().numpy()) <= order_tol(k), k
 
 
 def test_two_frames_in_flight_on_two_streams(device):
@@ -379,7 +388,7 @@ def test_fused_output_clamp_equals_torch_clamp_forward_and_backward(device):
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
-        assert rel_l2(outs[1][1][k].cpu().numpy(), outs[0][1][k].cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(outs[1][1][k].cpu().numpy(), outs[0][1][k].cpu().numpy()) <= order_tol(k), k
 
 
 def test_api_errors(device):
@@ -656,7 +665,7 @@ def test_wrong_guess_about_long_tiles_never_changes_results(wrong_guess, device,
     torch.cuda.synchronize()
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= order_tol(k), k
 
 
 def test_tile_counters_are_clean_after_every_frame(device):
@@ -860,9 +869,9 @@ def test_second_segment_equals_the_concatenated_call(name, binding, device, monk
         if t[k] is None:
             continue
         full = t[k].grad.cpu().numpy()
-        assert rel_l2(a[k].grad.cpu().numpy(), full[:cut]) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(a[k].grad.cpu().numpy(), full[:cut]) <= order_tol(k), k
         second_ref = full[cut:, :K] if (k == "shs" and K < sc["M"]) else full[cut:]
-        assert rel_l2(b[k].grad.cpu().numpy(), second_ref) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(b[k].grad.cpu().numpy(), second_ref) <= order_tol(k), k
 
 
 def test_second_segment_argument_errors(device):
@@ -1136,7 +1145,7 @@ def test_segmented_backward_equals_the_one_wave_per_quad_backward(binding, devic
     (HGS_BWD_SEGMENTED=0, or a caller that offers none) the one-wave-per-quad kernel runs.  Same frame through both -- a
     stacked scene with lists a few hundred to two thousand entries deep, i.e. many segments per quad, early-saturating
     pixels, clamped outputs: images bit-equal (the forward only ADDS checkpoint stores), gradients within the summation
-    order of the float atomics plus the checkpoint's colour-prefix cancellation (ATOMIC_ORDER_TOL), both within the bar of the oracle."""
+    order of the float atomics plus the checkpoint's colour-prefix cancellation (ALT_BACKWARD_TOL), both within the bar of the oracle."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     if binding == "ctypes":
@@ -1160,7 +1169,7 @@ def test_segmented_backward_equals_the_one_wave_per_quad_backward(binding, devic
         dgr._cpp.use_checkpoints(True)
     assert torch.equal(images[True], images[False])
     for k in grads[True]:
-        assert rel_l2(grads[True][k], grads[False][k]) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(grads[True][k], grads[False][k]) <= ALT_BACKWARD_TOL, k
         if k in refg:
             assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k
 
@@ -1172,7 +1181,7 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, size, 
     of it: tiles from a few hundred to several thousand entries deep).  With a checkpoint buffer the tiles of CKPT_DEEP_MIN
     entries and more leave checkpoints and go through the depth-segmented backward, the others through the one-wave-per-tile
     kernel; without one (HGS_BWD_SEGMENTED=0) that kernel takes them all.  Images bit-equal, gradients equal within the float
-    atomics' order and the checkpoints' prefix cancellation (ATOMIC_ORDER_TOL), both within the oracle's bar."""
+    atomics' order and the checkpoints' prefix cancellation (ALT_BACKWARD_TOL), both within the oracle's bar."""
     import diff_gaussian_rasterization as dgr
     from hugs_amd import synthetic as syn
     if binding == "ctypes":
@@ -1210,11 +1219,11 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, size, 
     monkeypatch.delenv("HGS_BWD_TWO_LAUNCHES")
     assert torch.equal(color.detach(), images[True])
     for k in grads[True]:
-        assert rel_l2(t[k].grad.cpu().numpy(), grads[True][k]) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(t[k].grad.cpu().numpy(), grads[True][k]) <= ALT_BACKWARD_TOL, k
     assert torch.equal(images[True], images[False])
     check_image(images[True].cpu().numpy(), ref["color"], "dense frame with deep tiles")
     for k in grads[True]:
-        assert rel_l2(grads[True][k], grads[False][k]) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(grads[True][k], grads[False][k]) <= ALT_BACKWARD_TOL, k
         if k in refg:
             assert rel_l2(grads[True][k].reshape(refg[k].shape), refg[k]) <= GRAD_REL_TOL, k
 
@@ -1243,7 +1252,7 @@ def test_backward_long_after_its_forward_covers_the_slot_layouts_upper_bound(dev
     c1.backward(dL)
     assert torch.equal(c1.detach(), c0.detach())
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(t1[k].grad.cpu().numpy(), t0[k].grad.cpu().numpy()) <= order_tol(k), k
 
 
 @pytest.mark.gpu
@@ -1298,7 +1307,7 @@ def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monke
     frame and as a dense one (a scene behind the stack, long-tile threshold lowered so that its tiles count as long):
     the same sorted lists; images within 1e-6 and n_contrib equal on >= 99.98 % of the pixels (the products are rounded in
     another order: a pixel whose T lands within 1e-7 of 1e-4 may stop one entry earlier or later), both within the oracle's
-    bar; gradients -- through the checkpoints the depth-parallel path leaves for the segmented backward -- within ATOMIC_ORDER_TOL of
+    bar; gradients -- through the checkpoints the depth-parallel path leaves for the segmented backward -- within ALT_BACKWARD_TOL of
     each other and within the oracle's bar."""
     from diff_gaussian_rasterization import _debug_forward_state
     from hugs_amd import synthetic as syn
@@ -1346,7 +1355,7 @@ def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monke
     assert float((a["n_contrib"] == b["n_contrib"]).mean()) >= 0.9998
     assert not np.array_equal(a["color"], b["color"]), "the depth-parallel path did not run"
     for k in a["grads"]:
-        assert rel_l2(a["grads"][k], b["grads"][k]) <= ATOMIC_ORDER_TOL, k
+        assert rel_l2(a["grads"][k], b["grads"][k]) <= ALT_BACKWARD_TOL, k
 
 
 @pytest.mark.gpu

@@ -214,10 +214,16 @@ def test_forward_does_not_depend_on_the_number_of_threads():
     for n in (1, 7):
         ho.set_threads(n)
         out[n] = ho.forward(inp)
+    # a team SMALLER than the number of chunks (what OMP_THREAD_LIMIT / OMP_DYNAMIC / a cgroup cap can hand the sort): no chunk is left out
+    ho.set_threads(3)
+    ho.set_sort_chunks(7)
+    out["3 of 7"] = ho.forward(inp)
+    ho.set_sort_chunks(0)
     ho.set_threads(1)
     assert out[1]["N"] >= 65536
     for k, a in out[1].items():
         assert np.array_equal(np.asarray(a), np.asarray(out[7][k])), k
+        assert np.array_equal(np.asarray(a), np.asarray(out["3 of 7"][k])), k
 
 
 def test_backward_does_not_depend_on_the_number_of_threads():

@@ -34,6 +34,8 @@ def main():
         for mode, flag in (("fwd", ["--forward-only"]), ("fwd_bwd", [])):
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--steps", "300", "--warmup", "40",
                                 "--no-cpu-baseline", "--no-two-streams"] + flag, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise SystemExit(f"bench.py failed for P={P} ({mode}), rc {r.returncode}:\n{r.stderr[-2000:]}")
             d = json.loads(r.stdout.strip().splitlines()[-1])
             row[mode] = {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]}
             row["num_rendered_N"], row["visible"] = d["config"]["num_rendered_N"], d["config"]["visible"]
@@ -43,6 +45,8 @@ def main():
     # (round 4) the trained-scene profile: 200 000 scene + 110 210 human Gaussians, surfaces / heavy-tailed sizes / reset opacities
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--profile", "trained", "--steps", "300", "--warmup", "40",
                         "--no-cpu-baseline", "--no-two-streams"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise SystemExit(f"bench.py --profile trained failed, rc {r.returncode}:\n{r.stderr[-2000:]}")
     d = json.loads(r.stdout.strip().splitlines()[-1])
     out["trained_profile"] = {"fwd_bwd": {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]},
                               "gaussians": d["config"]["gaussians"], "num_rendered_N": d["config"]["num_rendered_N"], "visible": d["config"]["visible"]}

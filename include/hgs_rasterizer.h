@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 10
+#define HGS_ABI_VERSION 11
 
 /* scratch buffer ids passed to the allocation callback */
 enum { HGS_BUF_GEOM = 0, HGS_BUF_BINNING = 1, HGS_BUF_IMAGE = 2, HGS_BUF_CKPT = 3, HGS_NUM_BUFS = 4 };
@@ -204,6 +204,22 @@ typedef struct hgs_backward_args {
     float *seg2_dL_drotations;  /* [P2,4] */
     uint32_t flags;             /* HGS_BWD_* bits */
     uint32_t reserved;
+    /* Optional (all NULL: none): gradients of the FIRST set's Gaussians left by ANOTHER render's backward of the same step -- the
+     * separate human-only render next to the joint one (/root/reference/hugs/renderer/gs_renderer.py:56,69: both differentiate the
+     * same human tensors).  The per-Gaussian kernel adds them to its own before storing, so dL_dopacity .. dL_drotations of the
+     * first set come out as the SUM of the two renders' gradients -- what autograd otherwise forms with one elementwise kernel per
+     * tensor.  Same shapes as the first set's outputs; the other render ran with the same sh_degree.  May not alias the outputs. */
+    const float *add_dL_dopacity;
+    const float *add_dL_dcolors;
+    const float *add_dL_dmeans3D;
+    const float *add_dL_dcov3D;
+    const float *add_dL_dsh;
+    const float *add_dL_dscales;
+    const float *add_dL_drotations;
+    /* Optional hipEvent_t: `stream` waits for it BETWEEN the blend backward and the per-Gaussian kernel (hipStreamWaitEvent) --
+     * the other render's backward, running on another stream, records it when the add_* buffers are complete; the blend
+     * backward, the bulk of this call, does not wait. */
+    void *wait_before_per_gaussian;
 } hgs_backward_args;
 
 /* hgs_backward_args.flags.  dL/dscales is, by default, the true derivative -- it carries settings.scale_modifier, the factor
@@ -394,6 +410,10 @@ size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int
  * "forward_calls" / "forward_ns" (time inside hgs_rasterize_forward) / "forward_wait_ns" (the part of it spent waiting for N),
  * "backward_calls" / "backward_ns".  -1 for an unknown name. */
 int64_t hgs_debug_stat(const char *name);
+
+/* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE)
+ * from the environment once, at its first frame; a test or A/B tool that changes them inside one process calls this afterwards. */
+void hgs_reload_switches(void);
 
 #ifdef __cplusplus
 }

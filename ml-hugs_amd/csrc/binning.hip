@@ -358,10 +358,10 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count,
                       unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
 {
     // (both at most SORT_CAP_SMALL: that is what the one-workgroup-per-tile sort holds)
-    // (read on every call: the tests switch them between frames)
-    auto from_env = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
-    const uint32_t long_min_sparse = from_env("HGS_LONG_MIN_SPARSE", LONG_MIN_SPARSE), long_min_dense = from_env("HGS_LONG_MIN_DENSE", LONG_MIN_DENSE);
-    const uint32_t dense_arg = long_min_dense | (getenv("HGS_LONG_MIN_DENSE") ? 0x80000000u : 0u);
+    const Switches& sw = switches();
+    auto clamped = [](int v, int dflt) { v = v > 0 ? v : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
+    const uint32_t long_min_sparse = clamped(sw.long_min_sparse, LONG_MIN_SPARSE), long_min_dense = clamped(sw.long_min_dense, LONG_MIN_DENSE);
+    const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
                        ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, long_min_sparse, dense_arg);
 }

@@ -475,8 +475,7 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
         // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)
         uint32_t slots = (uint32_t)(num_rendered >> CKPT_SHIFT) + (uint32_t)num_tiles;   // (the sparse layout; a dense frame's upper bound)
         if (!sparse_frame && dense_slots >= 0 && (uint64_t)dense_slots < slots) slots = (uint32_t)dense_slots;
-        const char* two = getenv("HGS_BWD_TWO_LAUNCHES");   // (read per frame: A/B measurements and the equivalence test)
-        const bool two_launches = two && two[0] == '1';
+        const bool two_launches = switches().bwd_two_launches;   // (A/B measurements and the equivalence test)
         if ((sparse_frame || two_launches) && slots)
             hipLaunchKernelGGL(blend_backward_segmented_kernel, dim3(slots), dim3(256), 0, st, cam, (uint32_t)(P - 1), ranges, act,
                                act_stride, splats, bg, final_T, n_contrib, dL_dpix, grad_accum, ck);

@@ -30,6 +30,32 @@ int fail(int code, const char* fmt, ...)
 
 }  // namespace
 
+namespace {
+std::mutex g_sw_mu;
+hgs::Switches g_sw;
+std::atomic<bool> g_sw_loaded{false};
+void load_switches()
+{
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+    hgs::Switches s;
+    const char* e = getenv("HGS_BIN_MODE");
+    s.bin_mode = e && (e[0] == 'c' || e[0] == 'o') ? e[0] : 0;
+    e = getenv("HGS_BWD_TWO_LAUNCHES");
+    s.bwd_two_launches = e && e[0] == '1';
+    e = getenv("HGS_DEEP_FORWARD");
+    s.deep_forward = !(e && e[0] == '0');
+    s.long_min_sparse = num("HGS_LONG_MIN_SPARSE"), s.long_min_dense = num("HGS_LONG_MIN_DENSE");
+    std::lock_guard<std::mutex> lk(g_sw_mu);
+    g_sw = s;
+    g_sw_loaded.store(true, std::memory_order_release);
+}
+}  // namespace
+const hgs::Switches& hgs::switches()
+{
+    if (!g_sw_loaded.load(std::memory_order_acquire)) load_switches();
+    return g_sw;
+}
+
 // for the other translation units (densify.hip, knn.hip): message behind hgs_last_error() on this thread
 void hgs::set_last_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 
@@ -453,6 +479,8 @@ size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
 size_t hgs_ckpt_bytes(int64_t N, int32_t H, int32_t W) { return CkptLayout(N, num_tiles_of(H, W)).total; }
 
+void hgs_reload_switches(void) { load_switches(); }
+
 int64_t hgs_debug_stat(const char* name)
 {
     if (!name) return -1;
@@ -546,8 +574,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_lease)) return rc;
     int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
-    if (const char* e = group ? getenv("HGS_BIN_MODE") : nullptr)
-        bin_mode = (e[0] == 'c' && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : e[0] == 'o' ? BIN_IN_ORDER : bin_mode;
+    if (const int forced = group ? switches().bin_mode : 0)
+        bin_mode = (forced == 'c' && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : forced == 'o' ? BIN_IN_ORDER : bin_mode;
     uint32_t* cell_count = bin_mode == BIN_BY_CELL ? tile_count + cell_counters_at : nullptr;
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
@@ -760,6 +788,13 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
                             f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
                             a.grad_accum, ck, a.state.num_rendered, dense_slots, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
+    if (a.add_dL_dopacity || a.add_dL_dcolors || a.add_dL_dmeans3D || a.add_dL_dcov3D || a.add_dL_dsh || a.add_dL_dscales || a.add_dL_drotations) {
+        if (!a.add_dL_dopacity || !a.add_dL_dcolors || !a.add_dL_dmeans3D || !a.add_dL_dcov3D || !a.add_dL_dscales || !a.add_dL_drotations ||
+            (f.shs && !a.add_dL_dsh))
+            return fail(HGS_ERR_INVALID_ARGUMENT, "add_*: all of the other render's gradient buffers are required");
+        if ((((uintptr_t)a.add_dL_drotations) & 15u) != 0) return fail(HGS_ERR_INVALID_ARGUMENT, "add_dL_drotations must be 16-byte aligned");
+    }
+    if (a.wait_before_per_gaussian) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)a.wait_before_per_gaussian, 0));
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");
     return HGS_OK;

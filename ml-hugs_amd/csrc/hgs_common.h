@@ -193,6 +193,17 @@ struct BinningLayout {
 // kernels / launchers (defined in the .hip files)
 void set_last_error(const char* msg);  // hgs_api.hip
 
+// The A/B switches that launch paths consult, read from the environment ONCE (at the first frame) -- not with a getenv per launch;
+// hgs_reload_switches() (tests, A/B tools that flip them inside one process) reads them again.  hgs_api.hip.
+struct Switches {
+    int bin_mode;               // HGS_BIN_MODE: 0 = the library's choice, 'c' = by cell, 'o' = in order
+    bool bwd_two_launches;      // HGS_BWD_TWO_LAUNCHES=1: dense frames with checkpoints run the two backward forms as two launches
+    bool deep_forward;          // HGS_DEEP_FORWARD=0: long tiles are blended by one wave per quad like any other tile
+    int long_min_sparse;        // HGS_LONG_MIN_SPARSE (0: default)
+    int long_min_dense;         // HGS_LONG_MIN_DENSE  (0: default; set = applies whatever the frame's deepest list)
+};
+const Switches& switches();
+
 // mode = bin_mode_for(): what the kernel does for the binning besides its own work (see preprocess.hip).  `counters`: the
 // per-cell (BIN_BY_CELL) or per-tile (BIN_IN_ORDER) counters, ZERO on entry (hgs_api.hip keeps self-cleaning counter
 // arrays per stream).
@@ -238,7 +249,7 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
 // other tiles (a multiple of 8: the tile -> XCD mapping behind them stays what it is without them).
 inline uint32_t deep_workers_for(int num_tiles) { const uint32_t w = 4u * (uint32_t)num_tiles; return (w < 2048u ? w : 2048u) + 7u & ~7u; }
 // HGS_DEEP_FORWARD=0: long tiles are blended by one wave per quad like any other tile (A/B measurements, parity tests)
-inline bool deep_forward_enabled() { const char* e = getenv("HGS_DEEP_FORWARD"); return !(e && e[0] == '0'); }
+inline bool deep_forward_enabled() { return switches().deep_forward; }
 void launch_blend_forward(const Camera& cam, int P, const uint2* ranges, const uint64_t* act, size_t act_stride,
                           const uint32_t* act_count, const Splat* splats, const float* bg, float* out_color,
                           float* final_T, uint32_t* n_contrib, const uint32_t* n_total, bool clamp_output,

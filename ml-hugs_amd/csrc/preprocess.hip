@@ -147,6 +147,13 @@ struct SecondInputs {
 struct SecondGrads {
     float *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dcov3D;
 };
+// Gradients of the FIRST set's Gaussians from ANOTHER render of the same step (hgs_backward_args.add_*): the kernel adds them
+// to its own before it stores -- the sum autograd would form with one elementwise kernel per tensor.  All NULL: none.
+struct FirstAdds {
+    const float *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dcov3D;
+};
+// (a plain store where nothing is added: v + 0.0f would turn a -0.0f into +0.0f)
+__device__ __forceinline__ float plus(float v, const float* other, size_t idx) { return other ? v + other[idx] : v; }
 
 template <int MODE>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256
 __global__ void __launch_bounds__(MODE != BIN_NONE ? BIN_GROUP : 256)
@@ -386,7 +393,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity_,
                            float* __restrict__ dL_dcolors_, float* __restrict__ dL_dmeans3D_,
                            float* __restrict__ dL_dsh_, float* __restrict__ dL_dscale_, float* __restrict__ dL_drot_,
-                           float* __restrict__ dL_dcov3D_, SecondGrads out2, int coop_mode)
+                           float* __restrict__ dL_dcov3D_, SecondGrads out2, FirstAdds add1, int coop_mode)
 {
     extern __shared__ float sh_stage[];  // [waves][64][3 K + 1]
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,6 +447,14 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     float* dL_drot = second ? out2.dL_drot : dL_drot_;
     float* dL_dcov3D = second ? out2.dL_dcov3D : dL_dcov3D_;
     const int M = second ? in2.M : cam.M;
+    // the other render's gradients of this Gaussian (first set only; NULL: nothing to add)
+    const float* ad_opacity = second ? nullptr : add1.dL_dopacity;
+    const float* ad_colors = second ? nullptr : add1.dL_dcolors;
+    const float* ad_means3D = second ? nullptr : add1.dL_dmeans3D;
+    const float* ad_sh = second ? nullptr : add1.dL_dsh;
+    const float* ad_scale = second ? nullptr : add1.dL_dscale;
+    const float* ad_rot = second ? nullptr : add1.dL_drot;
+    const float* ad_cov3D = second ? nullptr : add1.dL_dcov3D;
     // accumulator record written by the blend-backward atomics, raw moments of u = G dL/dalpha over the pixels:
     //   sum u dx, sum u dy, sum u dx^2, sum u dx dy | sum u dy^2, sum u, dL/dr, dL/dg | dL/db - - -
     // with u = opacity G dL/dalpha (the uncapped alpha times dL/dalpha).  Turned here, once per Gaussian, into
@@ -479,8 +494,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     }
     if (has) {
         dL_dmean2D[3 * (size_t)i] = acc0.x, dL_dmean2D[3 * (size_t)i + 1] = acc0.y, dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
-        dL_dopacity[j] = acc1.y;
-        dL_dcolors[3 * j] = acc1.z, dL_dcolors[3 * j + 1] = acc1.w, dL_dcolors[3 * j + 2] = acc_b;
+        dL_dopacity[j] = plus(acc1.y, ad_opacity, j);
+        dL_dcolors[3 * j] = plus(acc1.z, ad_colors, 3 * j), dL_dcolors[3 * j + 1] = plus(acc1.w, ad_colors, 3 * j + 1);
+        dL_dcolors[3 * j + 2] = plus(acc_b, ad_colors, 3 * j + 2);
     }
 
     const float4 tail = reinterpret_cast<const float4*>(splats + i)[2];
@@ -489,15 +505,15 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     if (has && !live) {
         // every output is fully written by this kernel (the caller does not pre-zero them)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * j + k] = 0.0f, dL_dscale[3 * j + k] = 0.0f;
-        reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * j + k] = plus(0.0f, ad_means3D, 3 * j + k), dL_dscale[3 * j + k] = plus(0.0f, ad_scale, 3 * j + k);
+        reinterpret_cast<float4*>(dL_drot)[j] = ad_rot ? reinterpret_cast<const float4*>(ad_rot)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = 0.0f;
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = plus(0.0f, ad_cov3D, 6 * j + k);
         if (shs && !coop)
-            for (int k = 0; k < 3 * M; ++k) dL_dsh[j * M * 3 + k] = 0.0f;
+            for (int k = 0; k < 3 * M; ++k) dL_dsh[j * M * 3 + k] = k < 3 * Kact ? plus(0.0f, ad_sh, j * M * 3 + k) : 0.0f;
     }
     if (coop && !live)
-        for (int k = 0; k < 3 * Kact; ++k) my_row[k] = 0.0f;
+        for (int k = 0; k < 3 * Kact; ++k) my_row[k] = plus(0.0f, ad_sh, j * M * 3 + k);
     // (no early return: every lane takes part in the wave's row stores at the end)
     auto per_gaussian = [&]() {
     const uint32_t clamped = __float_as_uint(tail.w);
@@ -534,7 +550,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
         dS[4] = 2.0f * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2.0f * e.T11 * e.T12 * dL_dc;
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = dS[k];
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = plus(dS[k], ad_cov3D, 6 * j + k);
 
     // dL/dT (2x3) -> dL/dJ -> dL/dt (view-space mean), with the frustum-clamp masks (A.6 quirk 2)
     float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
@@ -608,6 +624,10 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
             }
             for (int k = 3 * K; k < 3 * M; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
         }
+        if (ad_sh) {   // (the other render ran at the same degree: above it both gradients are zero)
+            float* row = coop ? my_row : dL_dsh + j * M * 3;
+            for (int k = 0; k < 3 * K; ++k) row[k] += ad_sh[j * M * 3 + k];
+        }
         float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
 #define SHW(k) shw[k]
         if (D > 0) {
@@ -650,9 +670,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
         dm1 += (-vx * vy * ddx + (s2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
         dm2 += (-vx * vz * ddx - vy * vz * ddy + (s2 - vz * vz) * ddz) * inv32;
     }
-    dL_dmeans3D[3 * j] = dm0;
-    dL_dmeans3D[3 * j + 1] = dm1;
-    dL_dmeans3D[3 * j + 2] = dm2;
+    dL_dmeans3D[3 * j] = plus(dm0, ad_means3D, 3 * j);
+    dL_dmeans3D[3 * j + 1] = plus(dm1, ad_means3D, 3 * j + 1);
+    dL_dmeans3D[3 * j + 2] = plus(dm2, ad_means3D, 3 * j + 2);
 
     // Sigma3D -> scale, quaternion (quaternion gradient w.r.t. the UN-normalised q)
     if (!cov3D_precomp) {
@@ -678,7 +698,7 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
                 dMc[ii] = 2.0f * acc;
             }
             float ds = R[0][jj] * dMc[0] + R[1][jj] * dMc[1] + R[2][jj] * dMc[2];
-            dL_dscale[3 * j + jj] = cam.scale_grad_factor * ds;
+            dL_dscale[3 * j + jj] = plus(cam.scale_grad_factor * ds, ad_scale, 3 * j + jj);
 #pragma unroll
             for (int ii = 0; ii < 3; ++ii) dR[ii][jj] = s[jj] * dMc[ii];
         }
@@ -690,11 +710,15 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
                        r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
         dq.w = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] +
                        qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        if (ad_rot) {
+            const float4 o = reinterpret_cast<const float4*>(ad_rot)[j];
+            dq.x += o.x, dq.y += o.y, dq.z += o.z, dq.w += o.w;
+        }
         reinterpret_cast<float4*>(dL_drot)[j] = dq;
     } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dscale[3 * j + k] = 0.0f;
-        reinterpret_cast<float4*>(dL_drot)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 3; ++k) dL_dscale[3 * j + k] = plus(0.0f, ad_scale, 3 * j + k);
+        reinterpret_cast<float4*>(dL_drot)[j] = ad_rot ? reinterpret_cast<const float4*>(ad_rot)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     };  // per_gaussian
     if (live) per_gaussian();
@@ -727,6 +751,8 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
                            f.seg2.rotations, f.seg2.cov3D_precomp};
     const SecondGrads out2{a.seg2_dL_dopacity, a.seg2_dL_dcolors, a.seg2_dL_dmeans3D, a.seg2_dL_dsh, a.seg2_dL_dscales,
                            a.seg2_dL_drotations, a.seg2_dL_dcov3D};
+    const FirstAdds add1{a.add_dL_dopacity, a.add_dL_dcolors, a.add_dL_dmeans3D, a.add_dL_dsh, a.add_dL_dscales, a.add_dL_drotations,
+                         a.add_dL_dcov3D};
     static const int forced = [] { const char* e = getenv("HGS_K8_COOP"); return e ? atoi(e) : -1; }();   // measurement override
     // default: the wave STORES the rows; loading them through LDS as well was measured slower at every degree (C2, degree 3:
     // 37.0 us per-thread / 32.0 store only / 39.4 load + store; degree 1: 38.3 / 25.5 / 27.9 -- the round trip through LDS
@@ -736,7 +762,7 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), stage_bytes, st, P, cam, f.means3D, f.shs,
                        f.opacities, f.scales, f.rotations, f.cov3D_precomp, in2, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
                        a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
-                       a.dL_drotations, a.dL_dcov3D, out2, coop_mode);
+                       a.dL_drotations, a.dL_dcov3D, out2, add1, coop_mode);
 }
 
 // K10

@@ -1,42 +1,55 @@
-// The PyTorch binding of the C ABI (include/hgs_rasterizer.h) as a C++ autograd node: what BASELINE.json's north_star calls
-// "a thin C-ABI PyTorch extension".  It does exactly what ml-hugs_amd/diff_gaussian_rasterization/__init__.py's ctypes +
-// Python autograd.Function path does -- same library calls, same scratch and hint policy -- without the interpreter in
-// the per-frame path: on small frames (the 6 890-Gaussian SMPL template at 512x512) the rasterizer's kernels take ~120 us
-// per forward+backward and the Python binding ~290 us of host time.  Host-only code: compiled with g++ against the torch
-// headers (tools are in __graft_entry__.build()); no kernels here, PyTorch supplies device memory, streams and autograd.
+// The PyTorch binding of the C ABI (include/hgs_rasterizer.h): what BASELINE.json's north_star calls "a thin C-ABI PyTorch
+// extension".  Host-only code (g++ against the torch headers, __graft_entry__.build()); no kernels here -- PyTorch supplies
+// device memory, streams and autograd, the library does the work.
 //
-// Mirrors upstream's pybind entry points used at /root/reference/hugs/renderer/gs_renderer.py:144-152 (rasterize_gaussians
-// / rasterize_gaussians_backward behind the module's autograd.Function).
+// Round 5: ONE C++ call per frame.  A frame's host time (Python adapter + torch::autograd::Function plumbing + launches) was of the
+// size of its kernels on the frames HUGS renders most (the human-only render: ~120-150 us of kernels), so the time of a step
+// followed the host -- 0.156-0.213 ms box to box on the same kernels.  Three entry points now share one hand-made autograd node
+// (a torch::autograd::Node, not a torch::autograd::Function: no IValue dictionary, no per-argument wrapping):
+//   rasterize    the module API (GaussianRasterizer.forward, /root/reference/hugs/renderer/gs_renderer.py:144-152)
+//   render       the whole of render() (gs_renderer.py:103-161): viewspace tensor, settings, rasterization, visibility -- one call
+//   render_pair  the joint human+scene render AND the separate human-only render of one training step (gs_renderer.py:56,69) as
+//                ONE node: the human-only frame runs on a library-side stream under the joint frame (forward and backward), its
+//                gradients of the human tensors are added inside the joint frame's per-Gaussian kernel (hgs_backward_args.add_*),
+//                and autograd sees one node on one stream -- no cross-stream AccumulateGrad fences, no elementwise sums.
+// (A HIP graph of the frame's launches was measured first and dropped: tools/microbench/graph_launch.hip, DESIGN_HISTORY.md.)
 #include <torch/extension.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
-#include <vector>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <tuple>
+#include <vector>
 
 #include "hgs_rasterizer.h"
 
 namespace {
 
 using torch::Tensor;
-using torch::autograd::AutogradContext;
+using torch::autograd::SavedVariable;
 using torch::autograd::variable_list;
 
+// ------------------------------------------------------------------------------------------------ per-shape memory
 struct Hint { int64_t n; bool has_long; bool sparse; uint64_t stamp = 0; };
+using ShapeKey = std::tuple<int, int64_t, int64_t, int64_t>;   // (device, P, H, W)
 uint64_t g_hint_clock = 0;
-constexpr size_t HINT_SHAPES = 256;   // shapes remembered; the least recently used go first (round 3 cleared the table at 256)
+constexpr size_t HINT_SHAPES = 256;   // shapes remembered; the least recently used go first
 std::mutex g_mu;
-std::map<std::tuple<int, int64_t, int64_t, int64_t>, Hint> g_hints;   // (device, P, H, W) -> previous frame of this shape
+std::map<ShapeKey, Hint> g_hints;     // previous frame of each shape
 // (caller holds g_mu)
-void remember_hint(const std::tuple<int, int64_t, int64_t, int64_t>& key, Hint h)
+void remember_hint(const ShapeKey& key, Hint h)
 {
     h.stamp = ++g_hint_clock;
     g_hints[key] = h;
     while (g_hints.size() > HINT_SHAPES) {   // densification changes P all the time: drop the least recently used quarter
-        std::vector<std::pair<uint64_t, std::tuple<int, int64_t, int64_t, int64_t>>> by_age;
+        std::vector<std::pair<uint64_t, ShapeKey>> by_age;
         for (auto& kv : g_hints) by_age.push_back({kv.second.stamp, kv.first});
         std::sort(by_age.begin(), by_age.end());
         for (size_t k = 0; k < HINT_SHAPES / 4; ++k) g_hints.erase(by_age[k].second);
@@ -85,6 +98,55 @@ Tensor arena_for(int dev, void* stream, size_t bytes, const at::TensorOptions& b
     return t;
 }
 
+// The gradient sink of render() -- `viewspace_points`, a zero [P,3] leaf that requires grad (gs_renderer.py:107-113) -- without a
+// fill kernel per frame: every frame's tensor is a fresh leaf over the SAME zero-filled storage (one per device, grown on demand).
+// Nothing writes into it: the rasterizer never reads means2D, and autograd refuses in-place operations on a leaf that requires grad.
+std::map<int, Tensor> g_zeros;
+Tensor viewspace_zeros(int64_t rows, const at::TensorOptions& fopts)
+{
+    Tensor base;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        Tensor& z = g_zeros[(int)fopts.device().index()];
+        if (!z.defined() || z.size(0) < rows) z = at::zeros({std::max<int64_t>(rows + rows / 4 + 1024, 4096), 3}, fopts);
+        base = z;
+    }
+    Tensor v = base.narrow(0, 0, rows).detach();
+    v.set_requires_grad(true);
+    return v;
+}
+
+// the library-side stream the second frame of a pair runs on, and two events per host thread to fence it against the caller's
+std::map<int, c10::hip::HIPStream> g_side;
+c10::hip::HIPStream side_stream(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_side.find(dev);
+    if (it == g_side.end()) it = g_side.emplace(dev, c10::hip::getStreamFromPool(/*isHighPriority=*/false, (c10::DeviceIndex)dev)).first;
+    return it->second;
+}
+struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    void make()
+    {
+        if (a) return;
+        TORCH_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess,
+                    "hipEventCreate failed");
+    }
+};
+thread_local std::map<int, Events> t_events;
+Events& events_for(int dev)
+{
+    Events& e = t_events[dev];
+    e.make();
+    return e;
+}
+// `later` does not start before what `earlier` holds now has run
+void fence(hipEvent_t ev, hipStream_t earlier, hipStream_t later)
+{
+    TORCH_CHECK(hipEventRecord(ev, earlier) == hipSuccess && hipStreamWaitEvent(later, ev, 0) == hipSuccess, "stream fence failed");
+}
+
 inline const float* fptr(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 
 inline Tensor f32c(const Tensor& t)
@@ -110,6 +172,7 @@ void raise_last(const char* what) { TORCH_CHECK(false, what, ": ", hgs_last_erro
 // scales, rotations of the first set; then of the second set (hgs_segment) in the same order
 struct GradLayout {
     int64_t off[16], size[16], total;
+    GradLayout() : total(0) {}
     GradLayout(int64_t P, int64_t M, int64_t P2, int64_t M2)
     {
         const int64_t Pt = P + P2;
@@ -132,6 +195,20 @@ void point_at_grads(hgs_backward_args& bw, float* base, const GradLayout& g, int
     bw.seg2_dL_dscales = base + g.off[14], bw.seg2_dL_drotations = base + g.off[15];
 }
 
+// ------------------------------------------------------------------------------------------------ one render's inputs
+// One set of Gaussians as the library takes it (fp32, contiguous; undefined = absent)
+struct Set {
+    Tensor means3D, sh, colors, opac, scales, rot, cov;
+    int64_t P() const { return means3D.defined() ? means3D.size(0) : 0; }
+    int64_t M() const { return sh.defined() && sh.numel() ? sh.size(1) : 0; }
+};
+
+Set make_set(const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales, const Tensor& rot,
+             const Tensor& cov)
+{
+    return Set{f32c(means3D), f32c(sh), f32c(colors), f32c(opac), f32c(scales), f32c(rot), f32c(cov)};
+}
+
 // (the second set goes to the kernels as raw pointers: a tensor on another device, of another dtype or with another row count
 //  than means3D would be read -- or its gradient written -- out of bounds instead of raising)
 void check_segment_tensor(const char* name, const Tensor& t, const Tensor& means3D, int64_t tail, bool three_d = false)
@@ -147,232 +224,301 @@ void check_segment_tensor(const char* name, const Tensor& t, const Tensor& means
     }
 }
 
-void fill_segment(hgs_segment& g, const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac,
-                  const Tensor& scales, const Tensor& rot, const Tensor& cov)
+void fill_segment(hgs_segment& g, const Set& s)
 {
     memset(&g, 0, sizeof g);
-    if (!means3D.defined() || means3D.numel() == 0) return;
-    TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "second: means3D must have dimensions (num_points, 3)");
-    check_segment_tensor("shs", sh, means3D, 0, true);
-    check_segment_tensor("colors_precomp", colors, means3D, 3);
-    check_segment_tensor("opacities", opac, means3D, 1);
-    check_segment_tensor("scales", scales, means3D, 3);
-    check_segment_tensor("rotations", rot, means3D, 4);
-    check_segment_tensor("cov3D_precomp", cov, means3D, 6);
-    g.P = (int32_t)means3D.size(0);
-    g.M = sh.defined() && sh.numel() ? (int32_t)sh.size(1) : 0;
-    g.means3D = fptr(means3D), g.shs = fptr(sh), g.colors_precomp = fptr(colors), g.opacities = fptr(opac);
-    g.scales = fptr(scales), g.rotations = fptr(rot), g.cov3D_precomp = fptr(cov);
+    if (s.P() == 0) return;
+    TORCH_CHECK(s.means3D.dim() == 2 && s.means3D.size(1) == 3, "second: means3D must have dimensions (num_points, 3)");
+    check_segment_tensor("shs", s.sh, s.means3D, 0, true);
+    check_segment_tensor("colors_precomp", s.colors, s.means3D, 3);
+    check_segment_tensor("opacities", s.opac, s.means3D, 1);
+    check_segment_tensor("scales", s.scales, s.means3D, 3);
+    check_segment_tensor("rotations", s.rot, s.means3D, 4);
+    check_segment_tensor("cov3D_precomp", s.cov, s.means3D, 6);
+    g.P = (int32_t)s.P();
+    g.M = (int32_t)s.M();
+    g.means3D = fptr(s.means3D), g.shs = fptr(s.sh), g.colors_precomp = fptr(s.colors), g.opacities = fptr(s.opac);
+    g.scales = fptr(s.scales), g.rotations = fptr(s.rot), g.cov3D_precomp = fptr(s.cov);
 }
 
-void fill_forward(hgs_forward_args& a, const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac,
-                  const Tensor& scales, const Tensor& rot, const Tensor& cov, const Tensor& bg, const Tensor& view,
-                  const Tensor& proj, const Tensor& campos, int64_t H, int64_t W, double tanfovx, double tanfovy, double mod,
-                  int64_t degree, bool prefiltered, bool debug, bool clamp_output)
+struct Settings {
+    Tensor bg, view, proj, campos;   // on the device, fp32, contiguous
+    int64_t H, W, degree;
+    double tanfovx, tanfovy, mod;
+    bool prefiltered, debug, clamp_output, with_visibility;
+};
+
+// One hgs_rasterize_forward / hgs_rasterize_backward pair and everything its backward needs
+struct Frame {
+    hgs_backward_args bw;     // bw.fwd and bw.state are filled by the forward; the gradient pointers aim into `slab`
+    Set a, b;                 // the first and (optional) second set of Gaussians
+    Settings s;
+    Tensor color, radii, visible;
+    Tensor scratch, slab;
+    std::vector<Tensor> keep;   // buffers the allocation callback handed out (an unhinted or under-guessed frame)
+    GradLayout gl;
+    ShapeKey key;
+    bool fresh = true;        // the slab's accumulator was zeroed by this frame's forward and has not been used yet
+    bool deferred = false;
+    Frame() { memset(&bw, 0, sizeof bw); }
+    int64_t P1() const { return a.P(); }
+    int64_t P2() const { return b.P(); }
+};
+
+void fill_forward(Frame& f)
 {
-    memset(&a, 0, sizeof a);
-    a.s.image_height = (int32_t)H, a.s.image_width = (int32_t)W;
-    a.s.tanfovx = (float)tanfovx, a.s.tanfovy = (float)tanfovy;
-    a.s.bg = fptr(bg), a.s.viewmatrix = fptr(view), a.s.projmatrix = fptr(proj), a.s.campos = fptr(campos);
-    a.s.scale_modifier = (float)mod, a.s.sh_degree = (int32_t)degree, a.s.prefiltered = prefiltered, a.s.debug = debug;
-    a.P = (int32_t)means3D.size(0);
-    a.M = sh.defined() && sh.numel() ? (int32_t)sh.size(1) : 0;
-    a.means3D = fptr(means3D), a.shs = fptr(sh), a.colors_precomp = fptr(colors), a.opacities = fptr(opac);
-    a.scales = fptr(scales), a.rotations = fptr(rot), a.cov3D_precomp = fptr(cov);
-    a.clamp_output = clamp_output ? 1 : 0;
+    hgs_forward_args& a = f.bw.fwd;
+    const Settings& s = f.s;
+    a.s.image_height = (int32_t)s.H, a.s.image_width = (int32_t)s.W;
+    a.s.tanfovx = (float)s.tanfovx, a.s.tanfovy = (float)s.tanfovy;
+    a.s.bg = fptr(s.bg), a.s.viewmatrix = fptr(s.view), a.s.projmatrix = fptr(s.proj), a.s.campos = fptr(s.campos);
+    a.s.scale_modifier = (float)s.mod, a.s.sh_degree = (int32_t)s.degree, a.s.prefiltered = s.prefiltered, a.s.debug = s.debug;
+    a.P = (int32_t)f.a.P();
+    a.M = (int32_t)f.a.M();
+    a.means3D = fptr(f.a.means3D), a.shs = fptr(f.a.sh), a.colors_precomp = fptr(f.a.colors), a.opacities = fptr(f.a.opac);
+    a.scales = fptr(f.a.scales), a.rotations = fptr(f.a.rot), a.cov3D_precomp = fptr(f.a.cov);
+    a.clamp_output = s.clamp_output ? 1 : 0;
+    fill_segment(a.seg2, f.b);
 }
 
-class Rasterize : public torch::autograd::Function<Rasterize> {
-public:
-    static variable_list forward(AutogradContext* ctx, Tensor means3D_, Tensor means2D, Tensor sh_, Tensor colors_,
-                                 Tensor opac_, Tensor scales_, Tensor rot_, Tensor cov_, Tensor bg_, Tensor view_,
-                                 Tensor proj_, Tensor campos_, int64_t H, int64_t W, double tanfovx, double tanfovy,
-                                 double mod, int64_t degree, bool prefiltered, bool debug, bool clamp_output, bool needs_grad,
-                                 Tensor means3D_b_, Tensor sh_b_, Tensor colors_b_, Tensor opac_b_, Tensor scales_b_, Tensor rot_b_,
-                                 Tensor cov_b_, bool with_visibility)
+// Allocate the frame's outputs and scratch, enqueue its forward on `stream`.  `defer`: do not wait for N when the shape has a
+// history (finish_frame() must follow).  Returns with f.bw.state filled (num_rendered = -1 for a deferred frame).
+void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer)
+{
+    const auto dev = f.a.means3D.device();
+    const int64_t P1 = f.P1(), P2 = f.P2(), P = P1 + P2, H = f.s.H, W = f.s.W;
+    TORCH_CHECK(P2 == 0 || P1 > 0, "a second set of Gaussians needs a non-empty first one");
+    TORCH_CHECK(P2 == 0 || f.b.means3D.device() == dev, "second: means3D is on ", f.b.means3D.device(), ", the first set of Gaussians on ", dev);
+    TORCH_CHECK(P2 == 0 || (f.b.means3D.dim() == 2 && f.b.means3D.size(1) == 3), "means3D must have dimensions (num_points, 3)");
+    const auto fopts = at::TensorOptions().dtype(at::kFloat).device(dev);
+    const auto bopts = at::TensorOptions().dtype(at::kByte).device(dev);
+    f.color = P == 0 ? at::zeros({3, H, W}, fopts) : at::empty({3, H, W}, fopts);
+    f.radii = at::empty({P}, fopts.dtype(at::kInt));
+    if (f.s.with_visibility) f.visible = at::empty({P}, fopts.dtype(at::kBool));   // `radii > 0`, written with radii
+    fill_forward(f);
+    hgs_forward_args& a = f.bw.fwd;
+    a.out_color = f.color.data_ptr<float>(), a.radii = P ? f.radii.data_ptr<int32_t>() : nullptr;
+    a.visible = (f.s.with_visibility && P) ? (uint8_t*)f.visible.data_ptr<bool>() : nullptr;
+    const int64_t M = a.M, M2 = a.seg2.M;
+    if (needs_grad && P > 0) {
+        f.gl = GradLayout(P1, M, P2, M2);
+        f.slab = at::empty({f.gl.total}, fopts);
+        point_at_grads(f.bw, f.slab.data_ptr<float>(), f.gl, M, M2);
+        a.grad_accum_to_zero = f.bw.grad_accum;
+    }
+    f.key = std::make_tuple((int)dev.index(), P, H, W);
     {
-        TORCH_CHECK(means3D_.is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
-        const auto dev = means3D_.device();
-        Tensor means3D = means3D_.numel() ? f32c(means3D_) : means3D_.to(at::kFloat).reshape({0, 3});
-        TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
-        Tensor sh = f32c(sh_), colors = f32c(colors_), opac = f32c(opac_), scales = f32c(scales_), rot = f32c(rot_), cov = f32c(cov_);
-        auto on_dev = [&](const Tensor& t) { return f32c(t.device() == dev ? t : t.to(dev)); };
-        Tensor bg = on_dev(bg_), view = on_dev(view_), proj = on_dev(proj_), campos = on_dev(campos_);
-        // the optional second set of Gaussians (hgs_segment): rendered behind the first in index order, nothing concatenated
-        Tensor means3D_b = f32c(means3D_b_), sh_b = f32c(sh_b_), colors_b = f32c(colors_b_), opac_b = f32c(opac_b_),
-               scales_b = f32c(scales_b_), rot_b = f32c(rot_b_), cov_b = f32c(cov_b_);
-        const int64_t P1 = means3D.size(0), P2 = means3D_b.defined() ? means3D_b.size(0) : 0;
-        TORCH_CHECK(P2 == 0 || P1 > 0, "a second set of Gaussians needs a non-empty first one");
-        TORCH_CHECK(P2 == 0 || means3D_b.device() == dev, "second: means3D is on ", means3D_b.device(), ", the first set of Gaussians on ", dev);
-        TORCH_CHECK(P2 == 0 || (means3D_b.dim() == 2 && means3D_b.size(1) == 3), "means3D must have dimensions (num_points, 3)");
-        const int64_t P = P1 + P2;
-        const auto fopts = at::TensorOptions().dtype(at::kFloat).device(dev);
-        const auto bopts = at::TensorOptions().dtype(at::kByte).device(dev);
-        Tensor color = P == 0 ? at::zeros({3, H, W}, fopts) : at::empty({3, H, W}, fopts);
-        Tensor radii = at::empty({P}, fopts.dtype(at::kInt));
-        Tensor visible = with_visibility ? at::empty({P}, fopts.dtype(at::kBool)) : Tensor();   // `radii > 0`, written with radii
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_hints.find(f.key);
+        if (it != g_hints.end()) it->second.stamp = ++g_hint_clock;   // (used: not the next one to go)
+        // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
+        a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse || it->second.has_long)) ? 1 : 0;
+        if (g_use_hint && it != g_hints.end()) {
+            a.binning_capacity_hint = round_capacity(it->second.n);
+            a.expect_no_long_tiles = it->second.has_long ? 0 : 1;
+        }
+    }
+    f.deferred = defer && a.binning_capacity_hint > 0 && P > 0;
+    a.defer_n = f.deferred ? 1 : 0;
+    if (P > 0) {
+        // pre-sized scratch, no allocation callbacks: geom | image | binning(hint) [| checkpoints(hint)]
+        const size_t g = align256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), im = align256(hgs_image_bytes((int32_t)H, (int32_t)W));
+        const size_t b = a.binning_capacity_hint > 0 ? align256(hgs_binning_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
+        const size_t ck = b && a.backward_checkpoints ? align256(hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
+        // per frame when backward will need it, else the stream's arena
+        f.scratch = needs_grad ? at::empty({(int64_t)(g + im + b + ck)}, bopts) : arena_for((int)dev.index(), (void*)stream, g + im + b + ck, bopts);
+        char* base = (char*)f.scratch.data_ptr();
+        a.scratch[HGS_BUF_GEOM] = base, a.scratch_bytes[HGS_BUF_GEOM] = g;
+        a.scratch[HGS_BUF_IMAGE] = base + g, a.scratch_bytes[HGS_BUF_IMAGE] = im;
+        if (b) a.scratch[HGS_BUF_BINNING] = base + g + im, a.scratch_bytes[HGS_BUF_BINNING] = b;
+        if (ck) a.scratch[HGS_BUF_CKPT] = base + g + im + b, a.scratch_bytes[HGS_BUF_CKPT] = ck;
+    }
+    AllocCtx actx{&f.keep, bopts};
+    const int64_t n = hgs_rasterize_forward(&a, alloc_cb, &actx, &f.bw.state, (void*)stream);
+    if (n < 0) raise_last("rasterize_gaussians");
+}
 
-        hgs_backward_args bw;
-        memset(&bw, 0, sizeof bw);
-        hgs_forward_args& a = bw.fwd;
-        fill_forward(a, means3D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, tanfovx, tanfovy, mod, degree,
-                     prefiltered, debug, clamp_output);
-        fill_segment(a.seg2, means3D_b, sh_b, colors_b, opac_b, scales_b, rot_b, cov_b);
-        a.out_color = color.data_ptr<float>(), a.radii = P ? radii.data_ptr<int32_t>() : nullptr;
-        a.visible = (with_visibility && P) ? (uint8_t*)visible.data_ptr<bool>() : nullptr;
-        const int64_t M = a.M, M2 = a.seg2.M;
-        // (needs_grad is decided by the caller: grad mode is off inside forward())
-        Tensor slab;
-        if (needs_grad && P > 0) {
-            GradLayout g(P1, M, P2, M2);
-            slab = at::empty({g.total}, fopts);
-            point_at_grads(bw, slab.data_ptr<float>(), g, M, M2);
-            a.grad_accum_to_zero = bw.grad_accum;
+// N of the frame (a deferred frame is waited for now -- its scan ran long ago -- and run again, waiting, if it did not fit its
+// binning buffer), the shape's record, this thread's "last frame"
+void finish_frame(Frame& f, hipStream_t stream)
+{
+    hgs_forward_args& a = f.bw.fwd;
+    int64_t n = f.bw.state.num_rendered;
+    if (f.deferred) {
+        n = hgs_forward_poll(&f.bw.state, 1, (void*)stream);
+        if (n == HGS_ERR_OVERFLOW || n == HGS_ERR_EXPIRED) {
+            TORCH_CHECK(std::string(hgs_last_error()).find("2^32") == std::string::npos, "rasterize_gaussians: ", hgs_last_error());
+            a.defer_n = 0, a.binning_capacity_hint = 0, a.scratch[HGS_BUF_BINNING] = nullptr, a.scratch[HGS_BUF_CKPT] = nullptr;
+            AllocCtx actx{&f.keep, at::TensorOptions().dtype(at::kByte).device(f.a.means3D.device())};
+            n = hgs_rasterize_forward(&a, alloc_cb, &actx, &f.bw.state, (void*)stream);
         }
-        const auto key = std::make_tuple((int)dev.index(), P, H, W);
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            auto it = g_hints.find(key);
-            if (it != g_hints.end()) it->second.stamp = ++g_hint_clock;   // (used: not the next one to go)
-            // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
-            a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse || it->second.has_long)) ? 1 : 0;
-            if (g_use_hint && it != g_hints.end()) {
-                a.binning_capacity_hint = round_capacity(it->second.n);
-                a.expect_no_long_tiles = it->second.has_long ? 0 : 1;
-            }
-        }
-        std::vector<Tensor> keep;
-        AllocCtx actx{&keep, bopts};
-        Tensor scratch;
-        if (P > 0) {
-            // pre-sized scratch, no allocation callbacks: geom | image | binning(hint) [| checkpoints(hint)]
-            const size_t g = align256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), im = align256(hgs_image_bytes((int32_t)H, (int32_t)W));
-            const size_t b = a.binning_capacity_hint > 0 ? align256(hgs_binning_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
-            const size_t ck = b && a.backward_checkpoints ? align256(hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
-            // per frame when backward will need it, else the stream's arena
-            scratch = needs_grad ? at::empty({(int64_t)(g + im + b + ck)}, bopts)
-                                 : arena_for((int)dev.index(), (void*)c10::hip::getCurrentHIPStream(dev.index()).stream(), g + im + b + ck, bopts);
-            char* base = (char*)scratch.data_ptr();
-            a.scratch[HGS_BUF_GEOM] = base, a.scratch_bytes[HGS_BUF_GEOM] = g;
-            a.scratch[HGS_BUF_IMAGE] = base + g, a.scratch_bytes[HGS_BUF_IMAGE] = im;
-            if (b) a.scratch[HGS_BUF_BINNING] = base + g + im, a.scratch_bytes[HGS_BUF_BINNING] = b;
-            if (ck) a.scratch[HGS_BUF_CKPT] = base + g + im + b, a.scratch_bytes[HGS_BUF_CKPT] = ck;
-        }
-        int64_t n;
-        {
-            c10::DeviceGuard guard(dev);
-            n = hgs_rasterize_forward(&a, alloc_cb, &actx, &bw.state, (void*)c10::hip::getCurrentHIPStream(dev.index()).stream());
-        }
-        if (n < 0) raise_last("rasterize_gaussians");
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            remember_hint(key, Hint{n, bw.state.has_long_tiles != 0, bw.state.sparse_frame != 0});
-        }
-        t_last_n = n, t_last_capacity = bw.state.binning_capacity;
-        t_last_long = bw.state.has_long_tiles != 0, t_last_sparse = bw.state.sparse_frame != 0;
+        if (n < 0) raise_last("rasterize_gaussians (deferred frame)");
+        f.deferred = false;
+    }
+    if (f.P1() + f.P2() == 0) n = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        remember_hint(f.key, Hint{n, f.bw.state.has_long_tiles != 0, f.bw.state.sparse_frame != 0});
+    }
+    t_last_n = n, t_last_capacity = f.bw.state.binning_capacity;
+    t_last_long = f.bw.state.has_long_tiles != 0, t_last_sparse = f.bw.state.sparse_frame != 0;
+}
 
-        if (with_visibility) ctx->mark_non_differentiable({radii, visible});
-        else ctx->mark_non_differentiable({radii});
-        if (needs_grad) {
-            ctx->set_materialize_grads(false);
-            ctx->save_for_backward({means3D, sh.defined() ? sh : Tensor(), colors.defined() ? colors : Tensor(),
-                                    opac.defined() ? opac : Tensor(), scales.defined() ? scales : Tensor(),
-                                    rot.defined() ? rot : Tensor(), cov.defined() ? cov : Tensor(), radii, bg, view, proj, campos,
-                                    scratch, slab, means3D_b.defined() ? means3D_b : Tensor(), sh_b.defined() ? sh_b : Tensor(),
-                                    colors_b.defined() ? colors_b : Tensor(), opac_b.defined() ? opac_b : Tensor(),
-                                    scales_b.defined() ? scales_b : Tensor(), rot_b.defined() ? rot_b : Tensor(),
-                                    cov_b.defined() ? cov_b : Tensor()});
-            // (buffers the allocation callback handed out -- the binning / checkpoint buffers of an unhinted or under-guessed
-            // frame -- stay alive with the node)
-            for (const Tensor& t : keep) ctx->saved_data["keep" + std::to_string(&t - keep.data())] = t;
-            ctx->saved_data["H"] = H, ctx->saved_data["W"] = W, ctx->saved_data["tx"] = tanfovx, ctx->saved_data["ty"] = tanfovy;
-            ctx->saved_data["mod"] = mod, ctx->saved_data["D"] = degree, ctx->saved_data["flags"] = (int64_t)((prefiltered ? 1 : 0) | (debug ? 2 : 0) | (clamp_output ? 4 : 0));
-            ctx->saved_data["N"] = n, ctx->saved_data["cap"] = bw.state.binning_capacity;
-            ctx->saved_data["sparse"] = (int64_t)bw.state.sparse_frame, ctx->saved_data["long"] = (int64_t)bw.state.has_long_tiles;
-            ctx->saved_data["geom"] = (int64_t)(uintptr_t)bw.state.geom, ctx->saved_data["geom_b"] = (int64_t)bw.state.geom_bytes;
-            ctx->saved_data["bin"] = (int64_t)(uintptr_t)bw.state.binning, ctx->saved_data["bin_b"] = (int64_t)bw.state.binning_bytes;
-            ctx->saved_data["img"] = (int64_t)(uintptr_t)bw.state.image, ctx->saved_data["img_b"] = (int64_t)bw.state.image_bytes;
-            ctx->saved_data["ck"] = (int64_t)(uintptr_t)bw.state.ckpt, ctx->saved_data["ck_b"] = (int64_t)bw.state.ckpt_bytes;
-            ctx->saved_data["fresh"] = true;
+// ------------------------------------------------------------------------------------------------ the autograd node
+// Inputs (= next edges), in this order: means3D, means2D, sh, colors, opacities, scales, rotations, cov3D of the first set, then
+// means3D, sh, colors, opacities, scales, rotations, cov3D of the second.  Outputs: the image of frame 0 [, the image of frame 1].
+// Frame 1, when present, renders the FIRST set alone (the human-only render next to the joint one).
+struct RasterNode : public torch::autograd::Node {
+    Frame f[2];
+    int nframes = 1;
+    bool released = false;
+    std::vector<SavedVariable> saved;   // the differentiable inputs: unpacking them runs autograd's in-place-modification check
+
+    std::string name() const override { return "HgsRasterizeBackward"; }
+
+    void release_variables() override
+    {
+        std::lock_guard<std::mutex> lk(mutex_);
+        released = true;
+        saved.clear();
+        for (Frame& fr : f) {
+            fr.a = Set{}, fr.b = Set{};
+            fr.scratch = Tensor(), fr.slab = Tensor(), fr.keep.clear();
         }
-        if (with_visibility) return {color, radii, visible};
-        return {color, radii};
     }
 
-    static variable_list backward(AutogradContext* ctx, variable_list grads)
+    // one frame's backward on `stream`; `add_from`: the frame whose first-set gradients are added in (ready once `wait` has fired)
+    void run_backward(Frame& fr, const Tensor& g_color, hipStream_t stream, const Frame* add_from, hipEvent_t wait)
     {
-        variable_list out(30);
-        const Tensor& g_color = grads[0];
-        if (!g_color.defined()) return out;   // colour did not take part in the loss
-        const auto sv = ctx->get_saved_variables();
-        if (sv.empty()) return out;
-        const Tensor &means3D = sv[0], &sh = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rot = sv[5], &cov = sv[6],
-                     &radii = sv[7], &bg = sv[8], &view = sv[9], &proj = sv[10], &campos = sv[11];
-        Tensor slab = sv[13];
-        const Tensor &means3D_b = sv[14], &sh_b = sv[15], &colors_b = sv[16], &opac_b = sv[17], &scales_b = sv[18], &rot_b = sv[19],
-                     &cov_b = sv[20];
-        const int64_t P1 = means3D.size(0), P2 = means3D_b.defined() ? means3D_b.size(0) : 0;
-        const int64_t P = P1 + P2, H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+        hgs_backward_args& bw = fr.bw;
+        const int64_t M = bw.fwd.M, M2 = bw.fwd.seg2.M;
+        if (!fr.fresh) {   // a second backward (retain_graph): a fresh slab with a zeroed accumulator
+            fr.slab = at::empty({fr.gl.total}, fr.a.means3D.options());
+            fr.slab.narrow(0, 0, std::max<int64_t>(fr.gl.off[1], 1)).zero_();
+            point_at_grads(bw, fr.slab.data_ptr<float>(), fr.gl, M, M2);
+        }
+        fr.fresh = false;
+        bw.dL_dout_color = g_color.data_ptr<float>();
+        bw.flags = g_upstream_scale_grad ? HGS_BWD_UPSTREAM_SCALE_GRAD : 0u;
+        bw.add_dL_dopacity = bw.add_dL_dcolors = bw.add_dL_dmeans3D = bw.add_dL_dcov3D = bw.add_dL_dsh = bw.add_dL_dscales = bw.add_dL_drotations = nullptr;
+        bw.wait_before_per_gaussian = nullptr;
+        if (add_from) {
+            const hgs_backward_args& o = add_from->bw;
+            bw.add_dL_dopacity = o.dL_dopacity, bw.add_dL_dcolors = o.dL_dcolors, bw.add_dL_dmeans3D = o.dL_dmeans3D, bw.add_dL_dcov3D = o.dL_dcov3D;
+            bw.add_dL_dsh = o.dL_dsh, bw.add_dL_dscales = o.dL_dscales, bw.add_dL_drotations = o.dL_drotations;
+            bw.wait_before_per_gaussian = (void*)wait;
+        }
+        if (hgs_rasterize_backward(&bw, (void*)stream) < 0) raise_last("rasterize_gaussians_backward");
+    }
+
+    variable_list apply(variable_list&& grads) override
+    {
+        std::lock_guard<std::mutex> lk(mutex_);
+        variable_list out(15);
+        TORCH_CHECK(!released, "Trying to backward through the rasterizer a second time (or after its buffers have been freed). "
+                               "Specify retain_graph=True if you need to backward through the graph a second time.");
+        for (auto& sv : saved) (void)sv.unpack(shared_from_this());   // raises if an input was modified in place since the forward
+        Frame& J = f[0];
+        const int64_t P1 = J.P1(), P2 = J.P2(), P = P1 + P2;
+        const bool g0 = grads.size() > 0 && grads[0].defined(), g1 = nframes > 1 && grads.size() > 1 && grads[1].defined();
+        if (!g0 && !g1) return out;   // the images did not take part in the loss
         if (P == 0) {   // nothing was rendered (so there is no second set either): empty gradients of the inputs' shapes
-            out[0] = at::zeros_like(means3D), out[1] = at::zeros_like(means3D);
-            for (int k = 1; k <= 6; ++k)
-                if (sv[k].defined()) out[k + 1] = at::zeros_like(sv[k]);
+            out[0] = at::zeros_like(J.a.means3D), out[1] = at::zeros_like(J.a.means3D);
+            const Tensor* firsts[6] = {&J.a.sh, &J.a.colors, &J.a.opac, &J.a.scales, &J.a.rot, &J.a.cov};
+            for (int k = 0; k < 6; ++k)
+                if (firsts[k]->defined()) out[k + 2] = at::zeros_like(*firsts[k]);
             return out;
         }
-        const int64_t flags = ctx->saved_data["flags"].toInt();
-        hgs_backward_args bw;
-        memset(&bw, 0, sizeof bw);
-        fill_forward(bw.fwd, means3D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, ctx->saved_data["tx"].toDouble(),
-                     ctx->saved_data["ty"].toDouble(), ctx->saved_data["mod"].toDouble(), ctx->saved_data["D"].toInt(), flags & 1, flags & 2,
-                     flags & 4);
-        fill_segment(bw.fwd.seg2, means3D_b, sh_b, colors_b, opac_b, scales_b, rot_b, cov_b);
-        bw.fwd.radii = radii.data_ptr<int32_t>();
-        const int64_t M = bw.fwd.M, M2 = bw.fwd.seg2.M;
-        bw.state.geom = (void*)(uintptr_t)ctx->saved_data["geom"].toInt(), bw.state.geom_bytes = (size_t)ctx->saved_data["geom_b"].toInt();
-        bw.state.binning = (void*)(uintptr_t)ctx->saved_data["bin"].toInt(), bw.state.binning_bytes = (size_t)ctx->saved_data["bin_b"].toInt();
-        bw.state.image = (void*)(uintptr_t)ctx->saved_data["img"].toInt(), bw.state.image_bytes = (size_t)ctx->saved_data["img_b"].toInt();
-        bw.state.ckpt = (void*)(uintptr_t)ctx->saved_data["ck"].toInt(), bw.state.ckpt_bytes = (size_t)ctx->saved_data["ck_b"].toInt();
-        bw.state.num_rendered = ctx->saved_data["N"].toInt(), bw.state.binning_capacity = ctx->saved_data["cap"].toInt();
-        bw.state.sparse_frame = (int32_t)ctx->saved_data["sparse"].toInt(), bw.state.has_long_tiles = (int32_t)ctx->saved_data["long"].toInt();
-        GradLayout gl(P1, M, P2, M2);
-        const auto dev = means3D.device();
-        if (!ctx->saved_data["fresh"].toBool()) {   // a second backward (retain_graph): a fresh, zeroed slab
-            slab = at::empty({gl.total}, means3D.options());
-            slab.narrow(0, 0, std::max<int64_t>(gl.off[1], 1)).zero_();
+        at::AutoGradMode no_grad(false);
+        const auto dev = J.a.means3D.device();
+        c10::DeviceGuard guard(dev);
+        const hipStream_t main = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        Frame* src = &J;   // whose slab the first set's (and the joint viewspace) gradients are returned from
+        if (g0 && g1) {
+            // the human-only frame on the side stream under the joint frame's blend backward; its gradients of the human tensors
+            // are added by the joint frame's per-Gaussian kernel, which alone waits for them
+            Tensor ga = f32c(grads[0]), gb = f32c(grads[1]);
+            Events& ev = events_for((int)dev.index());
+            const hipStream_t side = side_stream((int)dev.index()).stream();
+            fence(ev.a, main, side);                       // dL/dimage was produced on the caller's stream
+            run_backward(f[1], gb, side, nullptr, nullptr);
+            TORCH_CHECK(hipEventRecord(ev.b, side) == hipSuccess, "hipEventRecord failed");
+            run_backward(J, ga, main, &f[1], ev.b);        // (main has waited for the side stream when this returns)
+        } else if (g0) {
+            run_backward(J, f32c(grads[0]), main, nullptr, nullptr);
+        } else {
+            run_backward(f[1], f32c(grads[1]), main, nullptr, nullptr);
+            src = &f[1];
         }
-        ctx->saved_data["fresh"] = false;
-        point_at_grads(bw, slab.data_ptr<float>(), gl, M, M2);
-        Tensor g = f32c(g_color);
-        bw.dL_dout_color = g.data_ptr<float>();
-        bw.flags = g_upstream_scale_grad ? HGS_BWD_UPSTREAM_SCALE_GRAD : 0u;
-        int32_t rc;
-        {
-            c10::DeviceGuard guard(dev);
-            rc = hgs_rasterize_backward(&bw, (void*)c10::hip::getCurrentHIPStream(dev.index()).stream());
-        }
-        if (rc < 0) raise_last("rasterize_gaussians_backward");
+        const hgs_backward_args& bw = src->bw;
+        const GradLayout& gl = src->gl;
+        const Tensor& slab = src->slab;
+        const int64_t M = bw.fwd.M;
         auto view_of = [&](int k, at::IntArrayRef shape) { return slab.narrow(0, gl.off[k], gl.size[k]).view(shape); };
-        out[0] = view_of(4, {P1, 3});                                 // means3D
-        out[1] = view_of(1, {P, 3});                                  // means2D (the viewspace gradient sink, both sets)
-        if (sh.defined() && sh.numel()) out[2] = view_of(6, {P1, M, 3});
-        if (colors.defined() && colors.numel()) out[3] = view_of(3, {P1, 3});
+        const Set& a = src->a;
+        out[0] = view_of(4, {P1, 3});                                                // means3D
+        if (src == &J) out[1] = view_of(1, {P, 3});                                  // means2D (the viewspace gradient sink, both sets)
+        if (a.sh.defined()) out[2] = view_of(6, {P1, M, 3});
+        if (a.colors.defined()) out[3] = view_of(3, {P1, 3});
         out[4] = view_of(2, {P1, 1});
-        if (scales.defined() && scales.numel()) out[5] = view_of(7, {P1, 3});
-        if (rot.defined() && rot.numel()) out[6] = view_of(8, {P1, 4});
-        if (cov.defined() && cov.numel()) out[7] = view_of(5, {P1, 6});
-        if (P2 > 0) {   // the second set's gradients, written in place by the library
-            out[22] = view_of(11, {P2, 3});
-            if (sh_b.defined() && sh_b.numel()) out[23] = view_of(13, {P2, M2, 3});
-            if (colors_b.defined() && colors_b.numel()) out[24] = view_of(10, {P2, 3});
-            out[25] = view_of(9, {P2, 1});
-            if (scales_b.defined() && scales_b.numel()) out[26] = view_of(14, {P2, 3});
-            if (rot_b.defined() && rot_b.numel()) out[27] = view_of(15, {P2, 4});
-            if (cov_b.defined() && cov_b.numel()) out[28] = view_of(12, {P2, 6});
+        if (a.scales.defined()) out[5] = view_of(7, {P1, 3});
+        if (a.rot.defined()) out[6] = view_of(8, {P1, 4});
+        if (a.cov.defined()) out[7] = view_of(5, {P1, 6});
+        if (P2 > 0 && src == &J) {   // the second set's gradients, written in place by the library
+            const Set& b = J.b;
+            const int64_t M2 = bw.fwd.seg2.M;
+            out[8] = view_of(11, {P2, 3});
+            if (b.sh.defined()) out[9] = view_of(13, {P2, M2, 3});
+            if (b.colors.defined()) out[10] = view_of(10, {P2, 3});
+            out[11] = view_of(9, {P2, 1});
+            if (b.scales.defined()) out[12] = view_of(14, {P2, 3});
+            if (b.rot.defined()) out[13] = view_of(15, {P2, 4});
+            if (b.cov.defined()) out[14] = view_of(12, {P2, 6});
         }
         return out;
     }
 };
 
+bool any_requires_grad(std::initializer_list<const Tensor*> ts)
+{
+    if (!at::GradMode::is_enabled()) return false;
+    for (const Tensor* t : ts)
+        if (t->defined() && t->requires_grad()) return true;
+    return false;
+}
+
+Settings make_settings(const Tensor& means3D, const Tensor& bg, const Tensor& view, const Tensor& proj, const Tensor& campos, int64_t H, int64_t W,
+                       double tanfovx, double tanfovy, double mod, int64_t degree, bool prefiltered, bool debug, bool clamp_output, bool with_visibility)
+{
+    const auto dev = means3D.device();
+    auto on_dev = [&](const Tensor& t) { return f32c(t.device() == dev ? t : t.to(dev)); };
+    return Settings{on_dev(bg), on_dev(view), on_dev(proj), on_dev(campos), H, W, degree, tanfovx, tanfovy, mod, prefiltered, debug, clamp_output, with_visibility};
+}
+
+// Attach the node: edges to the inputs' gradient functions, the saved inputs, the images as its outputs
+void attach(const std::shared_ptr<RasterNode>& node, const Tensor (&inputs)[15])
+{
+    torch::autograd::edge_list edges;
+    edges.reserve(15);
+    for (const Tensor& t : inputs) {
+        if (t.defined() && t.requires_grad()) {
+            edges.push_back(torch::autograd::impl::gradient_edge(t));
+            node->saved.emplace_back(t, false);
+        } else {
+            edges.emplace_back();
+        }
+    }
+    node->set_next_edges(std::move(edges));
+    for (int k = 0; k < node->nframes; ++k) {
+        torch::autograd::create_gradient_edge(node->f[k].color, node);
+        // (the image now owns the node: the node must not own the image -- a reference cycle would keep both, and the frame's
+        //  scratch, alive for ever.  radii / visible stay: the backward reads radii, and they do not point back at the node.)
+        node->f[k].color = Tensor();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ entry points
+// The module API: GaussianRasterizer.forward's arguments, upstream's two return values [+ the visibility filter]
 std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot,
                               Tensor cov, Tensor bg, Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W,
                               double tanfovx, double tanfovy, double mod, int64_t degree, bool prefiltered, bool debug,
@@ -380,18 +526,104 @@ std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor 
 {
     // `second`: nothing, or the second set's (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
     TORCH_CHECK(second.empty() || second.size() == 7, "the second set of Gaussians is a list of seven tensors");
-    if (second.empty()) second.assign(7, at::empty({0}, means3D.options()));
-    bool needs_grad = false;
-    if (at::GradMode::is_enabled()) {
-        for (const Tensor* t : {&means3D, &means2D, &sh, &colors, &opac, &scales, &rot, &cov})
-            needs_grad = needs_grad || (t->defined() && t->requires_grad());
-        for (const Tensor& t : second) needs_grad = needs_grad || (t.defined() && t.requires_grad());
+    TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
+    if (second.empty()) second.assign(7, Tensor());
+    const bool needs_grad = any_requires_grad({&means3D, &means2D, &sh, &colors, &opac, &scales, &rot, &cov, &second[0], &second[1], &second[2],
+                                               &second[3], &second[4], &second[5], &second[6]});
+    auto node = std::shared_ptr<RasterNode>(new RasterNode(), torch::autograd::deleteNode);
+    Frame& f = node->f[0];
+    {
+        at::AutoGradMode no_grad(false);
+        const auto dev = means3D.device();
+        c10::DeviceGuard guard(dev);
+        f.a = make_set(means3D, sh, colors, opac, scales, rot, cov);
+        if (!f.a.means3D.defined()) f.a.means3D = means3D.to(at::kFloat).reshape({0, 3});
+        TORCH_CHECK(f.a.means3D.dim() == 2 && f.a.means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+        f.b = make_set(second[0], second[1], second[2], second[3], second[4], second[5], second[6]);
+        f.s = make_settings(means3D, bg, view, proj, campos, H, W, tanfovx, tanfovy, mod, degree, prefiltered, debug, clamp_output, with_visibility);
+        const hipStream_t st = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        start_frame(f, needs_grad, st, false);
+        finish_frame(f, st);
     }
-    auto r = Rasterize::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, bg, view, proj, campos, H, W, tanfovx, tanfovy,
-                              mod, degree, prefiltered, debug, clamp_output, needs_grad, second[0], second[1], second[2], second[3],
-                              second[4], second[5], second[6], with_visibility);
-    if (with_visibility) return {r[0], r[1], r[2]};
-    return {r[0], r[1]};
+    Tensor color = f.color, radii = f.radii, visible = f.visible;
+    if (needs_grad) {
+        const Tensor inputs[15] = {means3D, means2D, sh, colors, opac, scales, rot, cov, second[0], second[1], second[2], second[3], second[4], second[5], second[6]};
+        attach(node, inputs);
+    }
+    if (with_visibility) return {color, radii, visible};
+    return {color, radii};
+}
+
+// The whole of render() (/root/reference/hugs/renderer/gs_renderer.py:103-161) as one call: the zero viewspace leaf (:107-113),
+// tanfov in double (:116-117), `feats.ndim == 2` = precomputed colours (:119-123), the rasterization with the clamp fused (:153)
+// and the visibility filter (:159).  `second`: nothing, or the second model's (means3D, feats, opacity, scales, rotations).
+// -> (image, radii, visibility_filter, viewspace_points)
+std::vector<Tensor> render(Tensor means3D, Tensor feats, Tensor opacity, Tensor scales, Tensor rotations, std::vector<Tensor> second, Tensor bg, Tensor view,
+                           Tensor proj, Tensor campos, int64_t H, int64_t W, double fovx, double fovy, double mod, int64_t degree)
+{
+    TORCH_CHECK(second.empty() || second.size() == 5, "the second model is a list of five tensors");
+    TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
+    const bool is_rgb = feats.dim() == 2;
+    const Tensor none;
+    if (second.empty()) second.assign(5, Tensor());
+    const int64_t rows = means3D.size(0) + (second[0].defined() ? second[0].size(0) : 0);
+    Tensor viewspace = viewspace_zeros(rows, at::TensorOptions().dtype(means3D.scalar_type()).device(means3D.device()));
+    auto out = rasterize(means3D, viewspace, is_rgb ? none : feats, is_rgb ? feats : none, opacity, scales, rotations, none, bg, view, proj, campos, H, W,
+                         std::tan(fovx * 0.5), std::tan(fovy * 0.5), mod, degree, false, false, true,
+                         second[0].defined() ? std::vector<Tensor>{second[0], is_rgb ? none : second[1], is_rgb ? second[1] : none, second[2], second[3], second[4], none}
+                                             : std::vector<Tensor>{},
+                         true);
+    return {out[0], out[1], out[2], viewspace};
+}
+
+// The two renders of one HUGS training step (render_human_scene with render_mode="human_scene", render_human_separate=True:
+// gs_renderer.py:56 and :69) as one call and ONE autograd node.  human / scene: (means3D, feats, opacity, scales, rotations).
+// -> (image, radii, visibility_filter, viewspace_points, human_img, human_radii, human_visibility_filter)
+std::vector<Tensor> render_pair(std::vector<Tensor> human, std::vector<Tensor> scene, Tensor bg, Tensor human_bg, Tensor view, Tensor proj, Tensor campos,
+                                int64_t H, int64_t W, double fovx, double fovy, double mod, int64_t degree)
+{
+    TORCH_CHECK(human.size() == 5 && scene.size() == 5, "human and scene are lists of five tensors");
+    TORCH_CHECK(human[0].is_cuda(), "diff_gaussian_rasterization (MI355X): `means3D` must live on the GPU (HIP device); there is no CPU fallback");
+    TORCH_CHECK(human[0].size(0) > 0 && scene[0].size(0) > 0 && human[1].dim() == scene[1].dim(), "render_pair: two non-empty models with the same kind of features");
+    const bool is_rgb = human[1].dim() == 2;
+    const Tensor none;
+    const auto dev = human[0].device();
+    const int64_t rows = human[0].size(0) + scene[0].size(0);
+    Tensor viewspace = viewspace_zeros(rows, at::TensorOptions().dtype(human[0].scalar_type()).device(dev));
+    const bool needs_grad = any_requires_grad({&human[0], &human[1], &human[2], &human[3], &human[4], &scene[0], &scene[1], &scene[2], &scene[3], &scene[4]}) ||
+                            at::GradMode::is_enabled();   // (the viewspace leaf requires grad)
+    auto node = std::shared_ptr<RasterNode>(new RasterNode(), torch::autograd::deleteNode);
+    node->nframes = 2;
+    Frame &J = node->f[0], &Hh = node->f[1];
+    {
+        at::AutoGradMode no_grad(false);
+        c10::DeviceGuard guard(dev);
+        const double tx = std::tan(fovx * 0.5), ty = std::tan(fovy * 0.5);
+        J.a = make_set(human[0], is_rgb ? none : human[1], is_rgb ? human[1] : none, human[2], human[3], human[4], none);
+        J.b = make_set(scene[0], is_rgb ? none : scene[1], is_rgb ? scene[1] : none, scene[2], scene[3], scene[4], none);
+        J.s = make_settings(human[0], bg, view, proj, campos, H, W, tx, ty, mod, degree, false, false, true, true);
+        Hh.a = J.a;
+        Hh.s = J.s;
+        Hh.s.bg = human_bg.defined() ? f32c(human_bg.device() == dev ? human_bg : human_bg.to(dev)) : J.s.bg;
+        const hipStream_t main = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        const hipStream_t side = side_stream((int)dev.index()).stream();
+        Events& ev = events_for((int)dev.index());
+        // the human-only frame goes first, on the side stream, without a wait for its N: its latency-bound binning runs under the
+        // joint frame's (forward and, through the node, backward); outputs and scratch of both are allocated on the caller's stream
+        fence(ev.a, main, side);
+        start_frame(Hh, needs_grad, side, true);
+        start_frame(J, needs_grad, main, false);
+        finish_frame(Hh, side);
+        finish_frame(J, main);
+        fence(ev.b, side, main);   // what follows on the caller's stream sees both images
+    }
+    std::vector<Tensor> result = {J.color, J.radii, J.visible, viewspace, Hh.color, Hh.radii, Hh.visible};
+    if (needs_grad) {
+        const Tensor inputs[15] = {human[0], viewspace, is_rgb ? none : human[1], is_rgb ? human[1] : none, human[2], human[3], human[4], none,
+                                   scene[0], is_rgb ? none : scene[1], is_rgb ? scene[1] : none, scene[2], scene[3], scene[4], none};
+        attach(node, inputs);
+    }
+    return result;
 }
 
 }  // namespace
@@ -403,6 +635,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("cov"), py::arg("bg"), py::arg("view"), py::arg("proj"), py::arg("campos"), py::arg("H"), py::arg("W"),
           py::arg("tanfovx"), py::arg("tanfovy"), py::arg("mod"), py::arg("degree"), py::arg("prefiltered"), py::arg("debug"),
           py::arg("clamp_output"), py::arg("second") = std::vector<Tensor>(), py::arg("with_visibility") = false);
+    m.def("render", &render, "render() of the HUGS renderer as one call: (image, radii, visibility_filter, viewspace_points)",
+          py::arg("means3D"), py::arg("feats"), py::arg("opacity"), py::arg("scales"), py::arg("rotations"), py::arg("second"), py::arg("bg"),
+          py::arg("view"), py::arg("proj"), py::arg("campos"), py::arg("H"), py::arg("W"), py::arg("fovx"), py::arg("fovy"), py::arg("mod"),
+          py::arg("degree"));
+    m.def("render_pair", &render_pair,
+          "the joint human+scene render and the separate human-only render of one training step as one call and one autograd node: "
+          "(image, radii, visibility_filter, viewspace_points, human_img, human_radii, human_visibility_filter)",
+          py::arg("human"), py::arg("scene"), py::arg("bg"), py::arg("human_bg"), py::arg("view"), py::arg("proj"), py::arg("campos"), py::arg("H"),
+          py::arg("W"), py::arg("fovx"), py::arg("fovy"), py::arg("mod"), py::arg("degree"));
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
     m.def("last_frame_info", [] { return std::make_tuple(t_last_n, t_last_capacity, t_last_long, t_last_sparse); },
           "(N, binning capacity, has long tiles, sparse) of this thread's last forward");
@@ -410,6 +651,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         std::lock_guard<std::mutex> lk(g_mu);
         remember_hint(std::make_tuple(dev, P, H, W), Hint{n, has_long, sparse});
     }, py::arg("dev"), py::arg("P"), py::arg("H"), py::arg("W"), py::arg("n"), py::arg("has_long"), py::arg("sparse") = true);
+    m.def("get_hint", [](int dev, int64_t P, int64_t H, int64_t W) -> py::object {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_hints.find(std::make_tuple(dev, P, H, W));
+        if (it == g_hints.end()) return py::none();
+        return py::make_tuple(it->second.n, it->second.has_long, it->second.sparse);
+    }, "(N, has long tiles, sparse) of the last frame of this shape, or None");
     m.def("clear_hints", [] { std::lock_guard<std::mutex> lk(g_mu); g_hints.clear(); });
     m.def("use_hints", [](bool on) { g_use_hint = on; });
     m.def("use_checkpoints", [](bool on) { g_use_ckpt = on; });

@@ -31,7 +31,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # HGS_RASTERIZER_LIB lets a test/benchmark point at another build of the same library (A/B runs)
 _LIB_PATH = os.environ.get("HGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libhgs_rasterizer.so")
-_ABI_VERSION = 10
+_ABI_VERSION = 11
 
 
 def library_path():
@@ -76,7 +76,10 @@ class _BackwardArgs(C.Structure):
                 ("dL_dsh", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
                 ("seg2_dL_dopacity", C.c_void_p), ("seg2_dL_dcolors", C.c_void_p), ("seg2_dL_dmeans3D", C.c_void_p),
                 ("seg2_dL_dcov3D", C.c_void_p), ("seg2_dL_dsh", C.c_void_p), ("seg2_dL_dscales", C.c_void_p),
-                ("seg2_dL_drotations", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("seg2_dL_drotations", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("add_dL_dopacity", C.c_void_p), ("add_dL_dcolors", C.c_void_p), ("add_dL_dmeans3D", C.c_void_p),
+                ("add_dL_dcov3D", C.c_void_p), ("add_dL_dsh", C.c_void_p), ("add_dL_dscales", C.c_void_p),
+                ("add_dL_drotations", C.c_void_p), ("wait_before_per_gaussian", C.c_void_p)]
 
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
@@ -127,6 +130,8 @@ def _load():
     lib.hgs_scratch_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_debug_stat.argtypes = [C.c_char_p]
     lib.hgs_debug_stat.restype = C.c_int64
+    lib.hgs_reload_switches.argtypes = []
+    lib.hgs_reload_switches.restype = None
     lib.hgs_copy_bandwidth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.hgs_copy_bandwidth.restype = C.c_int32
     lib.hgs_profile_enable.argtypes = [C.c_uint32]
@@ -708,6 +713,10 @@ def rasterize_deferred(means3D, opacities, raster_settings, shs=None, colors_pre
             f.num_rendered = 0
             return f
         seen = _max_num_rendered.get(f.key)
+        if seen is None and _cpp is not None:   # (frames that went through the C++ binding's one-call entry points keep their record there)
+            known = _cpp.get_hint(*f.key)
+            if known is not None:
+                seen = int(known[0])
         bufs = []
 
         def _alloc(_ctx, which, nbytes):

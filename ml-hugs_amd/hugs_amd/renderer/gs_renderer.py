@@ -22,6 +22,7 @@ import os
 
 import torch
 
+import diff_gaussian_rasterization as _dgr
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_deferred
 
 _FIELDS = (("shs", "feats"), ("xyz", "means3D"), ("opacity", "opacity"), ("scales", "scales"), ("rotq", "rotations"))
@@ -30,6 +31,23 @@ _FIELDS = (("shs", "feats"), ("xyz", "means3D"), ("opacity", "opacity"), ("scale
 _JOINT_CONCAT = os.environ.get("HGS_JOINT_CONCAT", "0") == "1"
 _VIEWSPACE_NONLEAF = os.environ.get("HGS_VIEWSPACE_NONLEAF", "0") == "1"
 _FUSED_VISIBILITY = os.environ.get("HGS_FUSED_VISIBILITY", "1") != "0"
+
+
+# Round 5: one C++ call per frame.  render() -- viewspace tensor, settings, rasterization, visibility -- and the two renders of a
+# training step (render_human_scene with render_human_separate) each are ONE call into the C++ binding (csrc_torch/hgs_torch.cpp:
+# render / render_pair) with one hand-made autograd node behind it: the frames HUGS renders most take ~120-150 us of kernels, and
+# the Python statements below cost as much on a slow host.  Same kernels, same values.  HGS_FRAME_CALL=0 (or any of the A/B
+# switches above that change what a frame consists of) keeps the statement-by-statement path.
+_FRAME_CALL = os.environ.get("HGS_FRAME_CALL", "1") != "0"
+
+
+def _frame_call(device):
+    if not _FRAME_CALL or _VIEWSPACE_NONLEAF or not _FUSED_VISIBILITY or device.type != "cuda":
+        return None
+    return _dgr._load_cpp()
+
+
+_MODEL_KEYS = ("xyz", "shs", "opacity", "scales", "rotq")   # (means3D, feats, opacity, scales, rotations) of a model's output dict
 
 
 def _two_segments(human_gs_out, scene_gs_out):
@@ -88,6 +106,18 @@ def render_human_scene(data, human_gs_out, scene_gs_out, bg_color, human_bg_colo
 
     device = g["means3D"].device
     side = main = None
+    cpp = _frame_call(device) if (separate and _CONCURRENT_RENDERS and "second" in g) else None
+    if cpp is not None:
+        # both renders of the step in one call, one autograd node: the human-only frame runs on a library-side stream under the joint
+        # one (forward and backward) and its gradients of the human tensors are summed inside the joint frame's per-Gaussian kernel
+        out = cpp.render_pair([human_gs_out[k] for k in _MODEL_KEYS], [scene_gs_out[k] for k in _MODEL_KEYS], bg_color,
+                              human_bg_color if human_bg_color is not None else bg_color, data["world_view_transform"],
+                              data["full_proj_transform"], data["camera_center"], int(data["image_height"]), int(data["image_width"]),
+                              float(data["fovx"]), float(data["fovy"]), float(scaling_modifier), int(g["active_sh_degree"]))
+        n_h = human_gs_out["xyz"].shape[0]
+        return {"render": out[0], "viewspace_points": out[3], "visibility_filter": out[2], "radii": out[1],
+                "human_img": out[4], "human_visibility_filter": out[6], "human_radii": out[5],
+                "scene_visibility_filter": out[2][n_h:], "scene_radii": out[1][n_h:]}
     if separate and _CONCURRENT_RENDERS and device.type == "cuda":
         main, side = torch.cuda.current_stream(device), _side_stream(device)
         side.wait_stream(main)
@@ -145,6 +175,14 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
     # `.grad` receives the rasterizer's gradient buffer itself (no clone), the values are the same zeros, and everything the
     # trainer does with it (reads .grad, slices it, re-assigns it: gs_trainer.py:316-342) works alike.
     # HGS_VIEWSPACE_NONLEAF=1 restores the reference's construction.
+    cpp = _frame_call(device)
+    if cpp is not None:
+        sec = [] if second is None else [second["means3D"], second["feats"], second["opacity"], second["scales"], second["rotations"]]
+        image, radii, visible, screenspace_points = cpp.render(
+            means3D, feats, opacity, scales, rotations, sec, bg_color, data["world_view_transform"], data["full_proj_transform"],
+            data["camera_center"], int(data["image_height"]), int(data["image_width"]), float(data["fovx"]), float(data["fovy"]),
+            float(scaling_modifier), int(active_sh_degree))
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
     n_rows = means3D.shape[0] + (second["means3D"].shape[0] if second is not None else 0)
     if _VIEWSPACE_NONLEAF:
         screenspace_points = torch.zeros(n_rows, 3, dtype=means3D.dtype, requires_grad=True, device=device) + 0

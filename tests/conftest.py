@@ -19,3 +19,14 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment():
+    """The HIP library reads its HGS_* A/B switches once; tests flip them with monkeypatch.setenv + hgs_reload_switches().  An
+    autouse fixture is set up before (so torn down after) monkeypatch: by now the environment is back, and the library re-reads it."""
+    yield
+    import sys
+    dgr = sys.modules.get("diff_gaussian_rasterization")
+    if dgr is not None and getattr(dgr, "_lib", None) is not None:
+        dgr._lib.hgs_reload_switches()

@@ -45,6 +45,8 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(hgs_segment), offsetof(hgs_forward_args, backward_checkpoints), offsetof(hgs_forward_args, scratch_bytes), offsetof(hgs_forward_args, seg2));
   printf("%zu %zu %zu %zu\n", offsetof(hgs_segment, cov3D_precomp), offsetof(hgs_forward_state, ckpt), offsetof(hgs_forward_state, n_token), offsetof(hgs_backward_args, seg2_dL_drotations));
   printf("%zu %zu\n", offsetof(hgs_backward_args, flags), offsetof(hgs_forward_args, visible));
+  /* ABI v11: the other render's gradients to add, and the event the per-Gaussian kernel waits for */
+  printf("%zu %zu %zu\n", offsetof(hgs_backward_args, add_dL_dopacity), offsetof(hgs_backward_args, add_dL_drotations), offsetof(hgs_backward_args, wait_before_per_gaussian));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
@@ -58,7 +60,8 @@ int main(void) {
     Sg = dgr._Segment
     assert v[12:16] == [C.sizeof(Sg), F.backward_checkpoints.offset, F.scratch_bytes.offset, F.seg2.offset]
     assert v[16:20] == [Sg.cov3D_precomp.offset, St.ckpt.offset, St.n_token.offset, B.seg2_dL_drotations.offset]
-    assert v[20:] == [B.flags.offset, F.visible.offset]
+    assert v[20:22] == [B.flags.offset, F.visible.offset]
+    assert v[22:] == [B.add_dL_dopacity.offset, B.add_dL_drotations.offset, B.wait_before_per_gaussian.offset]
 
 
 def test_scratch_size_queries_and_offsets():

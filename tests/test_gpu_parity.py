@@ -73,6 +73,13 @@ def run_gpu(sc, device, debug=False):
     return t, color, radii
 
 
+def reload_switches(monkeypatch=None):
+    """The library reads its HGS_* switches from the environment once; a test that changes them tells it so.  (tests/conftest.py
+    reloads them again after every test, when monkeypatch has put the environment back.)"""
+    import diff_gaussian_rasterization as dgr
+    dgr._load().hgs_reload_switches()
+
+
 def _force_ctypes_binding(monkeypatch):
     """run the calls of this test through the Python (ctypes) binding instead of the C++ autograd node"""
     import diff_gaussian_rasterization as dgr
@@ -190,6 +197,7 @@ def test_both_binning_paths_give_the_same_lists_and_gradients(name, mode, device
     """Large frames sort the Gaussians by screen cell before they are binned (BIN_BY_CELL, hgs_common.h), small ones bin them
     in storage order (BIN_IN_ORDER); HGS_BIN_MODE forces either, and the stage-level test above must hold for both."""
     monkeypatch.setenv("HGS_BIN_MODE", mode)
+    reload_switches(monkeypatch)
     test_forward_stages_and_image(name, device)
     test_backward_gradients(name, device)
 
@@ -274,7 +282,7 @@ def test_cpp_binding_equals_ctypes_binding(name, device, monkeypatch):
         if hint is not None:
             cpp.set_hint(torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"], hint[0], hint[1])
         t, c, r = run_gpu(sc, device)
-        assert c.grad_fn is not None and c.grad_fn.name().endswith("Rasterize>") and dgr.last_frame_info()[0] > 0     # the C++ node
+        assert c.grad_fn is not None and c.grad_fn.name() == "HgsRasterizeBackward" and dgr.last_frame_info()[0] > 0     # the C++ node
         c.backward(g)
         runs.append((t, c, r))
     _force_ctypes_binding(monkeypatch)
@@ -1214,9 +1222,11 @@ def test_deep_tiles_of_a_dense_frame_take_the_segmented_backward(binding, size, 
     # doing the same work in another order -- the gradients differ by the float atomics' order only
     monkeypatch.setattr(dgr, "_USE_CKPT", True)
     monkeypatch.setenv("HGS_BWD_TWO_LAUNCHES", "1")
+    reload_switches(monkeypatch)
     t, color, _ = run_gpu(sc, device)
     color.backward(to_dev(sc["dL_dpix"], device))
     monkeypatch.delenv("HGS_BWD_TWO_LAUNCHES")
+    reload_switches(monkeypatch)
     assert torch.equal(color.detach(), images[True])
     for k in grads[True]:
         assert rel_l2(t[k].grad.cpu().numpy(), grads[True][k]) <= ALT_BACKWARD_TOL, k
@@ -1323,6 +1333,7 @@ def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monke
     #  for the sparse-frame threshold to apply)
     monkeypatch.setenv("HGS_LONG_MIN_DENSE", "256")
     monkeypatch.setenv("HGS_LONG_MIN_SPARSE", "256")
+    reload_switches(monkeypatch)
     sc["opacities"] = np.clip(sc["opacities"] * 3.0, 0.0, 0.95).astype(np.float32)
     inp = oracle_inputs(sc)
     ref = ho.forward(inp)
@@ -1332,6 +1343,7 @@ def test_depth_parallel_forward_equals_the_one_wave_forward(frame, device, monke
     out = {}
     for deep in ("1", "0"):
         monkeypatch.setenv("HGS_DEEP_FORWARD", deep)
+        reload_switches(monkeypatch)
         t = gpu_tensors(sc, device, grad=False)
         for _ in range(2):   # (the second frame runs on the first one's hints: the long-tile sort + workers in front of the tile kernel)
             color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],

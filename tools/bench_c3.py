@@ -13,7 +13,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from diff_gaussian_rasterization import profile_enable, profile_read   # noqa: E402
+import bench_common as bc                                                # noqa: E402
 from hugs_amd import synthetic as syn                                    # noqa: E402
 from hugs_amd.renderer import render_human_scene                         # noqa: E402
 
@@ -44,21 +46,22 @@ def main(P=110_210, steps=200, warmup=20):
 
     for _ in range(warmup):
         pkg = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms, host_busy_us = bc.timed_loop(step, steps)
     profile_enable()
     for _ in range(10):
         step()
     torch.cuda.synchronize()
     stages = {k: round(v[0] / 10.0, 4) for k, v in profile_read().items()}
     profile_enable(())
+    N, cap, has_long, sparse = bc.last_frame()
+    Pv = int(pkg["visibility_filter"].sum())
     print(json.dumps({"workload": f"C3: {P} human Gaussians, 512x512, degree 0, rotating rig, fwd+bwd", "ms_per_step": round(ms, 4),
-                      "fps": round(1e3 / ms, 1), "num_rendered_N": int(pkg["render"].grad_fn is not None and 0) or None,
-                      "visible": int(pkg["visibility_filter"].sum()), "stages_ms": stages}))
+                      "fps": round(1e3 / ms, 1), "host_busy_us_per_step": round(host_busy_us, 1), "num_rendered_N": N, "binning_capacity": cap,
+                      "sparse_frame": sparse, "has_long_tiles": has_long, "gaussians": P, "visible": Pv, "stages_ms": stages,
+                      "roofline": bc.roofline(stages, P, Pv, N, 512, 512, 0),
+                      "whole_frame": {"algorithmic_bytes": bc.frame_bytes(P, Pv, N, 512 * 512, 1024, 1),
+                                      "GB_per_s": round(bc.frame_bytes(P, Pv, N, 512 * 512, 1024, 1) / (ms * 1e-3) / 1e9, 1)},
+                      "box": bc.box()}))
 
 
 if __name__ == "__main__":

@@ -14,6 +14,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-hugs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_common as bc                                  # noqa: E402
 from hugs_amd import synthetic as syn                      # noqa: E402
 from hugs_amd.renderer import render_human_scene           # noqa: E402
 
@@ -52,13 +54,14 @@ def main(steps=100, warmup=15):
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    extra = {}
+    torch.cuda.reset_peak_memory_stats(dev)
+    ms, host_busy_us = bc.timed_loop(step, steps)
+    extra = {"host_busy_us_per_step": round(host_busy_us, 1), "peak_memory_MB": round(torch.cuda.max_memory_allocated(dev) / 2**20, 1)}
+    with torch.no_grad():   # the two frames' exact integers (N of the joint frame = this thread's last forward on the statement path too)
+        pk = render_human_scene(data, human, scene, bg_color=bg, human_bg_color=hbg, render_mode="human_scene", render_human_separate=False)
+        extra["joint_frame"] = {"gaussians": Ph + Ps, "visible": int(pk["visibility_filter"].sum()), "num_rendered_N": bc.last_frame()[0]}
+        pk = render_human_scene(data, human, None, bg_color=hbg, render_mode="human")
+        extra["human_only_frame"] = {"gaussians": Ph, "visible": int(pk["visibility_filter"].sum()), "num_rendered_N": bc.last_frame()[0]}
     if os.environ.get("HGS_C4_WITH_LOSS", "0") == "1":
         # the same step with the reference's photometric loss on both renders as the source of dL/dimage
         # (hugs/losses/loss.py:88-107,128-137: 0.8 l1 + 0.2 (1 - ssim)): fused row f-5 kernels, then the torch statements
@@ -97,6 +100,17 @@ def main(steps=100, warmup=15):
     torch.cuda.synchronize()
     stages = {k: round(v[0] / 5.0, 4) for k, v in profile_read().items()}
     profile_enable(())
+    jf, hf = extra["joint_frame"], extra["human_only_frame"]
+    T = ((H + 15) // 16) * ((W + 15) // 16)
+    # both renders' launches of a stage are summed in stages_ms: so are their algorithmic bytes (degree 0: K = 1)
+    sb = {k: a + b for (k, a), b in zip(bc.stage_bytes(Ph + Ps, jf["visible"], jf["num_rendered_N"], H * W, T, 1).items(),
+                                        bc.stage_bytes(Ph, hf["visible"], hf["num_rendered_N"], H * W, T, 1).values())}
+    dom = max((k for k in stages if k in sb), key=lambda k: stages[k])
+    gbps = sb[dom] / (stages[dom] * 1e-3) / 1e9
+    extra["roofline"] = {"bound": "hbm", "kernel": bc.KERNEL_OF[dom], "stage": dom, "achieved": round(gbps, 1), "peak": bc.HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(gbps / bc.HBM_PEAK_GBPS, 5), "algorithmic_bytes_both_renders": int(sb[dom]), "stage_ms_both_renders": stages[dom],
+                         "traffic": None}
+    extra["box"] = bc.box()
     print(json.dumps({"stages_ms_both_renders": stages, "workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
                       "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
                       "joint_render": "torch.cat (reference form)" if os.environ.get("HGS_JOINT_CONCAT", "0") == "1" else "second segment (no concatenation)",

@@ -1,0 +1,87 @@
+"""What every side-workload timing (tools/bench_c3.py, bench_c4.py) reports next to its milliseconds, the way bench.py does for the
+headline workload: the frame's exact integers (N, visible), host busy time per step, the box, and a `roofline` block -- the dominant
+stage's algorithmic bytes over its HIP-event time against the HBM peak."""
+import os
+import time
+import zlib
+
+import torch
+
+import diff_gaussian_rasterization as dgr
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md
+KERNEL_OF = {"blend_backward": "blend_backward (segmented / one wave per tile / mixed)", "sort": "tile sort fused with the forward blend (+ long-tile sorts)",
+             "preprocess": "preprocess_kernel", "preprocess_backward": "preprocess_backward_kernel", "scan": "tile_scan_kernel (+ cell scatter / group count)",
+             "emit_keys": "emit_kernel", "blend_forward": "blend_forward_kernel"}
+
+
+def last_frame():
+    """(N, capacity, has_long, sparse) of this thread's last forward, whichever binding ran it"""
+    cpp = dgr._load_cpp()
+    if cpp is not None:
+        n, cap, has_long, sparse = cpp.last_frame_info()
+        if n >= 0:
+            return int(n), int(cap), bool(has_long), bool(sparse)
+    n, cap = dgr.last_frame_info()
+    return (int(n) if n is not None else None), (int(cap) if cap is not None else None), None, None
+
+
+def _stat(name):
+    return dgr._load().hgs_debug_stat(name.encode())
+
+
+def timed_loop(step, steps):
+    """-> (ms per step, host busy us per step): busy = wall time minus what the library spent waiting for N (the host's only idle
+    time inside the loop); the GPU is drained before and after."""
+    torch.cuda.synchronize()
+    w0 = _stat("forward_wait_ns")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    busy = (t_host * 1e9 - (_stat("forward_wait_ns") - w0)) / steps * 1e-3
+    return ms, busy
+
+
+def stage_bytes(P, Pv, N, S, T, K, M=16):
+    """algorithmic bytes per launch of each stage (the fused sort + forward blend as in bench.py)"""
+    return {"preprocess": P * (44 + 12 * K) + 8 * P + 67 * Pv, "preprocess_backward": Pv * (111 + 12 * K) + P * (40 + 12 * M),
+            "blend_backward": 8 * T + 40 * N + 20 * S + 36 * Pv, "sort": 8 * T + 40 * N + 20 * S + 28 * N,
+            "emit_keys": 36 * Pv + 8 * N, "scan": 8 * T}
+
+
+def frame_bytes(P, Pv, N, S, T, K, M=16):
+    return P * (108 + 12 * K + 12 * M) + Pv * (226 + 12 * K) + 124 * N + 40 * S + 24 * T
+
+
+def roofline(stages_ms, P, Pv, N, H, W, D):
+    """the `roofline` block of the stage that takes longest"""
+    K, S, T = (D + 1) ** 2, H * W, ((H + 15) // 16) * ((W + 15) // 16)
+    b = stage_bytes(P, Pv, N, S, T, K)
+    dom = max((k for k in stages_ms if k in b), key=lambda k: stages_ms[k])
+    gbps = b[dom] / (stages_ms[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": KERNEL_OF[dom], "stage": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": int(b[dom]), "avg_launch_ms": stages_ms[dom], "traffic": None,
+            "note": "HIP events around every stage in a separate pass (each pair adds a few microseconds); the blend kernels are VALU / "
+                    "latency bound, not HBM bound (DESIGN.md section 4)"}
+
+
+def box():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 1)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "host_cpus": os.cpu_count(), "cpu_quota": quota, "box_id": "%04x" % (zlib.crc32(os.uname().nodename.encode()) & 0xFFFF),
+            "frame_call": os.environ.get("HGS_FRAME_CALL", "1") != "0"}

@@ -411,7 +411,7 @@ size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int
  * "backward_calls" / "backward_ns".  -1 for an unknown name. */
 int64_t hgs_debug_stat(const char *name);
 
-/* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE)
+/* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE, HGS_EMIT_SCAN, HGS_K1_STAGE_SH)
  * from the environment once, at its first frame; a test or A/B tool that changes them inside one process calls this afterwards. */
 void hgs_reload_switches(void);
 

@@ -80,12 +80,28 @@ constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at lea
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
 constexpr uint32_t N_TOO_MANY = 0xFFFFFFF0u;  // pair counts from here on are reported as "too many" (32-bit list positions)
 
-__global__ void __launch_bounds__(1024)
-tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __restrict__ cell_count, int num_cells,
-                 uint2* __restrict__ ranges, uint32_t* __restrict__ cursor, uint32_t* __restrict__ n_total,
-                 uint32_t* __restrict__ large_tiles, uint32_t* __restrict__ seg_first, uint32_t capacity,
-                 unsigned long long* __restrict__ host_slot, uint32_t ticket, uint32_t long_min_sparse, uint32_t long_min_dense_arg)
+// Everything the scan reads and writes (a kernel argument of tile_scan_kernel, and of emit_scan_kernel whose extra workgroup runs it)
+struct ScanArgs {
+    uint32_t* tile_count; int num_tiles; uint32_t* cell_count; int num_cells;
+    uint2* ranges; uint32_t* cursor; uint32_t* n_total; uint32_t* large_tiles; uint32_t* seg_first; uint32_t capacity;
+    unsigned long long* host_slot; uint32_t ticket, long_min_sparse, long_min_dense_arg;
+};
+
+// The scan as a workgroup of 1024 threads.  ZERO: re-zero the counters it has read (the stand-alone kernel, their only reader);
+// !ZERO: other workgroups of the same launch read them too, and the last of them to arrive zeroes them (emit_scan_kernel).
+template <bool ZERO>
+__device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
 {
+    uint32_t* __restrict__ tile_count = sa.tile_count;
+    const int num_tiles = sa.num_tiles, num_cells = sa.num_cells;
+    uint32_t* __restrict__ cell_count = sa.cell_count;
+    uint2* __restrict__ ranges = sa.ranges;
+    uint32_t* __restrict__ cursor = sa.cursor;
+    uint32_t* __restrict__ n_total = sa.n_total;
+    uint32_t* __restrict__ large_tiles = sa.large_tiles;
+    uint32_t* __restrict__ seg_first = sa.seg_first;
+    const uint32_t capacity = sa.capacity, ticket = sa.ticket, long_min_sparse = sa.long_min_sparse, long_min_dense_arg = sa.long_min_dense_arg;
+    unsigned long long* __restrict__ host_slot = sa.host_slot;
     // (bit 31: the dense threshold was given explicitly -- HGS_LONG_MIN_DENSE -- and applies whatever the frame's deepest list)
     const uint32_t long_min_dense = long_min_dense_arg & 0x7FFFFFFFu, dense_unconditional = long_min_dense_arg >> 31;
     __shared__ uint32_t n_long_sh;
@@ -94,7 +110,8 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
     if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
-    for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
+    if (ZERO)
+        for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0, carry2 = 0;
@@ -109,13 +126,15 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
             const uint4 lo = reinterpret_cast<const uint4*>(tile_count + t0)[0], hi = reinterpret_cast<const uint4*>(tile_count + t0)[1];
             c[0] = lo.x, c[1] = lo.y, c[2] = lo.z, c[3] = lo.w, c[4] = hi.x, c[5] = hi.y, c[6] = hi.z, c[7] = hi.w;
             // the counters are self-cleaning: zero again for the next frame on this stream
-            reinterpret_cast<uint4*>(tile_count + t0)[0] = make_uint4(0u, 0u, 0u, 0u);
-            reinterpret_cast<uint4*>(tile_count + t0)[1] = make_uint4(0u, 0u, 0u, 0u);
+            if (ZERO) {
+                reinterpret_cast<uint4*>(tile_count + t0)[0] = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<uint4*>(tile_count + t0)[1] = make_uint4(0u, 0u, 0u, 0u);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < SCAN_ITEMS; ++k) {
                 c[k] = t0 + k < num_tiles ? tile_count[t0 + k] : 0u;
-                if (t0 + k < num_tiles) tile_count[t0 + k] = 0u;
+                if (ZERO && t0 + k < num_tiles) tile_count[t0 + k] = 0u;
             }
         }
         uint32_t mine = 0, nonempty = 0;
@@ -353,17 +372,27 @@ tile_scan_kernel(uint32_t* __restrict__ tile_count, int num_tiles, uint32_t* __r
     }
 }
 
-void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
-                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
+__global__ void __launch_bounds__(1024) tile_scan_kernel(ScanArgs sa) { tile_scan_body<true>(sa); }
+
+static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
+                               uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                               unsigned long long* host_slot, uint32_t ticket)
 {
     // (both at most SORT_CAP_SMALL: that is what the one-workgroup-per-tile sort holds)
     const Switches& sw = switches();
     auto clamped = [](int v, int dflt) { v = v > 0 ? v : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
     const uint32_t long_min_sparse = clamped(sw.long_min_sparse, LONG_MIN_SPARSE), long_min_dense = clamped(sw.long_min_dense, LONG_MIN_DENSE);
     const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, num_tiles, cell_count, cell_count ? num_cells : 0,
-                       ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, long_min_sparse, dense_arg);
+    return ScanArgs{tile_count, num_tiles, cell_count, cell_count ? num_cells : 0, ranges, cursor, n_total, large_tiles, seg_first, capacity,
+                    host_slot, ticket, long_min_sparse, dense_arg};
+}
+
+void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
+                      uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
+{
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st,
+                       make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -524,13 +553,23 @@ count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __re
 constexpr int EMIT_THREADS = 1024;
 constexpr int EMIT_SLOTS = 8192;  // pair slots dealt per round (LDS: 2 bytes each)
 
-template <bool USE_LDS>
-__global__ void __launch_bounds__(EMIT_THREADS)
-emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
-            const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
-            int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
+// SCAN (round 5; BIN_IN_ORDER frames of at most EMIT_SCAN_TILES tiles whose binning capacity is known before N is): there is no tile
+// scan kernel in front -- every workgroup prefix-sums the frame's <= 16 KB of per-tile counts for itself (four tiles per thread,
+// one round trip that overlaps the group's record loads) where it used to read the scan's result, and decides the capacity gate
+// from its own total; ONE extra workgroup of the launch (emit_scan_kernel) does what only one can do: ranges, N, flags, the long
+// tiles' list, the checkpoint slot layout, the word the host polls.  The workgroup that arrives LAST at the launch's arrival
+// counter re-zeroes the counters (the stand-alone scan kernel, their only reader, did that itself).  One launch and ~7 us of
+// latency chain less on the frames that consist of nothing else (the human-only render).
+constexpr int EMIT_SCAN_TILES = 4096;
+
+template <bool USE_LDS, bool SCAN>
+__device__ __forceinline__ void
+emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
+          const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
+          int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_count, uint32_t capacity,
+          uint32_t* __restrict__ arrival)
 {
-    if (*gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
+    if (!SCAN && *gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     // BIN_BY_CELL (order != nullptr): the group is a run of `order` and spans a window of tiles; BIN_IN_ORDER: consecutive
     // Gaussians, the whole grid
     uint4 window = make_uint4(0u, 0u, (uint32_t)cam.gx, (uint32_t)cam.gy);
@@ -558,7 +597,58 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
     int gid = P;
     if (tid < G) gid = (USE_LDS && order) ? ((uint32_t)(g0 + tid) < n_alive ? (int)order[g0 + tid] : P) : g0 + tid;
     if (tid < G) mine = load_rect(P, cam, splats, gid, true);  // (gid >= P: an empty rectangle)
-    if (USE_LDS) {
+    bool gated = false;          // SCAN: this frame needs more binning entries than it was given (workgroup-uniform, launch-uniform)
+    uint32_t arrived_as = 0u;    // SCAN, thread 0: how many readers of the tile counters had reported in before this workgroup
+    __shared__ uint32_t last_here;
+    auto leave = [&]() {         // SCAN: the workgroup that reported in last re-zeroes the counters
+        if (!SCAN) return;
+        if (tid == 0) last_here = arrived_as == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (last_here) {
+            for (int t = tid; t < num_tiles; t += NT) tile_count[t] = 0u;
+            if (tid == 0) atomicExch(arrival, 0u);
+        }
+    };
+    if (SCAN) {
+        __shared__ uint32_t scan_w[NT / 64];
+        __shared__ unsigned long long scan_total64;
+        const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
+        const int t0 = tid * 4;   // (num_tiles <= 4 NT; the counter array is 16-byte aligned and padded to a multiple of eight)
+        uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t r[4] = {0u, 0u, 0u, 0u};
+        if (t0 < num_tiles) c4 = reinterpret_cast<const uint4*>(tile_count + t0)[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t0 + k < num_tiles) r[k] = my_runs[t0 + k];   // (meaningful only for the tiles this group touches)
+        if (tid == 0) scan_total64 = 0ull;
+        const uint32_t c[4] = {c4.x, t0 + 1 < num_tiles ? c4.y : 0u, t0 + 2 < num_tiles ? c4.z : 0u, t0 + 3 < num_tiles ? c4.w : 0u};
+        const uint32_t sum4 = c[0] + c[1] + c[2] + c[3];
+        const uint32_t inc = wave_inclusive_scan(sum4);
+        unsigned long long m64 = sum4;   // (the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m64 += (unsigned long long)__shfl_xor((long long)m64, d, 64);
+        __syncthreads();   // scan_total64 initialised
+        if (lane == 63) scan_w[w] = inc;
+        if (lane == 0 && m64) atomicAdd(&scan_total64, m64);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) {
+            const uint32_t v = scan_w[k];
+            if (k < w) before += v;
+            total += v;
+        }
+        uint32_t at = before + inc - sum4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t0 + k < num_tiles) hist[t0 + k] = at + r[k];   // this group's cursor into every tile's segment
+            at += c[k];
+        }
+        gated = scan_total64 >= (unsigned long long)N_TOO_MANY || total > capacity;
+        // every reader of the counters reports in (its loads have returned: their values were used above); the last one re-zeroes
+        // them -- at the END of its work: the returning atomic's round trip (~2 us) runs under the emission instead of in front of it
+        if (tid == 0) arrived_as = atomicAdd(arrival, 1u);
+    } else if (USE_LDS) {
         // this group's cursor into the tile segments of its window (entries of tiles the group does not touch are never
         // used, and run_start holds nothing meaningful for them)
         const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
@@ -580,6 +670,10 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
         const uint32_t v = wtot[k];
         if (k < w) before += v;
         total += v;
+    }
+    if (gated) {   // (every workgroup of the launch takes the same decision; the host re-runs the frame exactly sized)
+        leave();
+        return;
     }
     const uint32_t first = before + incl - mine.cnt;  // this Gaussian's pairs are slots [first, first + cnt)
     if (tid < G) {
@@ -647,6 +741,36 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
             keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)__float_as_int(c.w) << 4) | mask);
         }
     }
+    leave();
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(EMIT_THREADS)
+emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
+            const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
+            int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
+{
+    emit_body<USE_LDS, false>(P, G, cam, splats, cursor, run_start, order, windows, groups, keys, gate, nullptr, 0u, nullptr);
+}
+
+// grid = the binning groups + ONE workgroup (the last) that is the frame's tile scan
+__global__ void __launch_bounds__(EMIT_THREADS)
+emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ run_start, int groups,
+                 uint64_t* __restrict__ keys, ScanArgs sa, uint32_t* __restrict__ arrival)
+{
+    if ((int)blockIdx.x == groups) {
+        tile_scan_body<false>(sa);
+        __shared__ uint32_t last_here;
+        __syncthreads();
+        if (threadIdx.x == 0) last_here = atomicAdd(arrival, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (last_here) {
+            for (int t = threadIdx.x; t < sa.num_tiles; t += EMIT_THREADS) sa.tile_count[t] = 0u;
+            if (threadIdx.x == 0) atomicExch(arrival, 0u);
+        }
+        return;
+    }
+    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, nullptr, nullptr, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival);
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
@@ -663,6 +787,18 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
     else
         hipLaunchKernelGGL(emit_kernel<false>, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(EMIT_THREADS), 0, st, P, BIN_GROUP, cam, splats,
                            cursor, nullptr, nullptr, nullptr, 0, keys, gate);
+}
+
+bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return bin_mode == BIN_IN_ORDER && group > 0 && num_tiles <= EMIT_SCAN_TILES; }
+
+void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
+                      uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t* arrival, hipStream_t st)
+{
+    const int groups = (P + group - 1) / group, num_tiles = cam.gx * cam.gy;
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start,
+                       groups, keys, make_scan_args(tile_count, num_tiles, nullptr, 0, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket),
+                       arrival);
 }
 
 // ---------------------------------------------------------------------------------------------

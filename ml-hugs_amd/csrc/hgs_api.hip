@@ -45,6 +45,10 @@ void load_switches()
     e = getenv("HGS_DEEP_FORWARD");
     s.deep_forward = !(e && e[0] == '0');
     s.long_min_sparse = num("HGS_LONG_MIN_SPARSE"), s.long_min_dense = num("HGS_LONG_MIN_DENSE");
+    e = getenv("HGS_EMIT_SCAN");
+    s.emit_scan = !(e && e[0] == '0');
+    e = getenv("HGS_K1_STAGE_SH");
+    s.k1_stage_sh = e && e[0] == '1';
     std::lock_guard<std::mutex> lk(g_sw_mu);
     g_sw = s;
     g_sw_loaded.store(true, std::memory_order_release);
@@ -571,7 +575,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     TileCounterLease tc_lease;  // held until the scan is enqueued (or this call gives up)
     // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
     const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
-    if (int rc = acquire_tile_counters(st, cell_counters_at + (size_t)num_cells, &tile_count, &tc_lease)) return rc;
+    // (+ the arrival counter of emit_scan_kernel behind them, zero between frames like the rest)
+    const size_t arrival_at = cell_counters_at + (size_t)num_cells;
+    if (int rc = acquire_tile_counters(st, arrival_at + 1, &tile_count, &tc_lease)) return rc;
     int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
     if (const int forced = group ? switches().bin_mode : 0)
@@ -587,15 +593,22 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const uint32_t cap32 = hint > 0 ? (uint32_t)(hint > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : hint) : 0xFFFFFFFFu;
     const HostSlot slot = host_slot();  // tile_scan publishes N to the host through it
     if (!slot.word) return fail(HGS_ERR_HIP, "pinned host buffer allocation failed");
-    { ProfScope ps(HGS_STAGE_SCAN, st);
-      if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
-      else if (bin_mode == BIN_NONE) launch_count(Ptot, cam, splats, tile_count, st);
-      launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
-                       want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
-    STAGE_CHECK(dbg, st, "tile_scan");
-    // the scan, which re-zeroes the counters, is enqueued: the next frame on this stream may have them
-    tc_lease.scan_enqueued = true;
-    tc_lease.release();
+    // A frame of few tiles that is enqueued before N is known (a capacity hint) has no scan kernel: emit's workgroups scan the tile
+    // counts themselves and one extra workgroup of that launch does the scan's bookkeeping (binning.hip, emit_scan_kernel).
+    // HGS_EMIT_SCAN=0: always the stand-alone scan kernel (A/B measurements, the equivalence test).
+    bool scan_pending = switches().emit_scan && hint > 0 && emit_scan_applies(bin_mode, num_tiles, group);
+    uint32_t* const seg_first_arg = want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr;
+    if (!scan_pending) {
+        { ProfScope ps(HGS_STAGE_SCAN, st);
+          if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
+          else if (bin_mode == BIN_NONE) launch_count(Ptot, cam, splats, tile_count, st);
+          launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
+                           seg_first_arg, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
+        STAGE_CHECK(dbg, st, "tile_scan");
+        // the scan, which re-zeroes the counters, is enqueued: the next frame on this stream may have them
+        tc_lease.scan_enqueued = true;
+        tc_lease.release();
+    }
 
     uint32_t* act_count = (uint32_t*)(image + il.act_count);
     const uint32_t* gate = n_total + 1;
@@ -642,8 +655,18 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         uint64_t* list = (uint64_t*)(bin + bl.list);
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
-        { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(Ptot, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
-        STAGE_CHECK(dbg, st, "emit");
+        if (scan_pending) {   // (the first, optimistic enqueue of such a frame; a re-run after an overflow finds the scan's results in place)
+            { ProfScope ps(HGS_STAGE_EMIT_KEYS, st);
+              launch_emit_scan(Ptot, cam, splats, run_start, group, keys, tile_count, ranges, cursor, n_total, large_tiles, seg_first_arg, cap32,
+                               (unsigned long long*)slot.word, slot.ticket, tile_count + arrival_at, st); }
+            STAGE_CHECK(dbg, st, "emit + tile_scan");
+            scan_pending = false;
+            tc_lease.scan_enqueued = true;   // (its last workgroup re-zeroes the counters)
+            tc_lease.release();
+        } else {
+            { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(Ptot, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
+            STAGE_CHECK(dbg, st, "emit");
+        }
         { ProfScope ps(HGS_STAGE_SORT, st);
           launch_tile_sort(ranges, num_tiles, keys, list, (uint64_t*)(bin + bl.scratch), act, bl.act_stride, act_count, large_tiles, n_total,
                            bin + bl.parts, (uint32_t)bl.max_parts, true, with_long_tiles, fused ? &fb : nullptr, hist, st); }

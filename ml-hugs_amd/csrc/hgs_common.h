@@ -201,6 +201,8 @@ struct Switches {
     bool deep_forward;          // HGS_DEEP_FORWARD=0: long tiles are blended by one wave per quad like any other tile
     int long_min_sparse;        // HGS_LONG_MIN_SPARSE (0: default)
     int long_min_dense;         // HGS_LONG_MIN_DENSE  (0: default; set = applies whatever the frame's deepest list)
+    bool emit_scan;             // HGS_EMIT_SCAN=0: always the stand-alone tile scan kernel (else: folded into emit where it applies)
+    bool k1_stage_sh;           // HGS_K1_STAGE_SH=1: the preprocess kernel fetches the SH rows through LDS (measured no faster: off)
 };
 const Switches& switches();
 
@@ -224,6 +226,12 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count,
                       unsigned long long* host_slot, uint32_t ticket, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
                  const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
+// BIN_IN_ORDER frames of few tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
+// emit_scan_kernel).  `arrival`: one zero uint32 next to the per-stream counters, self-resetting.
+bool emit_scan_applies(int bin_mode, int num_tiles, int group);
+void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
+                      uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t* arrival, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 // fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
 // Checkpoints of the forward blend for the depth-segmented backward; state == nullptr: none.  They are written only when

@@ -125,6 +125,30 @@ __device__ __forceinline__ void sh_dot(const float (&B)[16], const float* __rest
     for (int k = 0; k < K; ++k) a0 += B[k] * c[k][0], a1 += B[k] * c[k][1], a2 += B[k] * c[k][2];
 }
 
+// Round 5: the SH rows through LDS.  A thread reading its own 192-byte row makes every load instruction of the wave touch 64
+// different lines (one dword or one float4 of each); the wave's 64 rows are ONE contiguous 12 KB block.  The staged instances of
+// the kernel fetch that block with LDS-DMA (`global_load_lds_dwordx4`: 1 KB per wave-instruction, whole lines, no staging VGPRs),
+// issued first thing -- in flight under the mean / scale / rotation loads and the projection -- and every thread then reads its
+// row with ds_read_b128.  The LDS image is swizzled: slot s of row r holds float4 (s ^ f(r)) of that row, f(r) = (r >> 1) & 3, so
+// that eight lanes reading "float4 q of my row" (48-dword pitch) cover all 32 banks; LDS-DMA writes lane l to base + 16 l, so the
+// swizzle is applied to the per-lane GLOBAL address (within one 64-byte quarter line: still whole lines).  Same coefficients in
+// the same left-to-right summation as sh_dot: bit-identical colours.
+constexpr int SH_STAGE_F4 = 12 * 64;   // float4 per staged wave (M = 16: 12 per row)
+constexpr int SH_STAGE_THREADS = 832;  // 13 waves x 12 KB = 156 KB of the CU's 160 KB, the binning arrays beside them
+template <int K>
+__device__ __forceinline__ void sh_dot_staged(const float (&B)[16], const float4* row, int f, float& a0, float& a1, float& a2)
+{
+    constexpr int NQ = (3 * K + 3) / 4;
+    float v[4 * NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4 t = row[q ^ f];
+        v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) a0 += B[k] * v[3 * k], a1 += B[k] * v[3 * k + 1], a2 += B[k] * v[3 * k + 2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: one thread per Gaussian, plus the first step of the binning (hgs_common.h, BIN_*):
 // BIN_BY_CELL (large frames): the workgroup takes part in a counting sort of the Gaussians by binning cell (the BIN_CELL x
@@ -155,8 +179,8 @@ struct FirstAdds {
 // (a plain store where nothing is added: v + 0.0f would turn a -0.0f into +0.0f)
 __device__ __forceinline__ float plus(float v, const float* other, size_t idx) { return other ? v + other[idx] : v; }
 
-template <int MODE>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256
-__global__ void __launch_bounds__(MODE != BIN_NONE ? BIN_GROUP : 256)
+template <int MODE, bool STAGE = false>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256; STAGE: at most SH_STAGE_THREADS
+__global__ void __launch_bounds__(STAGE ? SH_STAGE_THREADS : MODE != BIN_NONE ? BIN_GROUP : 256)
 preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                   const float* __restrict__ colors_precomp_, const float* __restrict__ opacities_,
                   const float* __restrict__ scales_, const float* __restrict__ rots_,
@@ -172,6 +196,31 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
     const int num_tiles = cam.gx * cam.gy;
     const int cells_x = (cam.gx + BIN_CELL - 1) / BIN_CELL, num_cells = cells_x * ((cam.gy + BIN_CELL - 1) / BIN_CELL);
     const int i = blockIdx.x * NT + threadIdx.x;
+    // ---- STAGE: the wave's SH rows on their way into LDS before anything else is asked of memory ----
+    const int lane = threadIdx.x & 63;
+    bool staged = false;        // (wave-uniform) this wave's rows are one block of one array: they come through LDS
+    const float4* my_row = nullptr;
+    if (STAGE) {
+        const int wave_first = __builtin_amdgcn_readfirstlane(i - lane);
+        const bool wave_second = wave_first >= in2.P1;
+        const int seg_end = wave_second ? P : in2.P1;
+        const int rows = min(64, seg_end - wave_first);
+        const float* shs_w = wave_second ? in2.shs : shs_;
+        staged = wave_first < P && shs_w != nullptr && (wave_second ? in2.M : cam.M) == 16 && cam.D > 0 && wave_first + rows >= min(wave_first + 64, P);
+        const int bin_words = MODE == BIN_BY_CELL ? 2 * num_cells : MODE == BIN_IN_ORDER ? num_tiles : 0;
+        float4* stage = reinterpret_cast<float4*>(bin_lds + ((bin_words + 3) & ~3)) + (size_t)(threadIdx.x >> 6) * SH_STAGE_F4;
+        my_row = stage + lane * 12;
+        if (staged) {
+            const int nq = (3 * (cam.D + 1) * (cam.D + 1) + 3) / 4;   // float4 per row that hold coefficients of the active degree
+            const float4* src = reinterpret_cast<const float4*>(shs_w + (size_t)(wave_second ? wave_first - in2.P1 : wave_first) * 48);
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int slot = it * 64 + lane, r = slot / 12, sl = slot - r * 12, q = sl ^ ((r >> 1) & 3);
+                if (r < rows && q < nq)
+                    __builtin_amdgcn_global_load_lds(src + r * 12 + q, (__attribute__((address_space(3))) void*)(stage + it * 64), 16, 0, 0);
+            }
+        }
+    }
     if (MODE != BIN_NONE)
         for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
     // Housekeeping that would otherwise be another launch: when the caller will run backward, its [P,12] gradient
@@ -269,6 +318,16 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
                         sh_basis(cam.D, dx, dy, dz, B);
                         const float* sh = shs + j * M * 3;
                         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+                        if (STAGE && staged) {
+                            // the wave's LDS-DMA has landed once its own vmcnt says so (nothing else orders a ds_read behind it)
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const int f = (lane >> 1) & 3;
+                            switch (cam.D) {
+                                case 1: sh_dot_staged<4>(B, my_row, f, acc0, acc1, acc2); break;
+                                case 2: sh_dot_staged<9>(B, my_row, f, acc0, acc1, acc2); break;
+                                default: sh_dot_staged<16>(B, my_row, f, acc0, acc1, acc2); break;
+                            }
+                        } else
                         // the number of coefficients is a compile-time constant inside each case, so all their loads are
                         // issued before the first is waited for (a runtime trip count made it one round trip per coefficient)
                         switch (cam.D) {
@@ -332,19 +391,21 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         __syncthreads();  // hist zeroed
         for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
         __syncthreads();
-        // eight tiles per thread and round: the returning atomics of a round are all in flight together
+        // sixteen tiles per thread and round: the returning atomics of a round are all in flight together (the SMPL template's
+        // groups are ONE wave each: the 1 024 tiles of a 512x512 frame are one round trip, not two)
+        constexpr int U = 16;
         uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
-        for (int t0 = threadIdx.x; t0 < num_tiles; t0 += 8 * NT) {
-            uint32_t c[8], base[8];
+        for (int t0 = threadIdx.x; t0 < num_tiles; t0 += U * NT) {
+            uint32_t c[U], base[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int t = t0 + u * NT;
                 c[u] = t < num_tiles ? hist[t] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&counters[t0 + u * NT], c[u]) : 0u;
+            for (int u = 0; u < U; ++u) base[u] = c[u] ? atomicAdd(&counters[t0 + u * NT], c[u]) : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < U; ++u)
                 if (c[u]) my_runs[t0 + u * NT] = base[u];
         }
     }
@@ -358,14 +419,40 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
                            a.seg2.rotations, a.seg2.cov3D_precomp};
 #define HGS_K1_ARGS P, cam, a.means3D, a.shs, a.colors_precomp, a.opacities, a.scales, a.rotations, a.cov3D_precomp, in2, a.s.viewmatrix, \
                     a.s.projmatrix, a.s.campos, splats, tiles_touched, a.radii, a.visible
-    if (mode == BIN_BY_CELL)
-        hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((P + group - 1) / group), dim3(group),
-                           2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy), st, HGS_K1_ARGS, counters, cell_slot, nullptr,
-                           (float4*)a.grad_accum_to_zero);
-    else if (mode == BIN_IN_ORDER)
-        hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((P + group - 1) / group), dim3(group),
-                           sizeof(uint32_t) * cam.gx * cam.gy, st, HGS_K1_ARGS, counters, nullptr, run_start, (float4*)a.grad_accum_to_zero);
-    else
+    // SH rows through LDS (degree >= 1 on the [P,16,3] layout): 12 KB per wave next to the binning arrays, when a binning group's
+    // waves fit one CU's LDS.  OFF by default (HGS_K1_STAGE_SH=1 turns it on): round 5 measured it no faster -- C2 21.7-22.0 us
+    // against 21.4-21.5 (HIP events), 100k 17.1 against 16.9, 50k 14.0 against 13.3 -- the kernel is a chain of dependent round trips
+    // (mean -> scale / rotation -> opacity / SH -> cell or tile atomics), not short of load bandwidth, and the staging buffers cut the
+    // CU from 20 resident waves to 13.  Bit-identical either way (tests/test_gpu_parity.py::test_sh_rows_through_lds...).
+    const bool wants_stage = switches().k1_stage_sh && a.shs && a.s.sh_degree > 0 && (a.M == 16 || (a.seg2.P > 0 && a.seg2.M == 16));
+    const size_t stage_bytes = sizeof(float4) * SH_STAGE_F4;
+    if (mode == BIN_BY_CELL) {
+        const size_t bin_bytes = 2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy);
+        // (the staging buffers cut the CU from 20 resident waves to 13: the launch stays ONE round of workgroups only when a whole
+        //  binning group's waves fit one CU's LDS -- 256-thread workgroups, three per CU, were measured at 36.5 us against 21.4 on C2:
+        //  782 workgroups on 768 slots are two rounds)
+        static const bool big_lds_ok = hipFuncSetAttribute((const void*)preprocess_kernel<BIN_BY_CELL, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           160 * 1024) == hipSuccess;
+        const size_t staged_total = ((bin_bytes + 15) & ~(size_t)15) + (size_t)((group + 63) / 64) * stage_bytes;
+        if (wants_stage && big_lds_ok && group <= 832 && staged_total <= 160 * 1024) {
+            hipLaunchKernelGGL((preprocess_kernel<BIN_BY_CELL, true>), dim3((P + group - 1) / group), dim3(group), staged_total, st,
+                               HGS_K1_ARGS, counters, cell_slot, nullptr, (float4*)a.grad_accum_to_zero);
+        } else
+            hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((P + group - 1) / group), dim3(group), bin_bytes, st, HGS_K1_ARGS, counters, cell_slot, nullptr,
+                               (float4*)a.grad_accum_to_zero);
+    } else if (mode == BIN_IN_ORDER) {
+        const size_t bin_bytes = sizeof(uint32_t) * cam.gx * cam.gy;
+        const size_t staged_total = ((bin_bytes + 15) & ~(size_t)15) + (size_t)((group + 63) / 64) * stage_bytes;
+        // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
+        static const bool big_lds_ok = hipFuncSetAttribute((const void*)preprocess_kernel<BIN_IN_ORDER, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           160 * 1024) == hipSuccess;
+        if (wants_stage && group <= SH_STAGE_THREADS && staged_total <= (big_lds_ok ? 160 * 1024 : 64 * 1024))
+            hipLaunchKernelGGL((preprocess_kernel<BIN_IN_ORDER, true>), dim3((P + group - 1) / group), dim3(group), staged_total, st, HGS_K1_ARGS, counters, nullptr,
+                               run_start, (float4*)a.grad_accum_to_zero);
+        else
+            hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((P + group - 1) / group), dim3(group), bin_bytes, st, HGS_K1_ARGS, counters, nullptr, run_start,
+                               (float4*)a.grad_accum_to_zero);
+    } else
         hipLaunchKernelGGL(preprocess_kernel<BIN_NONE>, dim3((P + 255) / 256), dim3(256), 0, st, HGS_K1_ARGS, nullptr, nullptr,
                            nullptr, (float4*)a.grad_accum_to_zero);
 #undef HGS_K1_ARGS

@@ -1419,3 +1419,74 @@ def test_trained_scene_profile_at_1080p(device):
         r = refg[k]
         assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
     assert rel_l2(means2D.grad.cpu().numpy(), refg["means2D"]) <= GRAD_REL_TOL
+
+
+@pytest.mark.parametrize("name", ["basic_d3", "big_splats", "deg1_ragged"])
+def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, device, monkeypatch):
+    """Round 5: a frame of few tiles that is enqueued before N is known has no tile scan kernel -- emit's workgroups prefix-sum the
+    tile counts themselves and one extra workgroup of that launch writes ranges / N / flags (binning.hip, emit_scan_kernel).  Same N,
+    ranges, sorted list and image as with the stand-alone kernel (HGS_EMIT_SCAN=0), with an ample guess of N and with one that is
+    too small (the gated frame is run again from the scan's results); the self-cleaning counters are clean for the frame after."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _debug_forward_state
+    _force_ctypes_binding(monkeypatch)      # (the hint is injected through the Python binding's hook)
+    sc = make_scene(**CASES[name])
+    t = gpu_tensors(sc, device, grad=False)
+    kw = dict(shs=t["shs"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+    key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])
+    dgr._last_num_rendered.pop(key, None)
+    c0, r0, s0 = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), **kw)   # no guess: the scan kernel
+    n = s0["N"]
+    assert n > 1000
+    for folded in ("1", "0"):
+        monkeypatch.setenv("HGS_EMIT_SCAN", folded)
+        reload_switches()
+        for guess in (dgr._round_capacity(n), 100, dgr._round_capacity(n)):
+            monkeypatch.setattr(dgr, "_capacity_hint", lambda k, g=guess: (g, 0))
+            c1, r1, s1 = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), **kw)
+            assert s1["N"] == n and s1["binning_capacity"] == (n if guess == 100 else guess)
+            assert torch.equal(c1, c0) and torch.equal(r1, r0)
+            for k in ("ranges", "values", "quad_masks", "pos1", "keys", "n_contrib", "final_T"):
+                assert torch.equal(s1[k], s0[k]), (folded, guess, k)
+
+
+@pytest.mark.parametrize("name", ["basic_d3", "rotcam_d2", "deg1_ragged", "single"])
+@pytest.mark.parametrize("mode", ["order", "cell"])
+def test_sh_rows_through_lds_give_the_same_colours(name, mode, device, monkeypatch):
+    """HGS_K1_STAGE_SH=1 (round 5; measured no faster, off by default): the preprocess kernel fetches a wave's 64 SH rows as one
+    contiguous block by LDS-DMA into a swizzled LDS image and every thread reads its row from there.  Same coefficients, same
+    summation order: every projected field, the lists and the image are bit-identical -- on ragged tails, both binning modes, every
+    degree >= 1 and the second segment."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = make_scene(**CASES[name])
+    monkeypatch.setenv("HGS_BIN_MODE", mode)
+    t = gpu_tensors(sc, device, grad=False)
+    kw = dict(shs=t["shs"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+    out = {}
+    for staged in ("0", "1"):
+        monkeypatch.setenv("HGS_K1_STAGE_SH", staged)
+        reload_switches()
+        out[staged] = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), **kw)
+    (c0, r0, s0), (c1, r1, s1) = out["0"], out["1"]
+    assert torch.equal(c0, c1) and torch.equal(r0, r1) and s0["N"] == s1["N"]
+    for k in ("splats", "ranges", "values", "quad_masks", "n_contrib", "final_T"):
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_sh_rows_through_lds_with_a_second_segment(device, monkeypatch):
+    """... and with two sets of Gaussians whose boundary falls inside a wave (that wave keeps the per-thread loads)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = make_scene(P=700, H=96, W=128, seed=41, D=2)
+    cut = 333
+    t = gpu_tensors(sc, device, grad=False)
+    out = {}
+    for staged in ("0", "1"):
+        monkeypatch.setenv("HGS_K1_STAGE_SH", staged)
+        reload_switches()
+        keys = ("means3D", "opacities", "shs", "scales", "rotations")
+        a = {k: t[k][:cut].contiguous() for k in keys}
+        b = {k: t[k][cut:].contiguous() for k in keys}
+        with torch.no_grad():
+            out[staged] = GaussianRasterizer(gpu_settings(sc, device))(means3D=a["means3D"], means2D=torch.zeros(700, 3, device=device), opacities=a["opacities"],
+                                                                       shs=a["shs"], scales=a["scales"], rotations=a["rotations"], second=b)
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])

@@ -361,12 +361,22 @@ def main():
     # beside), more often on a short one (at least 8 launches are timed whenever --steps >= 8)
     every_nth = max(1, min(8, args.steps * KF // 8))   # (20 steps: every 2nd launch, ten samples)
     profile_enable((dominant,), every_nth=every_nth)
+    import diff_gaussian_rasterization as dgr
+    _lib = dgr._load()
+    torch.cuda.reset_peak_memory_stats(device)
     fence()
+    wait0 = _lib.hgs_debug_stat(b"forward_wait_ns")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         color, radii = step()
+    host_issue_s = time.perf_counter() - t0   # (the loop without the final drain)
     fence()
     elapsed = time.perf_counter() - t0
+    # host busy per frame: the loop's wall time minus what the library spent waiting for N (the host's only idle time inside it)
+    host_busy_us = (host_issue_s * 1e9 - (_lib.hgs_debug_stat(b"forward_wait_ns") - wait0)) / (args.steps * KF) * 1e-3
+    peak_mem = torch.cuda.max_memory_allocated(device)
+    _cpp = dgr._load_cpp()
+    ckpt_bytes, ckpt_used = _cpp.last_ckpt_info() if _cpp is not None else (None, None)
     prof = profile_read()
     profile_enable(())
     coll_dev = device if backend == "nccl" else torch.device("cpu")  # where the tiny metric collectives run
@@ -374,7 +384,6 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, coll_dev)
 
     # exact integers of this frame (shared with the oracle): N and the visible count
-    import diff_gaussian_rasterization as dgr
     N = dgr.last_frame_info()[0]
     Pv = int((radii > 0).sum())
     if N is None:
@@ -461,6 +470,9 @@ def main():
         "whole_frame": {"algorithmic_bytes": int(frame_B), "GB_per_s": round(frame_B * fps / world / 1e9, 2),
                         "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5),
                         "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
+        "host_busy_us_per_frame": round(host_busy_us, 1),
+        "memory": {"peak_allocated_MB": round(peak_mem / 2**20, 1), "checkpoint_buffer_MB": None if ckpt_bytes is None else round(ckpt_bytes / 2**20, 1),
+                   "checkpoint_slots_used": ckpt_used},
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),
         "stages_ms": stages,
         # the two per-Gaussian kernels are the ones on the HBM roofline: their algorithmic bytes

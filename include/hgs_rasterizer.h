@@ -156,6 +156,13 @@ typedef struct hgs_forward_args {
     /* Optional [P (+ seg2.P)] bytes: visible[i] = (radii[i] > 0) -- the `visibility_filter` the reference's render() derives with
      * a separate elementwise kernel (/root/reference/hugs/renderer/gs_renderer.py:159), written by the kernel that writes radii. */
     uint8_t *visible;
+    /* Optional guess (checkpoint SLOTS; 0 = none) of what the frame's checkpoints need -- e.g. the previous frame's
+     * hgs_forward_state.ckpt_slots_used plus a margin -- for a frame that sets backward_checkpoints and binning_capacity_hint: the
+     * HGS_BUF_CKPT buffer is then hgs_ckpt_bytes_for_slots(guess) instead of hgs_ckpt_bytes(capacity): a dense frame leaves
+     * checkpoints on its deep tiles only and uses a fraction of the 128 bytes per list entry the full layout holds.  A frame that
+     * needs more is detected on the device and run again, exactly sized, like one that overflows its binning buffer (results are
+     * identical either way; a deferred frame reports HGS_ERR_OVERFLOW from hgs_forward_poll instead). */
+    int64_t ckpt_slots_hint;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */
@@ -169,6 +176,9 @@ typedef struct hgs_forward_state {
     int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
     int32_t has_long_tiles;   /* !=0: some tile list is long by the scan kernel's rule (see expect_no_long_tiles; feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
+    int64_t ckpt_slots;       /* slots the checkpoint buffer was laid out for (0: none) */
+    int64_t ckpt_slots_used;  /* slots the frame's checkpoints need: (N >> 5) + tiles on a sparse frame, the deep tiles' packed count on a
+                                 dense one (0 when it left none); feeds the next frame's ckpt_slots_hint */
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */
@@ -369,6 +379,7 @@ size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_image_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 size_t hgs_ckpt_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
+size_t hgs_ckpt_bytes_for_slots(int64_t slots);   /* (hgs_forward_args.ckpt_slots_hint) */
 
 /* Per-stage device timing with HIP events recorded on the launch stream (the
  * reference has no profiling hooks; this is the build's own).  `stage_mask` has bit k set to time
@@ -408,7 +419,8 @@ size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int
  * currently keeps), "tile_counter_max_entries" (the bound beyond which idle streams' arrays are dropped), "slot_ring"
  * (result slots: forwards after which an unpolled deferred frame expires); host-time accounting since the library was loaded:
  * "forward_calls" / "forward_ns" (time inside hgs_rasterize_forward) / "forward_wait_ns" (the part of it spent waiting for N),
- * "backward_calls" / "backward_ns".  -1 for an unknown name. */
+ * "backward_calls" / "backward_ns"; "binning_reruns" / "ckpt_reruns" (optimistically enqueued frames that were run again because
+ * they needed more binning entries / checkpoint slots than guessed).  -1 for an unknown name. */
 int64_t hgs_debug_stat(const char *name);
 
 /* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE, HGS_EMIT_SCAN, HGS_K1_STAGE_SH)

@@ -85,6 +85,7 @@ struct ScanArgs {
     uint32_t* tile_count; int num_tiles; uint32_t* cell_count; int num_cells;
     uint2* ranges; uint32_t* cursor; uint32_t* n_total; uint32_t* large_tiles; uint32_t* seg_first; uint32_t capacity;
     unsigned long long* host_slot; uint32_t ticket, long_min_sparse, long_min_dense_arg;
+    uint32_t ckpt_cap;   // checkpoint slots the frame's buffer was laid out for (0: enough for whatever this frame needs)
 };
 
 // The scan as a workgroup of 1024 threads.  ZERO: re-zero the counters it has read (the stand-alone kernel, their only reader);
@@ -108,7 +109,8 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
-    if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull;
+    __shared__ uint32_t longest;   // the frame's longest list
+    if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull, longest = 0u;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
     if (ZERO)
         for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
@@ -116,6 +118,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0, carry2 = 0;
     uint32_t my_huge = 0, my_sparse = 0, my_shallow = 0, my_dense = 0;   // this thread's lists beyond each threshold
+    uint32_t my_longest = 0;
     // (a frame of at most 8 192 tiles is ONE trip of this loop: the number of non-empty tiles -- dense frame or sparse -- is then
     //  complete behind the trip's barrier, before the checkpoint slots are dealt)
     const bool single_trip = num_tiles <= 1024 * SCAN_ITEMS;
@@ -183,12 +186,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         for (int k = 0; k < SCAN_ITEMS; ++k) {
             st[k] = start;
             start += c[k];
-            // (which lists are long depends on what kind of frame this is, known at the end: count for every threshold it may choose)
-            if (t0 + k < num_tiles) {
-                my_huge += (c[k] > (uint32_t)SORT_CAP_MID ? 1u : 0u) + (c[k] > DEEP_BWD_MIN ? 0x10000u : 0u);   // (two 16-bit counts)
-                my_sparse += c[k] > long_min_sparse ? 1u : 0u;
-                my_shallow += c[k] > (uint32_t)LONG_MIN_SPARSE_SHALLOW ? 1u : 0u, my_dense += c[k] > long_min_dense ? 1u : 0u;
-            }
+            my_longest = max(my_longest, c[k]);   // (counts beyond num_tiles were read as zero)
         }
         if (t0 + SCAN_ITEMS <= num_tiles) {
             uint4* r4 = reinterpret_cast<uint4*>(ranges + t0);
@@ -234,7 +232,35 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     // the workgroup's counters (no broadcast, no barrier for it); a frame WITH long lists then collects them into the list the
     // long tiles' kernels and the deep workers walk (large_tiles, n_total[2]); one without (the bench workload) pays four adds
     // per tile and a wave reduction for all this.
+    // (round 5) ... and a frame WITHOUT long lists -- the bench workload, every point of the sweep -- does not count at all: one
+    // running maximum per tile in the pass above, one wave reduction, and the counting pass below is skipped when the frame's
+    // longest list is under the lowest threshold a frame of its kind can choose (round 4 counted for all four thresholds on every
+    // frame: +1.2-1.5 us of this one-workgroup kernel).
     {
+        uint32_t x = my_longest;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
+        if (lane == 0 && x) atomicMax(&longest, x);
+    }
+    __syncthreads();
+    const uint32_t sparse_kind = n_nonempty < 4096u ? 1u : 0u;
+    const uint32_t lowest = sparse_kind ? min(long_min_sparse, (uint32_t)LONG_MIN_SPARSE_SHALLOW) : long_min_dense;
+    if (longest > lowest) {   // (workgroup-uniform) count the lists beyond each threshold from the ranges this workgroup wrote
+        for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {
+            uint2 rg8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + u * 1024 + (int)threadIdx.x;
+                rg8[u] = t < num_tiles ? ranges[t] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t len = rg8[u].y - rg8[u].x;
+                my_huge += (len > (uint32_t)SORT_CAP_MID ? 1u : 0u) + (len > DEEP_BWD_MIN ? 0x10000u : 0u);   // (two 16-bit counts)
+                my_sparse += len > long_min_sparse ? 1u : 0u;
+                my_shallow += len > (uint32_t)LONG_MIN_SPARSE_SHALLOW ? 1u : 0u, my_dense += len > long_min_dense ? 1u : 0u;
+            }
+        }
         uint32_t v[4] = {my_huge, my_sparse, my_shallow, my_dense};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // wave sum in lane 63: DPP row shifts + row broadcasts
@@ -253,8 +279,8 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
             if (v[2]) atomicAdd(&n_large_shallow, v[2]);
             if (v[3]) atomicAdd(&n_large_dense, v[3]);
         }
-        if (threadIdx.x == 0) n_long_sh = 0u;
     }
+    if (threadIdx.x == 0) n_long_sh = 0u;
     __syncthreads();
     // more pairs than 32-bit positions can address (N_TOO_MANY and above are reserved): the gate closes whatever the
     // capacity, and the host is told N = 0xFFFFFFFF, which it turns into HGS_ERR_OVERFLOW
@@ -334,6 +360,13 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         if (threadIdx.x == 0) seg_first[num_tiles] = carry2;
         dense_slots = carry2;
     }
+    // The checkpoint buffer of a frame that was enqueued before its N was known is laid out for a GUESS of the slots it needs (round
+    // 5: the shape's last count + a quarter -- not the (capacity >> CKPT_SHIFT) + T of the sparse layout, 128 bytes per list entry,
+    // that a dense frame uses a tenth of).  A frame that needs more closes the gate exactly as one that overflows its binning
+    // buffer does: the kernels behind return at once and the host runs it again, exactly sized.
+    // (slots the frame's checkpoints need: the sparse layout's (N >> CKPT_SHIFT) + T, or a dense frame's packed count; 0: it leaves none)
+    const uint32_t ckpt_needed = !seg_first ? 0u : sparse ? (carry >> CKPT_SHIFT) + (uint32_t)num_tiles : dense_slots;
+    if (seg_first && sa.ckpt_cap && threadIdx.x == 0 && ckpt_needed > sa.ckpt_cap) n_total[1] = 1u;
     uint32_t n_long = 0;
     if (any_long) {   // (workgroup-uniform) the frame has long lists: collect them
         for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {   // (eight loads in flight per thread: a 1080p frame is one trip)
@@ -367,7 +400,9 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         __hip_atomic_store(host_slot + 1, (unsigned long long)n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot + 2, (unsigned long long)huge | ((unsigned long long)very_deep << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // word 3: checkpoint slots in use on a dense frame (0xFFFFFFFF: not a dense frame with checkpoints) -- the backward's grid
-        __hip_atomic_store(host_slot + 3, (unsigned long long)dense_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and, in the high half, the slots the frame's checkpoints need whatever its kind (the host sizes the next frame's buffer
+        // by it and recognises a frame the checkpoint gate closed)
+        __hip_atomic_store(host_slot + 3, (unsigned long long)dense_slots | ((unsigned long long)ckpt_needed << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -376,7 +411,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ScanArgs sa) { tile_sca
 
 static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
                                uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                               unsigned long long* host_slot, uint32_t ticket)
+                               unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap)
 {
     // (both at most SORT_CAP_SMALL: that is what the one-workgroup-per-tile sort holds)
     const Switches& sw = switches();
@@ -384,15 +419,15 @@ static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* ce
     const uint32_t long_min_sparse = clamped(sw.long_min_sparse, LONG_MIN_SPARSE), long_min_dense = clamped(sw.long_min_dense, LONG_MIN_DENSE);
     const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
     return ScanArgs{tile_count, num_tiles, cell_count, cell_count ? num_cells : 0, ranges, cursor, n_total, large_tiles, seg_first, capacity,
-                    host_slot, ticket, long_min_sparse, dense_arg};
+                    host_slot, ticket, long_min_sparse, dense_arg, ckpt_cap};
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
                       uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st)
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, hipStream_t st)
 {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st,
-                       make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket));
+                       make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,11 +828,11 @@ bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return bin_mode
 
 void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
                       uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, uint32_t* arrival, hipStream_t st)
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, uint32_t* arrival, hipStream_t st)
 {
     const int groups = (P + group - 1) / group, num_tiles = cam.gx * cam.gy;
     hipLaunchKernelGGL(emit_scan_kernel, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start,
-                       groups, keys, make_scan_args(tile_count, num_tiles, nullptr, 0, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket),
+                       groups, keys, make_scan_args(tile_count, num_tiles, nullptr, 0, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap),
                        arrival);
 }
 

@@ -137,6 +137,7 @@ struct ProfScope {
 // Host-time accounting (hgs_debug_stat): nanoseconds spent inside the two entry points and, of the forward's, spinning for N --
 // "host busy per frame" of a frame loop = (its wall time - forward_wait_ns) / frames.  Two clock reads per call.
 std::atomic<uint64_t> g_stat_fwd_calls{0}, g_stat_fwd_ns{0}, g_stat_wait_ns{0}, g_stat_bwd_calls{0}, g_stat_bwd_ns{0};
+std::atomic<uint64_t> g_stat_binning_reruns{0}, g_stat_ckpt_reruns{0};   // optimistically enqueued frames that were run again
 inline uint64_t now_ns()
 {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -482,6 +483,7 @@ size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return GeomLayout(P < 1
 size_t hgs_image_bytes(int32_t H, int32_t W) { return ImageLayout(H, W).total; }
 size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).total; }
 size_t hgs_ckpt_bytes(int64_t N, int32_t H, int32_t W) { return CkptLayout(N, num_tiles_of(H, W)).total; }
+size_t hgs_ckpt_bytes_for_slots(int64_t slots) { return CkptLayout((size_t)(slots < 1 ? 1 : slots)).total; }
 
 void hgs_reload_switches(void) { load_switches(); }
 
@@ -499,6 +501,8 @@ int64_t hgs_debug_stat(const char* name)
     if (!strcmp(name, "forward_wait_ns")) return (int64_t)g_stat_wait_ns.load();
     if (!strcmp(name, "backward_calls")) return (int64_t)g_stat_bwd_calls.load();
     if (!strcmp(name, "backward_ns")) return (int64_t)g_stat_bwd_ns.load();
+    if (!strcmp(name, "binning_reruns")) return (int64_t)g_stat_binning_reruns.load();
+    if (!strcmp(name, "ckpt_reruns")) return (int64_t)g_stat_ckpt_reruns.load();
     return -1;
 }
 
@@ -598,12 +602,17 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // HGS_EMIT_SCAN=0: always the stand-alone scan kernel (A/B measurements, the equivalence test).
     bool scan_pending = switches().emit_scan && hint > 0 && emit_scan_applies(bin_mode, num_tiles, group);
     uint32_t* const seg_first_arg = want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr;
+    // checkpoint slots an optimistically enqueued frame's buffer is laid out for: the caller's guess, else the most a frame that
+    // fits the binning guess can need; the scan closes the gate on a frame that needs more.  (No binning guess: the buffer is
+    // sized after N and the frame's kind are known.)
+    const size_t ckpt_slots_guess = !want_ckpt || hint <= 0 ? 0 : a.ckpt_slots_hint > 0 ? (size_t)a.ckpt_slots_hint : CkptLayout::slots_for(hint, num_tiles);
+    const uint32_t ckpt_cap32 = (uint32_t)std::min<size_t>(ckpt_slots_guess, 0xFFFFFFFFu);
     if (!scan_pending) {
         { ProfScope ps(HGS_STAGE_SCAN, st);
           if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
           else if (bin_mode == BIN_NONE) launch_count(Ptot, cam, splats, tile_count, st);
           launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
-                           seg_first_arg, cap32, (unsigned long long*)slot.word, slot.ticket, st); }
+                           seg_first_arg, cap32, (unsigned long long*)slot.word, slot.ticket, ckpt_cap32, st); }
         STAGE_CHECK(dbg, st, "tile_scan");
         // the scan, which re-zeroes the counters, is enqueued: the next frame on this stream may have them
         tc_lease.scan_enqueued = true;
@@ -621,12 +630,13 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     FusedBlend fb{cam, (uint32_t)(Ptot - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0, Ckpt{}};
     // checkpoints for the depth-segmented backward: laid out for the same capacity as the binning buffer
     bool known_dense = false;  // (set once N and the frame's flags are known: a dense frame needs no checkpoint buffer)
+    size_t ckpt_slots_exact = 0;   // (set for the re-run of a frame whose needs are known)
     auto obtain_ckpt = [&](int64_t capacity) -> int {
         if (!want_ckpt || known_dense) return HGS_OK;
-        CkptLayout cl(capacity, num_tiles);
+        CkptLayout cl(ckpt_slots_exact ? ckpt_slots_exact : (capacity == hint && ckpt_slots_guess) ? ckpt_slots_guess : CkptLayout::slots_for(capacity, num_tiles));
         char* ck = obtain(HGS_BUF_CKPT, cl.total);
         if (!ck) return fail(HGS_ERR_ALLOC, "scratch allocation failed (checkpoints %zu B)", cl.total);
-        state->ckpt = ck, state->ckpt_bytes = cl.total;
+        state->ckpt = ck, state->ckpt_bytes = cl.total, state->ckpt_slots = (int64_t)cl.slots;
         fb.ck = Ckpt{(float4*)(ck + cl.state), (uint32_t*)(ck + cl.slot_tile), (const uint32_t*)(image + il.seg_first),
                      (uint32_t*)(image + il.quad_nproc), n_total + 3};
         return HGS_OK;
@@ -658,7 +668,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         if (scan_pending) {   // (the first, optimistic enqueue of such a frame; a re-run after an overflow finds the scan's results in place)
             { ProfScope ps(HGS_STAGE_EMIT_KEYS, st);
               launch_emit_scan(Ptot, cam, splats, run_start, group, keys, tile_count, ranges, cursor, n_total, large_tiles, seg_first_arg, cap32,
-                               (unsigned long long*)slot.word, slot.ticket, tile_count + arrival_at, st); }
+                               (unsigned long long*)slot.word, slot.ticket, ckpt_cap32, tile_count + arrival_at, st); }
             STAGE_CHECK(dbg, st, "emit + tile_scan");
             scan_pending = false;
             tc_lease.scan_enqueued = true;   // (its last workgroup re-zeroes the counters)
@@ -707,10 +717,16 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     state->num_rendered = N;
     state->sparse_frame = sparse ? 1 : 0;
     state->has_long_tiles = has_long ? 1 : 0;
-    if (!enqueued || N > hint) {
+    // checkpoint slots the frame needs (the high half of word 3 of its result slot, written by the scan)
+    const size_t ckpt_needed = !want_ckpt ? 0 : (size_t)(slot.word[3] >> 32);
+    state->ckpt_slots_used = (int64_t)ckpt_needed;
+    const bool ckpt_overflow = enqueued && state->ckpt && ckpt_needed > (size_t)state->ckpt_slots;   // (the scan closed the gate)
+    if (!enqueued || N > hint || ckpt_overflow) {
+        ckpt_slots_exact = ckpt_needed;
         // exact size known now (and whether there are long tiles); after a too-small guess the gated kernels above did
         // nothing, so the frame is simply enqueued again
         if (enqueued) HIP_TRY(hipMemsetAsync(n_total + 1, 0, sizeof(uint32_t), st));
+        if (enqueued) (N > hint ? g_stat_binning_reruns : g_stat_ckpt_reruns).fetch_add(1, std::memory_order_relaxed);
         known_dense = !sparse && hist.n_deep == 0;  // (a dense frame WITH lists beyond SORT_CAP_SMALL entries keeps its checkpoints: its deep tiles use them)
         if (known_dense) state->ckpt = nullptr, state->ckpt_bytes = 0, fb.ck = Ckpt{};
         if (int rc = enqueue_frame(N, has_long)) return rc;
@@ -749,6 +765,15 @@ int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
     if ((int64_t)n32 > state->binning_capacity)
         return fail(HGS_ERR_OVERFLOW, "deferred frame needed %u binning entries but was given %lld: its output is invalid, run it again",
                     n32, (long long)state->binning_capacity);
+    if (state->ckpt) {
+        const unsigned long long w3 = hs.word[3];
+        if (slot_state(*hs.word, ticket) != 1) return expired();   // (the slot was handed on between the two reads)
+        const int64_t needed = (int64_t)(w3 >> 32);   // (the exact figure the scan gated the frame with)
+        state->ckpt_slots_used = needed;
+        if (needed > state->ckpt_slots)
+            return fail(HGS_ERR_OVERFLOW, "deferred frame needed %lld checkpoint slots but was given %lld: its output is invalid, run it again",
+                        (long long)needed, (long long)state->ckpt_slots);
+    }
     state->num_rendered = (int64_t)n32;
     return state->num_rendered;
 }
@@ -783,7 +808,8 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
         return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size");
     Ckpt ck{};
     if (a.state.ckpt) {
-        CkptLayout cl(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered, cam.gx * cam.gy);
+        CkptLayout cl(a.state.ckpt_slots > 0 ? (size_t)a.state.ckpt_slots
+                                             : CkptLayout::slots_for(a.state.binning_capacity > 0 ? a.state.binning_capacity : a.state.num_rendered, cam.gx * cam.gy));
         if (a.state.ckpt_bytes < cl.total) return fail(HGS_ERR_INVALID_ARGUMENT, "forward state has the wrong size (checkpoints)");
         char* c = (char*)a.state.ckpt;
         ck = Ckpt{(float4*)(c + cl.state), (uint32_t*)(c + cl.slot_tile), (const uint32_t*)((const char*)a.state.image + il.seg_first),
@@ -801,7 +827,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
         const uint32_t index = (uint32_t)(a.state.n_token >> 32), ticket = (uint32_t)a.state.n_token;
         if (index < SLOT_RING && ticket != 0) {
             const volatile unsigned long long* w = g_slot_base + 8 * index;
-            const unsigned long long before = w[0], v3 = w[3], after = w[0];   // (the slot may be handed to a later frame any time)
+            const unsigned long long before = w[0], v3 = w[3] & 0xFFFFFFFFull, after = w[0];   // (the slot may be handed to a later frame any time)
             if (slot_state(before, ticket) == 1 && slot_state(after, ticket) == 1 && v3 != 0xFFFFFFFFull) dense_slots = (int64_t)v3;
         }
     }

@@ -160,8 +160,11 @@ struct ImageLayout {
 struct CkptLayout {
     size_t slot_tile, state, total;
     size_t slots;
-    CkptLayout(int64_t N, int num_tiles) {
-        slots = (size_t)((N < 0 ? 0 : N) >> CKPT_SHIFT) + (size_t)num_tiles;
+    // slots a frame of N list entries can need at most: the sparse layout (a dense frame packs its deep tiles' slots: far fewer)
+    static size_t slots_for(int64_t N, int num_tiles) { return (size_t)((N < 0 ? 0 : N) >> CKPT_SHIFT) + (size_t)num_tiles; }
+    CkptLayout(int64_t N, int num_tiles) : CkptLayout(slots_for(N, num_tiles)) {}
+    explicit CkptLayout(size_t slots_) {
+        slots = slots_ < 1 ? 1 : slots_;
         size_t o = 0;
         slot_tile = o;  o = align_up(o + 4 * slots);      // which tile a slot belongs to (written by the tile's forward workgroup)
         state = o;      o = align_up(o + 4096 * slots);   // float4 [slot][quad][lane]: (T, C0, C1, C2) before list position (k + 1) * CKPT_SEG
@@ -223,7 +226,7 @@ void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const 
 // (re-zeroes tile_count, and cell_count if given, behind itself)
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
                       uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, hipStream_t st);
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
                  const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // BIN_IN_ORDER frames of few tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
@@ -231,7 +234,7 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
 bool emit_scan_applies(int bin_mode, int num_tiles, int group);
 void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
                       uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, uint32_t* arrival, hipStream_t st);
+                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, uint32_t* arrival, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 // fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
 // Checkpoints of the forward blend for the depth-segmented backward; state == nullptr: none.  They are written only when

@@ -37,7 +37,7 @@ using torch::autograd::SavedVariable;
 using torch::autograd::variable_list;
 
 // ------------------------------------------------------------------------------------------------ per-shape memory
-struct Hint { int64_t n; bool has_long; bool sparse; uint64_t stamp = 0; };
+struct Hint { int64_t n; bool has_long; bool sparse; int64_t ckpt_used = 0; uint64_t stamp = 0; };
 using ShapeKey = std::tuple<int, int64_t, int64_t, int64_t>;   // (device, P, H, W)
 uint64_t g_hint_clock = 0;
 constexpr size_t HINT_SHAPES = 256;   // shapes remembered; the least recently used go first
@@ -60,6 +60,7 @@ bool g_upstream_scale_grad = false;   // HGS_BWD_UPSTREAM_SCALE_GRAD on every ba
 bool g_use_ckpt = true;   // leave checkpoints for the depth-segmented backward on sparse frames (HGS_BWD_SEGMENTED=0: off)
 thread_local int64_t t_last_n = -1, t_last_capacity = -1;
 thread_local bool t_last_long = false, t_last_sparse = false;
+thread_local int64_t t_last_ckpt_bytes = 0, t_last_ckpt_used = 0;
 
 // + 12.5 % + 4096, rounded up to 1/16 of the next power of two (at least 64 Ki entries): the same number as
 // diff_gaussian_rasterization._round_capacity -- frame after frame asks the caching allocator for the same size
@@ -70,6 +71,14 @@ int64_t round_capacity(int64_t n)
     while (p2 < want) p2 <<= 1;
     const int64_t granule = std::max<int64_t>(1 << 16, p2 >> 4);
     return (want + granule - 1) / granule * granule;
+}
+
+// checkpoint slots offered to a frame whose shape last used `used`: + 25 % + 64, in steps of 1 024 slots (4 MB) -- the same number as
+// diff_gaussian_rasterization._round_ckpt_slots; a frame that needs more is detected on the device and run again
+int64_t round_ckpt_slots(int64_t used)
+{
+    const int64_t want = used + used / 4 + 64;
+    return (want + 1023) / 1024 * 1024;
 }
 
 // Scratch of frames that need no backward (the reference's validation / animation / canonical loops run under no_grad,
@@ -316,6 +325,7 @@ void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer)
         if (g_use_hint && it != g_hints.end()) {
             a.binning_capacity_hint = round_capacity(it->second.n);
             a.expect_no_long_tiles = it->second.has_long ? 0 : 1;
+            if (a.backward_checkpoints && it->second.ckpt_used > 0) a.ckpt_slots_hint = round_ckpt_slots(it->second.ckpt_used);
         }
     }
     f.deferred = defer && a.binning_capacity_hint > 0 && P > 0;
@@ -324,7 +334,8 @@ void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer)
         // pre-sized scratch, no allocation callbacks: geom | image | binning(hint) [| checkpoints(hint)]
         const size_t g = align256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), im = align256(hgs_image_bytes((int32_t)H, (int32_t)W));
         const size_t b = a.binning_capacity_hint > 0 ? align256(hgs_binning_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
-        const size_t ck = b && a.backward_checkpoints ? align256(hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W)) : 0;
+        const size_t ck = !(b && a.backward_checkpoints) ? 0
+                          : align256(a.ckpt_slots_hint > 0 ? hgs_ckpt_bytes_for_slots(a.ckpt_slots_hint) : hgs_ckpt_bytes(a.binning_capacity_hint, (int32_t)H, (int32_t)W));
         // per frame when backward will need it, else the stream's arena
         f.scratch = needs_grad ? at::empty({(int64_t)(g + im + b + ck)}, bopts) : arena_for((int)dev.index(), (void*)stream, g + im + b + ck, bopts);
         char* base = (char*)f.scratch.data_ptr();
@@ -348,7 +359,7 @@ void finish_frame(Frame& f, hipStream_t stream)
         n = hgs_forward_poll(&f.bw.state, 1, (void*)stream);
         if (n == HGS_ERR_OVERFLOW || n == HGS_ERR_EXPIRED) {
             TORCH_CHECK(std::string(hgs_last_error()).find("2^32") == std::string::npos, "rasterize_gaussians: ", hgs_last_error());
-            a.defer_n = 0, a.binning_capacity_hint = 0, a.scratch[HGS_BUF_BINNING] = nullptr, a.scratch[HGS_BUF_CKPT] = nullptr;
+            a.defer_n = 0, a.binning_capacity_hint = 0, a.ckpt_slots_hint = 0, a.scratch[HGS_BUF_BINNING] = nullptr, a.scratch[HGS_BUF_CKPT] = nullptr;
             AllocCtx actx{&f.keep, at::TensorOptions().dtype(at::kByte).device(f.a.means3D.device())};
             n = hgs_rasterize_forward(&a, alloc_cb, &actx, &f.bw.state, (void*)stream);
         }
@@ -358,10 +369,11 @@ void finish_frame(Frame& f, hipStream_t stream)
     if (f.P1() + f.P2() == 0) n = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        remember_hint(f.key, Hint{n, f.bw.state.has_long_tiles != 0, f.bw.state.sparse_frame != 0});
+        remember_hint(f.key, Hint{n, f.bw.state.has_long_tiles != 0, f.bw.state.sparse_frame != 0, f.bw.state.ckpt_slots_used});
     }
     t_last_n = n, t_last_capacity = f.bw.state.binning_capacity;
     t_last_long = f.bw.state.has_long_tiles != 0, t_last_sparse = f.bw.state.sparse_frame != 0;
+    t_last_ckpt_bytes = (int64_t)f.bw.state.ckpt_bytes, t_last_ckpt_used = f.bw.state.ckpt_slots_used;
 }
 
 // ------------------------------------------------------------------------------------------------ the autograd node
@@ -647,16 +659,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("abi_version", [] { return (int)hgs_abi_version(); });
     m.def("last_frame_info", [] { return std::make_tuple(t_last_n, t_last_capacity, t_last_long, t_last_sparse); },
           "(N, binning capacity, has long tiles, sparse) of this thread's last forward");
-    m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse) {
+    m.def("last_ckpt_info", [] { return std::make_tuple(t_last_ckpt_bytes, t_last_ckpt_used); },
+          "(bytes of the checkpoint buffer, checkpoint slots used) of this thread's last forward");
+    m.def("set_hint", [](int dev, int64_t P, int64_t H, int64_t W, int64_t n, bool has_long, bool sparse, int64_t ckpt_used) {
         std::lock_guard<std::mutex> lk(g_mu);
-        remember_hint(std::make_tuple(dev, P, H, W), Hint{n, has_long, sparse});
-    }, py::arg("dev"), py::arg("P"), py::arg("H"), py::arg("W"), py::arg("n"), py::arg("has_long"), py::arg("sparse") = true);
+        remember_hint(std::make_tuple(dev, P, H, W), Hint{n, has_long, sparse, ckpt_used});
+    }, py::arg("dev"), py::arg("P"), py::arg("H"), py::arg("W"), py::arg("n"), py::arg("has_long"), py::arg("sparse") = true, py::arg("ckpt_used") = 0);
     m.def("get_hint", [](int dev, int64_t P, int64_t H, int64_t W) -> py::object {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_hints.find(std::make_tuple(dev, P, H, W));
         if (it == g_hints.end()) return py::none();
-        return py::make_tuple(it->second.n, it->second.has_long, it->second.sparse);
-    }, "(N, has long tiles, sparse) of the last frame of this shape, or None");
+        return py::make_tuple(it->second.n, it->second.has_long, it->second.sparse, it->second.ckpt_used);
+    }, "(N, has long tiles, sparse, checkpoint slots used) of the last frame of this shape, or None");
     m.def("clear_hints", [] { std::lock_guard<std::mutex> lk(g_mu); g_hints.clear(); });
     m.def("use_hints", [](bool on) { g_use_hint = on; });
     m.def("use_checkpoints", [](bool on) { g_use_ckpt = on; });

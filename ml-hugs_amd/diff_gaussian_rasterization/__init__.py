@@ -59,14 +59,14 @@ class _ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
                 ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
                 ("defer_n", C.c_int32), ("backward_checkpoints", C.c_int32), ("scratch", C.c_void_p * 4),
-                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment), ("visible", C.c_void_p)]
+                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment), ("visible", C.c_void_p), ("ckpt_slots_hint", C.c_int64)]
 
 
 class _ForwardState(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
                 ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
                 ("ckpt", C.c_void_p), ("ckpt_bytes", C.c_size_t), ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64), ("sparse_frame", C.c_int32),
-                ("has_long_tiles", C.c_int32), ("n_token", C.c_uint64)]
+                ("has_long_tiles", C.c_int32), ("n_token", C.c_uint64), ("ckpt_slots", C.c_int64), ("ckpt_slots_used", C.c_int64)]
 
 
 class _BackwardArgs(C.Structure):
@@ -121,8 +121,9 @@ def _load():
     lib.hgs_mark_visible.restype = C.c_int32
     lib.hgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hgs_last_error.restype = C.c_char_p
-    for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_ckpt_bytes, lib.hgs_scratch_offset):
+    for fn in (lib.hgs_geom_bytes, lib.hgs_image_bytes, lib.hgs_binning_bytes, lib.hgs_ckpt_bytes, lib.hgs_ckpt_bytes_for_slots, lib.hgs_scratch_offset):
         fn.restype = C.c_size_t
+    lib.hgs_ckpt_bytes_for_slots.argtypes = [C.c_int64]
     lib.hgs_ckpt_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.hgs_geom_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.hgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
@@ -265,6 +266,21 @@ _last_sparse = {}
 _USE_CKPT = os.environ.get("HGS_BWD_SEGMENTED", "1") != "0"
 
 
+_last_ckpt_used = {}   # checkpoint slots the last frame of a shape needed: sizes the next frame's checkpoint buffer
+
+
+def _round_ckpt_slots(used):
+    """+ 25 % + 64, in steps of 1 024 slots (4 MB); csrc_torch/hgs_torch.cpp round_ckpt_slots computes the same number"""
+    want = used + used // 4 + 64
+    return (want + 1023) // 1024 * 1024
+
+
+def _ckpt_hint(key):
+    """hgs_forward_args.ckpt_slots_hint from the previous frame of this shape (0: none -- the full layout)"""
+    used = _last_ckpt_used.get(key, 0) if _USE_HINT else 0
+    return _round_ckpt_slots(used) if used > 0 else 0
+
+
 _HINT_SHAPES = 256   # shapes remembered (densification changes P all the time: do not grow without bound)
 
 
@@ -277,6 +293,7 @@ def _remember(key, n, has_long, sparse=None, to_cpp=True):
         del _last_num_rendered[old]
         _max_num_rendered.pop(old, None)
         _last_sparse.pop(old, None)
+        _last_ckpt_used.pop(old, None)
     if sparse is not None:
         _last_sparse[key] = bool(sparse)
     if to_cpp and _cpp is not None:   # ... and what the Python paths learnt, the C++ node uses
@@ -365,12 +382,14 @@ def _arena(dev, stream_id, nbytes):
     return t
 
 
-def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=None, checkpoints=False):
+def _provide_scratch(args, lib, dev, P, H, W, capacity, persistent_for_stream=None, checkpoints=False, ckpt_slots=0):
     """Pre-sized scratch handed to the library through args.scratch (no allocation callbacks): one buffer holding geom |
     image | binning(capacity) [| checkpoints(capacity)].  Returns (buffer, (offsets))."""
     g, im = _align(lib.hgs_geom_bytes(P, H, W)), _align(lib.hgs_image_bytes(H, W))
     b = _align(lib.hgs_binning_bytes(capacity, H, W)) if capacity > 0 else 0
-    ck = _align(lib.hgs_ckpt_bytes(capacity, H, W)) if (capacity > 0 and checkpoints) else 0
+    ck = 0
+    if capacity > 0 and checkpoints:
+        ck = _align(lib.hgs_ckpt_bytes_for_slots(ckpt_slots) if ckpt_slots > 0 else lib.hgs_ckpt_bytes(capacity, H, W))
     total = g + im + b + ck
     buf = _arena(dev, persistent_for_stream, total) if persistent_for_stream is not None else \
         torch.empty(total, dtype=torch.uint8, device=dev)
@@ -496,8 +515,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch = None
             if P > 0:
                 # pre-sized scratch, no allocation callbacks: per frame when backward will need it, else the stream's arena
+                if args.backward_checkpoints and args.binning_capacity_hint > 0:
+                    args.ckpt_slots_hint = _ckpt_hint(hint_key)
                 scratch = _provide_scratch(args, lib, dev, P, H, W, int(args.binning_capacity_hint),
-                                           None if needs_grad else stream, bool(args.backward_checkpoints))
+                                           None if needs_grad else stream, bool(args.backward_checkpoints), int(args.ckpt_slots_hint))
             n = lib.hgs_rasterize_forward(C.byref(args), cb, None, C.byref(state), C.c_void_p(stream))
         finally:
             if prev_dev != dev.index:
@@ -510,6 +531,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.binning_capacity = int(state.binning_capacity)
         _last_frame_info = (ctx.num_rendered, ctx.binning_capacity)
         _remember(hint_key, int(n), bool(state.has_long_tiles), bool(state.sparse_frame))
+        _last_ckpt_used[hint_key] = int(state.ckpt_slots_used)
         ctx.bw, ctx.slab, ctx.keep, ctx.dims = bw, slab, keep, (P1, M, P2, M2)
         ctx.scratch, ctx.bufs = scratch, bufs   # kept alive for backward (and read by _debug_forward_state)
         empty = torch.empty(0, device=dev)

@@ -1490,3 +1490,66 @@ def test_sh_rows_through_lds_with_a_second_segment(device, monkeypatch):
             out[staged] = GaussianRasterizer(gpu_settings(sc, device))(means3D=a["means3D"], means2D=torch.zeros(700, 3, device=device), opacities=a["opacities"],
                                                                        shs=a["shs"], scales=a["scales"], rotations=a["rotations"], second=b)
     assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+
+
+def test_checkpoint_buffer_follows_what_the_shape_used_and_an_underestimate_is_repaired(device):
+    """Round 5: the checkpoint buffer of a frame that is enqueued before its N is known is laid out for the slots
+    the shape's last frame USED (+ 25 %), not for the sparse layout's 128 bytes per list entry; a frame that needs more -- here:
+    the same shape with the stacked splats 2.6 times larger, more than twice the deep tiles' slots, announced with the right N
+    but the small frame's slot count -- is detected by the scan kernel, the gated frame is run again exactly sized, and image and
+    gradients are those of a frame rendered without any guess."""
+    import diff_gaussian_rasterization as dgr
+    from hugs_amd import synthetic as syn
+    cpp = dgr._load_cpp()
+    if cpp is None:
+        pytest.skip("the C++ binding is not built / not selected")
+    lib = dgr._load()
+    stat = lambda k: lib.hgs_debug_stat(k.encode())
+    H = W = 1088
+    sc = _stacked_scene(9000, H, W, seed=31, spread_px=14.0)
+    bgd = syn.scene_gaussians(20_000, sc["cam"], seed=32, sigma_px=2.0)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        sc[k] = np.concatenate([sc[k], np.asarray(bgd[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    big = dict(sc)
+    big["scales"] = sc["scales"].copy()
+    big["scales"][:9000] *= 2.6
+    P = sc["means3D"].shape[0]
+    dL = to_dev(sc["dL_dpix"], device)
+    grads = lambda t: {k: t[k].grad.detach().clone() for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations")}
+
+    def frame(scene):
+        t, c, r = run_gpu(scene, device)
+        info = {"ckpt_bytes": cpp.last_ckpt_info()[0], "slots": cpp.last_ckpt_info()[1], "N": cpp.last_frame_info()[0],
+                "capacity": cpp.last_frame_info()[1]}
+        c.backward(dL)
+        torch.cuda.synchronize()
+        return c.detach().clone(), r.clone(), grads(t), info
+
+    cpp.use_hints(False)    # references: every frame waits for N and is sized exactly
+    try:
+        cpp.clear_hints()
+        frame(sc)           # (the shape's record in the LIBRARY: the second frame of a dense shape with deep lists leaves checkpoints)
+        ref_small = frame(sc)
+        ref_big = frame(big)
+    finally:
+        cpp.use_hints(True)
+    small, large = ref_small[3], ref_big[3]
+    assert small["slots"] > 0 and large["slots"] > 2 * small["slots"], (small, large)
+    assert small["ckpt_bytes"] <= 4100 * small["slots"] + 8192     # sized exactly: no guess was involved
+    cpp.clear_hints()
+    frame(sc)
+    a = frame(sc)           # hinted: the buffer follows what the frame before used
+    assert a[3]["slots"] == small["slots"] and a[3]["capacity"] > a[3]["N"]
+    assert a[3]["ckpt_bytes"] <= 4100 * dgr._round_ckpt_slots(small["slots"]) + 8192
+    assert a[3]["ckpt_bytes"] < lib.hgs_ckpt_bytes(a[3]["capacity"], H, W) // 4       # (the full layout for the same capacity)
+    # the big frame announced with its own N (so the binning buffer fits) but the small frame's slots: only the checkpoints overflow
+    cpp.set_hint(torch.device(device).index or 0, P, H, W, large["N"], True, False, small["slots"])
+    reruns, bin_reruns = stat("ckpt_reruns"), stat("binning_reruns")
+    b = frame(big)
+    assert stat("ckpt_reruns") == reruns + 1 and stat("binning_reruns") == bin_reruns
+    c = frame(big)          # and the next frame's guess follows what this one used
+    assert stat("ckpt_reruns") == reruns + 1 and c[3]["slots"] == large["slots"]
+    for got, ref in ((a, ref_small), (b, ref_big), (c, ref_big)):
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        for k in got[2]:
+            assert rel_l2(got[2][k].cpu().numpy(), ref[2][k].cpu().numpy()) <= order_tol(k), k

@@ -56,6 +56,7 @@ class GaussianSet:
         self.grad_accum, self.denom = torch.zeros(n, 1, device=dev), torch.zeros(n, 1, device=dev)
         self.max_radii2D = torch.zeros(n, device=dev)
 
+    noise_gen = None
     fused_forward = False   # the scene model goes through the fused SceneGS.forward of row f-6, the human through the torch statements
 
     def activated(self):
@@ -103,7 +104,9 @@ class GaussianSet:
                 R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), 1).view(-1, 3, 3)
-                offs = torch.bmm(R, (torch.randn_like(sc) * sc).unsqueeze(-1)).squeeze(-1)
+                # (noise_gen: a CPU generator when two fits on different devices must split alike, tests/test_psnr_parity.py)
+                noise = torch.randn(sc.shape, generator=self.noise_gen).to(sc) if self.noise_gen is not None else torch.randn_like(sc)
+                offs = torch.bmm(R, (noise * sc).unsqueeze(-1)).squeeze(-1)
                 new = {k: v.detach()[split].repeat(2, *([1] * (v.dim() - 1))) for k, v in self.p.items()}
                 new["xyz"] = new["xyz"] + offs
                 new["scaling"] = torch.log(sc / (0.8 * 2))

@@ -29,7 +29,7 @@ def stream_copy_gbps(nbytes=1 << 30, iters=20):
 
 def main():
     out = {"hbm_stream_copy_GBps_measured": round(stream_copy_gbps(), 1), "hbm_peak_GBps_datasheet": 8000.0, "points": []}
-    for P in (50_000, 100_000, 200_000, 300_000, 500_000, 1_000_000):
+    for P in (50_000, 100_000, 200_000, 300_000, 500_000, 1_000_000, 2_097_152):   # (the last: max_n_gaussians of hugs_scene.yaml:117)
         row = {"gaussians": P}
         for mode, flag in (("fwd", ["--forward-only"]), ("fwd_bwd", [])):
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--steps", "300", "--warmup", "40",

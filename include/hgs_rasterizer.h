@@ -423,7 +423,7 @@ size_t hgs_scratch_offset(const char *name, int32_t P, int64_t num_rendered, int
  * they needed more binning entries / checkpoint slots than guessed).  -1 for an unknown name. */
 int64_t hgs_debug_stat(const char *name);
 
-/* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE, HGS_EMIT_SCAN, HGS_K1_STAGE_SH)
+/* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE, HGS_EMIT_SCAN, HGS_K1_STAGE_SH, HGS_BIG_PER_GROUP)
  * from the environment once, at its first frame; a test or A/B tool that changes them inside one process calls this afterwards. */
 void hgs_reload_switches(void);
 

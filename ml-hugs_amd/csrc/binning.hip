@@ -462,9 +462,34 @@ __device__ __forceinline__ float max_power_in_quad(float sx, float sy, float A, 
 // binning cell up to the last step: cell_count[c] = population of cell c, cell_slot[i] = (cell, slot inside the cell).
 // cell_scatter: every workgroup prefix-sums the (<= BIN_MAX_CELLS) populations for itself and writes its Gaussians'
 // indices to order[start(cell) + slot]; the total -- the Gaussians that touch a tile at all -- goes to windows[groups].x.
+// Which Gaussian entry `tid` of binning group `block` is (P: none).  `tot` = (regular entries, where the big splats' groups begin
+// -- the regular count rounded up to a whole group --, number of big splats, 0), written by cell_scatter_kernel: regular groups are
+// runs of G entries of `order`; the first BIG_GROUPS_CAP groups behind them hold B big splats each in their first B slots; big
+// splats beyond that fill whole groups.
+__device__ __forceinline__ uint32_t big_groups_extent(const uint4 tot, uint32_t G, uint32_t B)
+{
+    const uint32_t n_big = tot.z;
+    if (n_big == 0u || B == 0u) return tot.x;
+    const uint32_t cap = (uint32_t)BIG_GROUPS_CAP * B;
+    return n_big <= cap ? tot.y + (n_big + B - 1u) / B * G : tot.y + (uint32_t)BIG_GROUPS_CAP * G + (n_big - cap);
+}
+__device__ __forceinline__ int group_member(const uint4 tot, uint32_t G, uint32_t B, uint32_t block, uint32_t tid, const uint32_t* __restrict__ order, int P)
+{
+    const uint32_t first = block * G;
+    if (first < tot.y || tot.z == 0u || B == 0u) return first + tid < tot.x ? (int)order[first + tid] : P;
+    const uint32_t bg = (first - tot.y) / G;
+    if (bg < (uint32_t)BIG_GROUPS_CAP) {
+        // (the B big splats of a padded group sit G / B slots apart: two or three per wave -- the count kernel walks a big splat's
+        //  tiles with the WAVE that holds it, and B of them in the group's first wave were measured slower than round 4's spreading)
+        const uint32_t stride = G >= B ? G / B : 1u, j = tid / stride;
+        return (tid - j * stride == 0u && j < B && bg * B + j < tot.z) ? (int)order[first + tid] : P;
+    }
+    return (uint32_t)BIG_GROUPS_CAP * B + (first - tot.y - (uint32_t)BIG_GROUPS_CAP * G) + tid < tot.z ? (int)order[first + tid] : P;
+}
+
 __global__ void __launch_bounds__(256)
 cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_count, const uint2* __restrict__ cell_slot,
-                    uint32_t* __restrict__ order, uint4* __restrict__ total_out)
+                    uint32_t* __restrict__ order, uint4* __restrict__ total_out, uint32_t G, uint32_t B)
 {
     __shared__ uint32_t start[BIN_MAX_CELLS];
     __shared__ uint32_t wsum[4];
@@ -473,6 +498,7 @@ cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_coun
     uint32_t c[PER], mine = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) c[k] = tid * PER + k < num_cells ? cell_count[tid * PER + k] : 0u, mine += c[k];
+    const uint32_t n_big = cell_count[num_cells];   // the big cell (preprocess.hip)
     const uint32_t incl = wave_inclusive_scan(mine);
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
@@ -486,12 +512,18 @@ cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_coun
     uint32_t run = before + incl - mine;
 #pragma unroll
     for (int k = 0; k < PER; ++k) start[tid * PER + k] = run, run += c[k];
-    if (blockIdx.x == 0 && tid == 0) *total_out = make_uint4(total, 0u, 0u, 0u);
+    const uint32_t big_start = (total + G - 1u) / G * G;
+    if (blockIdx.x == 0 && tid == 0) *total_out = make_uint4(total, big_start, n_big, 0u);
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     if (i < P) {
         const uint2 cs = cell_slot[i];
-        if (cs.x != 0xFFFFFFFFu) order[start[cs.x] + cs.y] = (uint32_t)i;
+        if (cs.x == (uint32_t)num_cells) {   // a big splat: slot s of the big cell
+            const uint32_t s = cs.y, cap = (uint32_t)BIG_GROUPS_CAP * B;
+            const uint32_t stride = G >= B ? G / B : 1u;
+            order[s < cap ? big_start + (s / B) * G + (s % B) * stride : big_start + (uint32_t)BIG_GROUPS_CAP * G + (s - cap)] = (uint32_t)i;
+        } else if (cs.x != 0xFFFFFFFFu)
+            order[start[cs.x] + cs.y] = (uint32_t)i;
     }
 }
 
@@ -501,19 +533,19 @@ cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_coun
 // the tile's segment -- and leaves it in run_start[g][tile] for emit, which shares the partition.
 __global__ void __launch_bounds__(BIN_GROUP)
 group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ order,
-                   uint4* __restrict__ windows, int groups, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start)
+                   uint4* __restrict__ windows, int groups, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start, uint32_t B)
 {
     extern __shared__ uint32_t hist[];  // [num_tiles], only the window is used
     __shared__ int win[4];              // min x, min y, max x (exclusive), max y (exclusive), in tiles
     const int NT = (int)blockDim.x, tid = threadIdx.x, lane = tid & 63;
-    const uint32_t n_alive = windows[groups].x;
+    const uint4 tot = windows[groups];
     const uint32_t first = (uint32_t)blockIdx.x * (uint32_t)G;
-    if (first >= n_alive) {  // (uniform) nothing left for this group
+    if (first >= big_groups_extent(tot, (uint32_t)G, B)) {  // (uniform) nothing left for this group
         if (tid == 0) windows[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     if (tid == 0) win[0] = win[1] = 0x7FFFFFFF, win[2] = win[3] = 0;
-    SplatRect mine = load_rect(P, cam, splats, first + (uint32_t)tid < n_alive ? (int)order[first + tid] : P, false);
+    SplatRect mine = load_rect(P, cam, splats, group_member(tot, (uint32_t)G, B, blockIdx.x, (uint32_t)tid, order, P), false);
     // the window: wave-level min / max, then one LDS atomic per wave and bound
     int lo_x = mine.cnt ? mine.minx : 0x7FFFFFFF, lo_y = mine.cnt ? mine.miny : 0x7FFFFFFF;
     int hi_x = mine.cnt ? mine.minx + mine.width : 0, hi_y = mine.cnt ? mine.miny + (int)(mine.cnt / (uint32_t)mine.width) : 0;
@@ -525,6 +557,10 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     __syncthreads();  // win initialised
     if (lane == 0 && hi_x > lo_x) atomicMin(&win[0], lo_x), atomicMin(&win[1], lo_y), atomicMax(&win[2], hi_x), atomicMax(&win[3], hi_y);
     __syncthreads();
+    if (win[2] <= win[0]) {   // (uniform) a group without a Gaussian: the rounding between the regular and the big groups
+        if (tid == 0) windows[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const int wx0 = win[0], wy0 = win[1], ww = win[2] - win[0], wh = win[3] - win[1];
     const int n_win = ww * wh;  // (> 0: every Gaussian in `order` touches a tile)
     const float inv_ww = 1.0f / (float)ww;
@@ -555,13 +591,13 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
 }
 
 void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
-                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st)
+                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, int big_per_group, hipStream_t st)
 {
-    const int groups = (P + group - 1) / group;
+    const int groups = (int)bin_groups_for(P, group);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, num_cells_of(cam.gx, cam.gy), cell_count,
-                       cell_slot, order, windows + groups);
+                       cell_slot, order, windows + groups, (uint32_t)group, (uint32_t)big_per_group);
     hipLaunchKernelGGL(group_count_kernel, dim3(groups), dim3(group), sizeof(uint32_t) * cam.gx * cam.gy, st, P, group, cam, splats,
-                       order, windows, groups, tile_count, run_start);
+                       order, windows, groups, tile_count, run_start, (uint32_t)big_per_group);
 }
 
 // count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise group_count_kernel counts):
@@ -602,17 +638,17 @@ __device__ __forceinline__ void
 emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
           const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
           int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate, uint32_t* __restrict__ tile_count, uint32_t capacity,
-          uint32_t* __restrict__ arrival)
+          uint32_t* __restrict__ arrival, uint32_t big_per_group)
 {
     if (!SCAN && *gate) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
     // BIN_BY_CELL (order != nullptr): the group is a run of `order` and spans a window of tiles; BIN_IN_ORDER: consecutive
     // Gaussians, the whole grid
     uint4 window = make_uint4(0u, 0u, (uint32_t)cam.gx, (uint32_t)cam.gy);
-    uint32_t n_alive = 0;
+    uint4 tot = make_uint4(0u, 0u, 0u, 0u);
     if (USE_LDS && order) {
         window = windows[blockIdx.x];
         if (window.z == 0u) return;  // the group is empty
-        n_alive = windows[groups].x;
+        tot = windows[groups];
     }
     constexpr int NT = EMIT_THREADS, PER = EMIT_SLOTS / NT;
     extern __shared__ uint32_t hist[];
@@ -630,7 +666,7 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     mine.cnt = 0;
     // the group's Gaussians: entries of `order` (LDS path: neighbours on screen), else consecutive indices
     int gid = P;
-    if (tid < G) gid = (USE_LDS && order) ? ((uint32_t)(g0 + tid) < n_alive ? (int)order[g0 + tid] : P) : g0 + tid;
+    if (tid < G) gid = (USE_LDS && order) ? group_member(tot, (uint32_t)G, big_per_group, blockIdx.x, (uint32_t)tid, order, P) : g0 + tid;
     if (tid < G) mine = load_rect(P, cam, splats, gid, true);  // (gid >= P: an empty rectangle)
     bool gated = false;          // SCAN: this frame needs more binning entries than it was given (workgroup-uniform, launch-uniform)
     uint32_t arrived_as = 0u;    // SCAN, thread 0: how many readers of the tile counters had reported in before this workgroup
@@ -783,9 +819,9 @@ template <bool USE_LDS>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
             const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
-            int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate)
+            int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate, uint32_t big_per_group)
 {
-    emit_body<USE_LDS, false>(P, G, cam, splats, cursor, run_start, order, windows, groups, keys, gate, nullptr, 0u, nullptr);
+    emit_body<USE_LDS, false>(P, G, cam, splats, cursor, run_start, order, windows, groups, keys, gate, nullptr, 0u, nullptr, big_per_group);
 }
 
 // grid = the binning groups + ONE workgroup (the last) that is the frame's tile scan
@@ -805,7 +841,7 @@ emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, con
         }
         return;
     }
-    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, nullptr, nullptr, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival);
+    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, nullptr, nullptr, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival, 0u);
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
@@ -814,14 +850,16 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
 }
 
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
-                 const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st)
+                 const uint4* windows, int group, int big_per_group, uint64_t* keys, const uint32_t* gate, hipStream_t st)
 {
-    if (group)
-        hipLaunchKernelGGL(emit_kernel<true>, dim3((P + group - 1) / group), dim3(EMIT_THREADS), sizeof(uint32_t) * cam.gx * cam.gy, st,
-                           P, group, cam, splats, cursor, run_start, order, windows, (P + group - 1) / group, keys, gate);
-    else
+    if (group) {
+        // (BIN_BY_CELL: the runs of `order` and the big splats' groups behind them; BIN_IN_ORDER: consecutive Gaussians)
+        const int groups = order ? (int)bin_groups_for(P, group) : (P + group - 1) / group;
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(groups), dim3(EMIT_THREADS), sizeof(uint32_t) * cam.gx * cam.gy, st,
+                           P, group, cam, splats, cursor, run_start, order, windows, groups, keys, gate, (uint32_t)big_per_group);
+    } else
         hipLaunchKernelGGL(emit_kernel<false>, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(EMIT_THREADS), 0, st, P, BIN_GROUP, cam, splats,
-                           cursor, nullptr, nullptr, nullptr, 0, keys, gate);
+                           cursor, nullptr, nullptr, nullptr, 0, keys, gate, 0u);
 }
 
 bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return bin_mode == BIN_IN_ORDER && group > 0 && num_tiles <= EMIT_SCAN_TILES; }

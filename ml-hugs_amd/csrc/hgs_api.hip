@@ -49,6 +49,8 @@ void load_switches()
     s.emit_scan = !(e && e[0] == '0');
     e = getenv("HGS_K1_STAGE_SH");
     s.k1_stage_sh = e && e[0] == '1';
+    e = getenv("HGS_BIG_PER_GROUP");
+    s.big_per_group = e ? std::max(0, std::min(atoi(e), 64)) : hgs::BIG_PER_GROUP;
     std::lock_guard<std::mutex> lk(g_sw_mu);
     g_sw = s;
     g_sw_loaded.store(true, std::memory_order_release);
@@ -580,7 +582,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // (the per-tile counters, then -- from the next multiple of eight -- the per-cell counters of the counting sort)
     const size_t cell_counters_at = ((size_t)num_tiles + 7) / 8 * 8;
     // (+ the arrival counter of emit_scan_kernel behind them, zero between frames like the rest)
-    const size_t arrival_at = cell_counters_at + (size_t)num_cells;
+    const size_t arrival_at = cell_counters_at + (size_t)num_cells + 1;   // (num_cells + 1 cell counters: the last is the big splats')
+    const int big_per_group = switches().big_per_group;
     if (int rc = acquire_tile_counters(st, arrival_at + 1, &tile_count, &tc_lease)) return rc;
     int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
@@ -590,7 +593,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 
     { ProfScope ps(HGS_STAGE_PREPROCESS, st);
       launch_preprocess(a, cam, splats, tiles_touched, bin_mode, bin_mode == BIN_BY_CELL ? cell_count : tile_count, cell_slot, run_start,
-                        group, st); }
+                        group, big_per_group, st); }
     STAGE_CHECK(dbg, st, "preprocess");
     // Binning capacity: exact (after waiting for N) or the caller's guess (frame enqueued before N is known).
     const int64_t hint = a.binning_capacity_hint > 0 ? a.binning_capacity_hint : 0;
@@ -609,9 +612,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const uint32_t ckpt_cap32 = (uint32_t)std::min<size_t>(ckpt_slots_guess, 0xFFFFFFFFu);
     if (!scan_pending) {
         { ProfScope ps(HGS_STAGE_SCAN, st);
-          if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, st);
+          if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, big_per_group, st);
           else if (bin_mode == BIN_NONE) launch_count(Ptot, cam, splats, tile_count, st);
-          launch_tile_scan(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles,
+          launch_tile_scan(tile_count, num_tiles, cell_count, num_cells + 1, ranges, cursor, n_total, large_tiles,
                            seg_first_arg, cap32, (unsigned long long*)slot.word, slot.ticket, ckpt_cap32, st); }
         STAGE_CHECK(dbg, st, "tile_scan");
         // the scan, which re-zeroes the counters, is enqueued: the next frame on this stream may have them
@@ -674,7 +677,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
             tc_lease.scan_enqueued = true;   // (its last workgroup re-zeroes the counters)
             tc_lease.release();
         } else {
-            { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(Ptot, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, keys, gate, st); }
+            { ProfScope ps(HGS_STAGE_EMIT_KEYS, st); launch_emit(Ptot, cam, splats, cursor, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, big_per_group, keys, gate, st); }
             STAGE_CHECK(dbg, st, "emit");
         }
         { ProfScope ps(HGS_STAGE_SORT, st);

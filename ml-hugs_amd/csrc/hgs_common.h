@@ -64,7 +64,19 @@ inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + T
 // Binning cells: BIN_CELL x BIN_CELL tiles.  On large frames the Gaussians are counting-sorted by the cell of their
 // rectangle's first tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
 constexpr int BIN_CELL = 4;
-constexpr uint32_t BIN_SPREAD_MIN = 256;  // splats of more tiles than this are spread over the cells instead of sorted by their first tile (preprocess.hip)
+constexpr uint32_t BIN_SPREAD_MIN = 256;  // splats of more tiles than this are BIG: not sorted by the cell of their first tile (preprocess.hip)
+// Round 5, measured and left OFF (HGS_BIG_PER_GROUP=n turns it on): binning groups of their own for the BIG splats of a frame -- a
+// trained scene keeps 1 220 background splats of 256 .. 8 160 tiles, 30 % of its pairs; round 4 deals them to pseudo-random cells,
+// three or four to EVERY group, whose tile window then is the whole screen.  VERDICT r4 / DESIGN r4 8.3 costed concentrating them
+// (n per group-sized run of `order`, the other slots empty; at most BIG_GROUPS_CAP such groups, the rest fills whole groups) at
+// -25 us of the trained-scene frame's count + emit.  Measured (trained profile, same box, stage events): scatter + count + scan
+// 49.3 -> 49.6 us, emit 48.3 -> 55.8 us at n = 32 with the big splats spread over the group's waves (74.7 / 56.4 with all of them in
+// the group's first wave: the count kernel walks a big splat's tiles with the wave that holds it), 1 504 -> 1 437-1 470 FPS;
+// n = 16: 1 488 / 1 386, n = 64: 1 352.  The regular groups' windows shrink, and nothing gets faster: the per-tile atomics of a
+// full-screen window were not what the two kernels spend their time on; the big groups' 22 000+ pairs become emit's tail.
+constexpr int BIG_PER_GROUP = 0, BIG_GROUPS_CAP = 128;
+// binning groups a frame of P Gaussians can need: the runs of `order`, the padded big groups, and one for the rounding between them
+inline size_t bin_groups_for(int P, int g) { return (size_t)((P + g - 1) / g) + (size_t)BIG_GROUPS_CAP + 1; }
 constexpr int BIN_MAX_CELLS = 2048;  // cells whose populations one scatter workgroup prefix-sums (a 1080p frame has 510)
 inline int num_cells_of(int gx, int gy) { return ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL); }
 enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binning groups (preprocess.hip, binning.hip)
@@ -104,9 +116,9 @@ struct GeomLayout {
         tiles_touched = o;  o = align_up(o + 4 * (size_t)P);
         cell_slot = order = windows = run_start = o;
         if (const int g = bin_group_for(P, num_tiles)) {
-            const size_t groups = (size_t)((P + g - 1) / g);
+            const size_t groups = bin_groups_for(P, g);
             cell_slot = o;  o = align_up(o + 8 * (size_t)P);   // uint2 per Gaussian: its binning cell, its slot inside the cell
-            order = o;      o = align_up(o + 4 * (size_t)P);   // the Gaussians that touch a tile, sorted by cell
+            order = o;      o = align_up(o + 4 * groups * (size_t)g);   // the Gaussians that touch a tile, sorted by cell; then the big ones, BIG_PER_GROUP per group-sized run
             // uint4 per binning group: the tile window (x0, y0, width, height) its rectangles span; then one more whose .x
             // is the number of Gaussians in `order`
             windows = o;    o = align_up(o + 16 * (groups + 1));
@@ -206,6 +218,7 @@ struct Switches {
     int long_min_dense;         // HGS_LONG_MIN_DENSE  (0: default; set = applies whatever the frame's deepest list)
     bool emit_scan;             // HGS_EMIT_SCAN=0: always the stand-alone tile scan kernel (else: folded into emit where it applies)
     bool k1_stage_sh;           // HGS_K1_STAGE_SH=1: the preprocess kernel fetches the SH rows through LDS (measured no faster: off)
+    int big_per_group;          // HGS_BIG_PER_GROUP: big splats per binning group of their own (default BIG_PER_GROUP = 0: spread over the cells)
 };
 const Switches& switches();
 
@@ -213,7 +226,7 @@ const Switches& switches();
 // per-cell (BIN_BY_CELL) or per-tile (BIN_IN_ORDER) counters, ZERO on entry (hgs_api.hip keeps self-cleaning counter
 // arrays per stream).
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched, int mode,
-                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, hipStream_t st);
+                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, int big_per_group, hipStream_t st);
 void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, const Splat* splats, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* V, uint8_t* present, hipStream_t st);
 
@@ -222,13 +235,13 @@ void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_
 // binning group (`group` consecutive entries of `order`) the tile window, the per-tile pair counts (added to tile_count with
 // one returning atomic per touched tile) and the group's run offsets
 void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
-                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, hipStream_t st);
+                           uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, int big_per_group, hipStream_t st);
 // (re-zeroes tile_count, and cell_count if given, behind itself)
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
                       uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
                       unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
-                 const uint4* windows, int group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
+                 const uint4* windows, int group, int big_per_group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // BIN_IN_ORDER frames of few tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
 // emit_scan_kernel).  `arrival`: one zero uint32 next to the per-stream counters, self-resetting.
 bool emit_scan_applies(int bin_mode, int num_tiles, int group);

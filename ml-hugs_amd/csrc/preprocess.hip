@@ -188,7 +188,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
                   const float* __restrict__ F, const float* __restrict__ campos, Splat* __restrict__ splats,
                   uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii, uint8_t* __restrict__ visible,
                   uint32_t* __restrict__ counters, uint2* __restrict__ cell_slot, uint32_t* __restrict__ run_start,
-                  float4* __restrict__ zero_accum)
+                  float4* __restrict__ zero_accum, int big_per_group)
 {
     const int NT = MODE != BIN_NONE ? (int)blockDim.x : 256;
     // BIN_BY_CELL: [num_cells] population of each cell in this workgroup, [num_cells] its base; BIN_IN_ORDER: [num_tiles] pairs
@@ -207,7 +207,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         const int rows = min(64, seg_end - wave_first);
         const float* shs_w = wave_second ? in2.shs : shs_;
         staged = wave_first < P && shs_w != nullptr && (wave_second ? in2.M : cam.M) == 16 && cam.D > 0 && wave_first + rows >= min(wave_first + 64, P);
-        const int bin_words = MODE == BIN_BY_CELL ? 2 * num_cells : MODE == BIN_IN_ORDER ? num_tiles : 0;
+        const int bin_words = MODE == BIN_BY_CELL ? 2 * (num_cells + 1) : MODE == BIN_IN_ORDER ? num_tiles : 0;
         float4* stage = reinterpret_cast<float4*>(bin_lds + ((bin_words + 3) & ~3)) + (size_t)(threadIdx.x >> 6) * SH_STAGE_F4;
         my_row = stage + lane * 12;
         if (staged) {
@@ -222,7 +222,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         }
     }
     if (MODE != BIN_NONE)
-        for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
+        for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells + 1 : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
     // Housekeeping that would otherwise be another launch: when the caller will run backward, its [P,12] gradient
     // accumulator is zeroed here, fully coalesced.
     if (zero_accum) {
@@ -362,21 +362,22 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
     }
 
     if (MODE == BIN_BY_CELL) {
-        uint32_t* population = bin_lds;
-        uint32_t* base = bin_lds + num_cells;
-        // the cell of the rectangle's first tile -- but a BIG splat (more than BIN_SPREAD_MIN tiles) is dealt to a pseudo-random
-        // cell instead: every splat that reaches the image's top-left corner has its first tile at (0, 0), and a trained scene
-        // keeps hundreds of background splats a hundred and more pixels across (some cover the whole frame); together in cell 0
-        // they made ONE binning group of 96 000 pairs where the mean is 6 700, and the count and emit kernels lasted as long
-        // as that group (43 + 98 us on the trained-scene profile).  Spread, each group gets a few; their tiles are all over the
-        // frame anyway, so the groups' locality -- what the cell order is for -- loses nothing.
+        uint32_t* population = bin_lds;              // [num_cells + 1]: the last entry is the BIG cell
+        uint32_t* base = bin_lds + num_cells + 1;
+        // the cell of the rectangle's first tile -- but a BIG splat (more than BIN_SPREAD_MIN tiles) goes to a cell of its own kind:
+        // every splat that reaches the image's top-left corner has its first tile at (0, 0), and a trained scene keeps a thousand
+        // background splats a hundred and more pixels across (some cover the whole frame); together in cell 0 they made ONE
+        // binning group of 96 000 pairs where the mean is 6 700 (round 3).  Round 4 dealt them to pseudo-random cells: balanced,
+        // but three or four in EVERY group, whose tile window -- what the count and emit kernels pay per tile of -- then was the
+        // whole screen.  Round 5: the big cell, scattered behind the others into groups of big_per_group (cell_scatter_kernel);
+        // big_per_group == 0 keeps round 4's spreading.
         const int cell = !touched ? -1
-                         : touched > BIN_SPREAD_MIN ? (int)((((uint32_t)i * 2654435761u) >> 12) % (uint32_t)num_cells)
+                         : touched > BIN_SPREAD_MIN ? (big_per_group > 0 ? num_cells : (int)((((uint32_t)i * 2654435761u) >> 12) % (uint32_t)num_cells))
                                                     : (rect_miny / BIN_CELL) * cells_x + rect_minx / BIN_CELL;
         __syncthreads();  // population zeroed
         const uint32_t rank = cell >= 0 ? atomicAdd(&population[cell], 1u) : 0u;
         __syncthreads();
-        for (int c = threadIdx.x; c < num_cells; c += NT) {
+        for (int c = threadIdx.x; c <= num_cells; c += NT) {
             const uint32_t n = population[c];
             if (n) base[c] = atomicAdd(&counters[c], n);
         }
@@ -412,7 +413,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
 }
 
 void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* splats, uint32_t* tiles_touched, int mode,
-                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, hipStream_t st)
+                       uint32_t* counters, uint2* cell_slot, uint32_t* run_start, int group, int big_per_group, hipStream_t st)
 {
     const int P = a.P + a.seg2.P;
     const SecondInputs in2{a.P, a.seg2.M, a.seg2.means3D, a.seg2.shs, a.seg2.colors_precomp, a.seg2.opacities, a.seg2.scales,
@@ -427,7 +428,7 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
     const bool wants_stage = switches().k1_stage_sh && a.shs && a.s.sh_degree > 0 && (a.M == 16 || (a.seg2.P > 0 && a.seg2.M == 16));
     const size_t stage_bytes = sizeof(float4) * SH_STAGE_F4;
     if (mode == BIN_BY_CELL) {
-        const size_t bin_bytes = 2 * sizeof(uint32_t) * num_cells_of(cam.gx, cam.gy);
+        const size_t bin_bytes = 2 * sizeof(uint32_t) * (num_cells_of(cam.gx, cam.gy) + 1);
         // (the staging buffers cut the CU from 20 resident waves to 13: the launch stays ONE round of workgroups only when a whole
         //  binning group's waves fit one CU's LDS -- 256-thread workgroups, three per CU, were measured at 36.5 us against 21.4 on C2:
         //  782 workgroups on 768 slots are two rounds)
@@ -436,10 +437,10 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
         const size_t staged_total = ((bin_bytes + 15) & ~(size_t)15) + (size_t)((group + 63) / 64) * stage_bytes;
         if (wants_stage && big_lds_ok && group <= 832 && staged_total <= 160 * 1024) {
             hipLaunchKernelGGL((preprocess_kernel<BIN_BY_CELL, true>), dim3((P + group - 1) / group), dim3(group), staged_total, st,
-                               HGS_K1_ARGS, counters, cell_slot, nullptr, (float4*)a.grad_accum_to_zero);
+                               HGS_K1_ARGS, counters, cell_slot, nullptr, (float4*)a.grad_accum_to_zero, big_per_group);
         } else
             hipLaunchKernelGGL(preprocess_kernel<BIN_BY_CELL>, dim3((P + group - 1) / group), dim3(group), bin_bytes, st, HGS_K1_ARGS, counters, cell_slot, nullptr,
-                               (float4*)a.grad_accum_to_zero);
+                               (float4*)a.grad_accum_to_zero, big_per_group);
     } else if (mode == BIN_IN_ORDER) {
         const size_t bin_bytes = sizeof(uint32_t) * cam.gx * cam.gy;
         const size_t staged_total = ((bin_bytes + 15) & ~(size_t)15) + (size_t)((group + 63) / 64) * stage_bytes;
@@ -448,13 +449,13 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
                                                            160 * 1024) == hipSuccess;
         if (wants_stage && group <= SH_STAGE_THREADS && staged_total <= (big_lds_ok ? 160 * 1024 : 64 * 1024))
             hipLaunchKernelGGL((preprocess_kernel<BIN_IN_ORDER, true>), dim3((P + group - 1) / group), dim3(group), staged_total, st, HGS_K1_ARGS, counters, nullptr,
-                               run_start, (float4*)a.grad_accum_to_zero);
+                               run_start, (float4*)a.grad_accum_to_zero, big_per_group);
         else
             hipLaunchKernelGGL(preprocess_kernel<BIN_IN_ORDER>, dim3((P + group - 1) / group), dim3(group), bin_bytes, st, HGS_K1_ARGS, counters, nullptr, run_start,
-                               (float4*)a.grad_accum_to_zero);
+                               (float4*)a.grad_accum_to_zero, big_per_group);
     } else
         hipLaunchKernelGGL(preprocess_kernel<BIN_NONE>, dim3((P + 255) / 256), dim3(256), 0, st, HGS_K1_ARGS, nullptr, nullptr,
-                           nullptr, (float4*)a.grad_accum_to_zero);
+                           nullptr, (float4*)a.grad_accum_to_zero, big_per_group);
 #undef HGS_K1_ARGS
 }
 

@@ -1555,3 +1555,40 @@ def test_checkpoint_buffer_follows_what_the_shape_used_and_an_underestimate_is_r
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         for k in got[2]:
             assert rel_l2(got[2][k].cpu().numpy(), ref[2][k].cpu().numpy()) <= order_tol(k), k
+
+
+@pytest.mark.parametrize("per_group", ["32", "5", "0"])
+def test_big_splats_get_binning_groups_of_their_own(per_group, device, monkeypatch):
+    """Round 5 (measured no faster, off by default): with HGS_BIG_PER_GROUP=n splats of more than 256 tiles are binned in groups of
+    their own, n each, behind the groups of the cell order; beyond BIG_GROUPS_CAP (128) such groups the rest fills whole groups;
+    0 (the default) = round 4's pseudo-random spreading.  Here: 40 000 small splats and 900 big ones at 1080p -- with 5 per group the 128 padded groups hold 640 of them and
+    260 take the overflow path.  Whatever the grouping, the sorted list is the oracle's."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    from hugs_amd import synthetic as syn
+    H, W = 1080, 1920
+    cam = syn.pinhole_camera(H, W)
+    small = syn.scene_gaussians(40_000, cam, seed=51, sigma_px=3.0)
+    big = syn.scene_gaussians(900, cam, seed=52, sigma_px=90.0, ref_P=900)
+    sc = {k: np.concatenate([np.asarray(small[k], np.float32), np.asarray(big[k], np.float32)], 0) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    order = np.random.default_rng(3).permutation(40_900)     # the big ones anywhere in the storage order
+    sc = {k: np.ascontiguousarray(v[order]) for k, v in sc.items()}
+    monkeypatch.setenv("HGS_BIG_PER_GROUP", per_group)
+    reload_switches()
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    settings = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), torch.ones(3, device=device), 1.0,
+                                             to_dev(cam["world_view_transform"], device), to_dev(cam["full_proj_transform"], device), 1,
+                                             to_dev(cam["camera_center"], device), False, False)
+    t = {k: to_dev(v, device) for k, v in sc.items()}
+    inp = ho.Inputs(sc["means3D"], sc["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
+                    math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), H, W, np.ones(3, np.float32), shs=sc["shs"], scales=sc["scales"],
+                    rotations=sc["rotations"], sh_degree=1)
+    ho.set_threads(ho.usable_cpus())
+    ref = ho.forward(inp, stop_after="binning")
+    assert int((ref["tiles_touched"] > 256).sum()) >= 700
+    for _ in range(2):   # (the second frame runs on the first one's guesses)
+        color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], settings, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        assert st["N"] == ref["N"] and np.array_equal(radii.cpu().numpy(), ref["radii"])
+        assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+        assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+        assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])

@@ -472,6 +472,7 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // are written as zeros straight from registers.  Waves whose rows are not one block of one array (M != 16, a wave that
 // straddles the two segments) keep the per-thread path.
 constexpr int SH_ROW_F4 = 12;  // float4 per row at M = 16
+template <bool ADD>   // ADD: the first set's gradients are added to another render's (FirstAdds); else this is round 4's kernel, instruction for instruction
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))   // (<= 128 VGPRs: four waves per SIMD hold 262 144 Gaussians at once)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                            const float* __restrict__ opacities_, const float* __restrict__ scales_, const float* __restrict__ rots_,
@@ -536,13 +537,13 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     float* dL_dcov3D = second ? out2.dL_dcov3D : dL_dcov3D_;
     const int M = second ? in2.M : cam.M;
     // the other render's gradients of this Gaussian (first set only; NULL: nothing to add)
-    const float* ad_opacity = second ? nullptr : add1.dL_dopacity;
-    const float* ad_colors = second ? nullptr : add1.dL_dcolors;
-    const float* ad_means3D = second ? nullptr : add1.dL_dmeans3D;
-    const float* ad_sh = second ? nullptr : add1.dL_dsh;
-    const float* ad_scale = second ? nullptr : add1.dL_dscale;
-    const float* ad_rot = second ? nullptr : add1.dL_drot;
-    const float* ad_cov3D = second ? nullptr : add1.dL_dcov3D;
+    const float* ad_opacity = !ADD || second ? nullptr : add1.dL_dopacity;
+    const float* ad_colors = !ADD || second ? nullptr : add1.dL_dcolors;
+    const float* ad_means3D = !ADD || second ? nullptr : add1.dL_dmeans3D;
+    const float* ad_sh = !ADD || second ? nullptr : add1.dL_dsh;
+    const float* ad_scale = !ADD || second ? nullptr : add1.dL_dscale;
+    const float* ad_rot = !ADD || second ? nullptr : add1.dL_drot;
+    const float* ad_cov3D = !ADD || second ? nullptr : add1.dL_dcov3D;
     // accumulator record written by the blend-backward atomics, raw moments of u = G dL/dalpha over the pixels:
     //   sum u dx, sum u dy, sum u dx^2, sum u dx dy | sum u dy^2, sum u, dL/dr, dL/dg | dL/db - - -
     // with u = opacity G dL/dalpha (the uncapped alpha times dL/dalpha).  Turned here, once per Gaussian, into
@@ -847,10 +848,12 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
     // sits in front of the whole per-Gaussian computation)
     const int coop_mode = forced >= 0 ? forced : 1;
     const size_t stage_bytes = (f.shs && coop_mode) ? (size_t)256 * (3 * (cam.D + 1) * (cam.D + 1) + 1) * sizeof(float) : 0;  // [4 waves][64 rows][3 K + 1]
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), stage_bytes, st, P, cam, f.means3D, f.shs,
-                       f.opacities, f.scales, f.rotations, f.cov3D_precomp, in2, f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats,
-                       a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D, a.dL_dsh, a.dL_dscales,
-                       a.dL_drotations, a.dL_dcov3D, out2, add1, coop_mode);
+#define HGS_K8_ARGS dim3(blocks), dim3(256), stage_bytes, st, P, cam, f.means3D, f.shs, f.opacities, f.scales, f.rotations, f.cov3D_precomp, in2,       \
+                    f.s.viewmatrix, f.s.projmatrix, f.s.campos, splats, a.grad_accum, a.dL_dmeans2D, a.dL_dopacity, a.dL_dcolors, a.dL_dmeans3D,  \
+                    a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dcov3D, out2, add1, coop_mode
+    if (a.add_dL_dopacity) hipLaunchKernelGGL(preprocess_backward_kernel<true>, HGS_K8_ARGS);
+    else hipLaunchKernelGGL(preprocess_backward_kernel<false>, HGS_K8_ARGS);
+#undef HGS_K8_ARGS
 }
 
 // K10

@@ -112,8 +112,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     __shared__ uint32_t longest;   // the frame's longest list
     if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull, longest = 0u;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
-    if (ZERO)
-        for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;
+    for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;   // (whatever ZERO: emit's workgroups do not read them)
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0, carry2 = 0;
@@ -624,14 +623,14 @@ count_kernel(int P, Camera cam, const Splat* __restrict__ splats, uint32_t* __re
 constexpr int EMIT_THREADS = 1024;
 constexpr int EMIT_SLOTS = 8192;  // pair slots dealt per round (LDS: 2 bytes each)
 
-// SCAN (round 5; BIN_IN_ORDER frames of at most EMIT_SCAN_TILES tiles whose binning capacity is known before N is): there is no tile
-// scan kernel in front -- every workgroup prefix-sums the frame's <= 16 KB of per-tile counts for itself (four tiles per thread,
-// one round trip that overlaps the group's record loads) where it used to read the scan's result, and decides the capacity gate
+// SCAN (round 5; frames of at most EMIT_SCAN_TILES tiles -- anything up to 1080p -- whose binning capacity is known before N is):
+// there is no tile scan kernel in front -- every workgroup prefix-sums the frame's <= 32 KB of per-tile counts for itself (eight tiles
+// per thread, one round trip that overlaps the group's record loads) where it used to read the scan's result, and decides the capacity gate
 // from its own total; ONE extra workgroup of the launch (emit_scan_kernel) does what only one can do: ranges, N, flags, the long
 // tiles' list, the checkpoint slot layout, the word the host polls.  The workgroup that arrives LAST at the launch's arrival
 // counter re-zeroes the counters (the stand-alone scan kernel, their only reader, did that itself).  One launch and ~7 us of
 // latency chain less on the frames that consist of nothing else (the human-only render).
-constexpr int EMIT_SCAN_TILES = 4096;
+constexpr int EMIT_SCAN_TILES = 8192;
 
 template <bool USE_LDS, bool SCAN>
 __device__ __forceinline__ void
@@ -647,7 +646,18 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     uint4 tot = make_uint4(0u, 0u, 0u, 0u);
     if (USE_LDS && order) {
         window = windows[blockIdx.x];
-        if (window.z == 0u) return;  // the group is empty
+        if (window.z == 0u) {  // the group is empty
+            if (SCAN) {   // (it reads no counter, but the launch's arrival count includes it)
+                __shared__ uint32_t last_empty;
+                if (threadIdx.x == 0) last_empty = atomicAdd(arrival, 1u) == gridDim.x - 1u ? 1u : 0u;
+                __syncthreads();
+                if (last_empty) {
+                    for (int t = threadIdx.x; t < cam.gx * cam.gy; t += EMIT_THREADS) tile_count[t] = 0u;
+                    if (threadIdx.x == 0) atomicExch(arrival, 0u);
+                }
+            }
+            return;
+        }
         tot = windows[groups];
     }
     constexpr int NT = EMIT_THREADS, PER = EMIT_SLOTS / NT;
@@ -683,19 +693,24 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     if (SCAN) {
         __shared__ uint32_t scan_w[NT / 64];
         __shared__ unsigned long long scan_total64;
+        constexpr int SPT = EMIT_SCAN_TILES / NT;   // consecutive tiles per thread of the scan
         const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
-        const int t0 = tid * 4;   // (num_tiles <= 4 NT; the counter array is 16-byte aligned and padded to a multiple of eight)
-        uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t r[4] = {0u, 0u, 0u, 0u};
-        if (t0 < num_tiles) c4 = reinterpret_cast<const uint4*>(tile_count + t0)[0];
+        // where this group's runs begin inside the segments of its window's tiles (fetched now, added behind the scan: one round trip)
+        const int ww = (int)window.z, n_win = ww * (int)window.w;
+        const float inv_ww = 1.0f / (float)ww;
+        auto tile_of = [&](int k) { const int r = (int)(((float)k + 0.5f) * inv_ww); return ((int)window.y + r) * cam.gx + (int)window.x + (k - r * ww); };
+        uint32_t rw[SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (t0 + k < num_tiles) r[k] = my_runs[t0 + k];   // (meaningful only for the tiles this group touches)
+        for (int j = 0; j < SPT; ++j) rw[j] = tid + j * NT < n_win ? my_runs[tile_of(tid + j * NT)] : 0u;   // (meaningful only for the tiles this group touches)
+        const int t0 = tid * SPT;   // (num_tiles <= SPT NT; the counter array is 16-byte aligned and padded to a multiple of eight)
+        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
+        if (t0 < num_tiles) lo = reinterpret_cast<const uint4*>(tile_count + t0)[0], hi = reinterpret_cast<const uint4*>(tile_count + t0)[1];
         if (tid == 0) scan_total64 = 0ull;
-        const uint32_t c[4] = {c4.x, t0 + 1 < num_tiles ? c4.y : 0u, t0 + 2 < num_tiles ? c4.z : 0u, t0 + 3 < num_tiles ? c4.w : 0u};
-        const uint32_t sum4 = c[0] + c[1] + c[2] + c[3];
-        const uint32_t inc = wave_inclusive_scan(sum4);
-        unsigned long long m64 = sum4;   // (the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32)
+        uint32_t c[SPT] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, sum = 0;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) c[k] = t0 + k < num_tiles ? c[k] : 0u, sum += c[k];
+        const uint32_t inc = wave_inclusive_scan(sum);
+        unsigned long long m64 = sum;   // (the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m64 += (unsigned long long)__shfl_xor((long long)m64, d, 64);
         __syncthreads();   // scan_total64 initialised
@@ -709,16 +724,20 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
             if (k < w) before += v;
             total += v;
         }
-        uint32_t at = before + inc - sum4;
+        uint32_t at = before + inc - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (t0 + k < num_tiles) hist[t0 + k] = at + r[k];   // this group's cursor into every tile's segment
+        for (int k = 0; k < SPT; ++k) {
+            if (t0 + k < num_tiles) hist[t0 + k] = at;   // where every tile's segment begins
             at += c[k];
         }
         gated = scan_total64 >= (unsigned long long)N_TOO_MANY || total > capacity;
         // every reader of the counters reports in (its loads have returned: their values were used above); the last one re-zeroes
         // them -- at the END of its work: the returning atomic's round trip (~2 us) runs under the emission instead of in front of it
         if (tid == 0) arrived_as = atomicAdd(arrival, 1u);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; ++j)
+            if (tid + j * NT < n_win) hist[tile_of(tid + j * NT)] += rw[j];   // this group's cursor into its window's segments
     } else if (USE_LDS) {
         // this group's cursor into the tile segments of its window (entries of tiles the group does not touch are never
         // used, and run_start holds nothing meaningful for them)
@@ -826,8 +845,8 @@ emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t
 
 // grid = the binning groups + ONE workgroup (the last) that is the frame's tile scan
 __global__ void __launch_bounds__(EMIT_THREADS)
-emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ run_start, int groups,
-                 uint64_t* __restrict__ keys, ScanArgs sa, uint32_t* __restrict__ arrival)
+emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order,
+                 const uint4* __restrict__ windows, int groups, uint64_t* __restrict__ keys, ScanArgs sa, uint32_t* __restrict__ arrival, uint32_t big_per_group)
 {
     if ((int)blockIdx.x == groups) {
         tile_scan_body<false>(sa);
@@ -841,7 +860,7 @@ emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, con
         }
         return;
     }
-    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, nullptr, nullptr, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival, 0u);
+    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, order, windows, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival, big_per_group);
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
@@ -862,16 +881,18 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
                            cursor, nullptr, nullptr, nullptr, 0, keys, gate, 0u);
 }
 
-bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return bin_mode == BIN_IN_ORDER && group > 0 && num_tiles <= EMIT_SCAN_TILES; }
+bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return (bin_mode == BIN_IN_ORDER || bin_mode == BIN_BY_CELL) && group > 0 && num_tiles <= EMIT_SCAN_TILES; }
 
-void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
-                      uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, uint32_t* arrival, hipStream_t st)
+// order / windows: BIN_BY_CELL (the groups are runs of `order`, behind cell_scatter and group_count); nullptr: BIN_IN_ORDER
+void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, const uint32_t* order, const uint4* windows, int group,
+                      int big_per_group, uint64_t* keys, uint32_t* tile_count, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+                      uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap,
+                      uint32_t* arrival, hipStream_t st)
 {
-    const int groups = (P + group - 1) / group, num_tiles = cam.gx * cam.gy;
-    hipLaunchKernelGGL(emit_scan_kernel, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start,
-                       groups, keys, make_scan_args(tile_count, num_tiles, nullptr, 0, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap),
-                       arrival);
+    const int groups = order ? (int)bin_groups_for(P, group) : (P + group - 1) / group, num_tiles = cam.gx * cam.gy;
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start, order, windows,
+                       groups, keys, make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap),
+                       arrival, (uint32_t)big_per_group);
 }
 
 // ---------------------------------------------------------------------------------------------

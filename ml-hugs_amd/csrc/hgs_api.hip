@@ -610,6 +610,11 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // sized after N and the frame's kind are known.)
     const size_t ckpt_slots_guess = !want_ckpt || hint <= 0 ? 0 : a.ckpt_slots_hint > 0 ? (size_t)a.ckpt_slots_hint : CkptLayout::slots_for(hint, num_tiles);
     const uint32_t ckpt_cap32 = (uint32_t)std::min<size_t>(ckpt_slots_guess, 0xFFFFFFFFu);
+    if (scan_pending && bin_mode == BIN_BY_CELL) {   // (the cell scatter and the per-group counts stay kernels of their own)
+        { ProfScope ps(HGS_STAGE_SCAN, st);
+          launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, big_per_group, st); }
+        STAGE_CHECK(dbg, st, "cell_scatter + group_count");
+    }
     if (!scan_pending) {
         { ProfScope ps(HGS_STAGE_SCAN, st);
           if (bin_mode == BIN_BY_CELL) launch_spatial_groups(Ptot, cam, splats, cell_count, cell_slot, order, windows, tile_count, run_start, group, big_per_group, st);
@@ -670,7 +675,8 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
         uint64_t* act = (uint64_t*)(bin + bl.act) + ACT_PAD;
         if (scan_pending) {   // (the first, optimistic enqueue of such a frame; a re-run after an overflow finds the scan's results in place)
             { ProfScope ps(HGS_STAGE_EMIT_KEYS, st);
-              launch_emit_scan(Ptot, cam, splats, run_start, group, keys, tile_count, ranges, cursor, n_total, large_tiles, seg_first_arg, cap32,
+              launch_emit_scan(Ptot, cam, splats, run_start, bin_mode == BIN_BY_CELL ? order : nullptr, windows, group, big_per_group, keys, tile_count,
+                               cell_count, cell_count ? num_cells + 1 : 0, ranges, cursor, n_total, large_tiles, seg_first_arg, cap32,
                                (unsigned long long*)slot.word, slot.ticket, ckpt_cap32, tile_count + arrival_at, st); }
             STAGE_CHECK(dbg, st, "emit + tile_scan");
             scan_pending = false;

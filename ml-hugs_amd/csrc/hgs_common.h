@@ -242,12 +242,13 @@ void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count,
                       unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, hipStream_t st);
 void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor, const uint32_t* run_start, const uint32_t* order,
                  const uint4* windows, int group, int big_per_group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
-// BIN_IN_ORDER frames of few tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
+// Frames of at most 8 192 tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
 // emit_scan_kernel).  `arrival`: one zero uint32 next to the per-stream counters, self-resetting.
 bool emit_scan_applies(int bin_mode, int num_tiles, int group);
-void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, int group, uint64_t* keys, uint32_t* tile_count,
-                      uint2* ranges, uint32_t* cursor, uint32_t* n_total, uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity,
-                      unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap, uint32_t* arrival, hipStream_t st);
+void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, const uint32_t* order, const uint4* windows, int group,
+                      int big_per_group, uint64_t* keys, uint32_t* tile_count, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
+                      uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap,
+                      uint32_t* arrival, hipStream_t st);
 // act points at the first entry of list array 0 (after the front pad)
 // fb != nullptr: the small-tile sort kernel also blends its tile (forward), see binning.hip
 // Checkpoints of the forward blend for the depth-segmented backward; state == nullptr: none.  They are written only when

@@ -1423,8 +1423,9 @@ def test_trained_scene_profile_at_1080p(device):
     assert rel_l2(means2D.grad.cpu().numpy(), refg["means2D"]) <= GRAD_REL_TOL
 
 
+@pytest.mark.parametrize("mode", ["order", "cell"])
 @pytest.mark.parametrize("name", ["basic_d3", "big_splats", "deg1_ragged"])
-def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, device, monkeypatch):
+def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, mode, device, monkeypatch):
     """Round 5: a frame of few tiles that is enqueued before N is known has no tile scan kernel -- emit's workgroups prefix-sum the
     tile counts themselves and one extra workgroup of that launch writes ranges / N / flags (binning.hip, emit_scan_kernel).  Same N,
     ranges, sorted list and image as with the stand-alone kernel (HGS_EMIT_SCAN=0), with an ample guess of N and with one that is
@@ -1432,6 +1433,8 @@ def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, device, monkeyp
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _debug_forward_state
     _force_ctypes_binding(monkeypatch)      # (the hint is injected through the Python binding's hook)
+    monkeypatch.setenv("HGS_BIN_MODE", mode)   # both kinds of binning groups: consecutive Gaussians, runs of the cell order
+    reload_switches()
     sc = make_scene(**CASES[name])
     t = gpu_tensors(sc, device, grad=False)
     kw = dict(shs=t["shs"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])

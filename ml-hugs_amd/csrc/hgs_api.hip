@@ -1,5 +1,6 @@
 // C ABI entry points (include/hgs_rasterizer.h): argument validation, scratch layout, stage sequencing.
 #include <atomic>
+#include <sched.h>
 #include <chrono>
 #include <cstdarg>
 #include <cstdlib>
@@ -222,6 +223,9 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
             if (q != hipErrorNotReady) return fail(HGS_ERR_HIP, "HIP error while waiting for tile_scan: %s", hipGetErrorString(q));
         }
         __builtin_ia32_pause();
+        // (a rank that shares its core -- more ranks than the cgroup's CPU quota leaves cores -- hands it on instead of burning the
+        //  time slice its GPU's scan kernel is waiting behind: after ~50 us of spinning, every 256th probe)
+        if (spins > 8192u && (spins & 0xFFu) == 0u) sched_yield();
     }
 }
 

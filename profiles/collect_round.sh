@@ -29,9 +29,15 @@ bash profiles/collect_rows.sh $TAG > /dev/null 2>&1; cp "$ROOT"/gpurun_out/${TAG
 python3 tools/fuzz_rows.py --seconds 45 > "$OUT/${TAG}_fuzz_rows.txt" 2>&1
 SOAK_SECONDS=40 python3 tools/soak.py > "$OUT/${TAG}_soak.txt" 2>&1
 python3 tools/soak_churn.py > "$OUT/${TAG}_soak_churn.txt" 2>&1
-# (round 4) workgroups per CU against LDS / registers: the occupancy facts DESIGN.md 4.4 relies on
-make -C tools/microbench bin/occupancy_lds bin/occupancy_regs > /dev/null 2>&1
-./tools/microbench/bin/occupancy_lds > "$OUT/r4_occupancy_lds.txt" 2>&1; ./tools/microbench/bin/occupancy_regs > "$OUT/r4_occupancy_regs.txt" 2>&1
+# (round 5) the host side of a frame: where the host time goes level by level, what a HIP graph of the launches would buy, and the
+# statement-by-statement adapter (two autograd nodes, torch's stream fences) next to the one-call path for C3 / C4
+python3 tools/microbench/host_split.py > "$OUT/${TAG}_host_split.txt" 2>&1
+make -C tools/microbench bin/graph_launch > /dev/null 2>&1
+./tools/microbench/bin/graph_launch > "$OUT/${TAG}_graph_launch.txt" 2>&1
+HGS_FRAME_CALL=0 python3 tools/bench_c3.py 6890 > "$OUT/${TAG}_c3_6890_statement_path.json" 2> /dev/null
+HGS_FRAME_CALL=0 python3 tools/bench_c4.py > "$OUT/${TAG}_c4_statement_path.json" 2> /dev/null
+HGS_EMIT_SCAN=0 python3 tools/bench_c3.py 6890 > "$OUT/${TAG}_c3_6890_scan_kernel.json" 2> /dev/null
+HGS_EMIT_SCAN=0 python3 tools/bench_c3.py > "$OUT/${TAG}_c3_110210_scan_kernel.json" 2> /dev/null
 rm -rf "$ROOT"/gpurun_out/${TAG}*/trace "$ROOT"/gpurun_out/${TAG}*/pmc_*
 tail -n 3 "$OUT/${TAG}_soak.txt" "$OUT/${TAG}_soak_churn.txt"
 cat "$OUT/${TAG}_bench.json"

@@ -881,7 +881,14 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
                            cursor, nullptr, nullptr, nullptr, 0, keys, gate, 0u);
 }
 
-bool emit_scan_applies(int bin_mode, int num_tiles, int group) { return (bin_mode == BIN_IN_ORDER || bin_mode == BIN_BY_CELL) && group > 0 && num_tiles <= EMIT_SCAN_TILES; }
+// (every emit workgroup repeats the scan: beyond ~1 000 of them -- a million Gaussians at 1080p, four rounds of workgroups -- the
+//  repeats cost what the one-workgroup kernel does: 1 M Gaussians scan + emit 111.8 us apart, 112.4 folded; 500 k 74.6 / 71.3)
+bool emit_scan_applies(int bin_mode, int num_tiles, int group, int P)
+{
+    if (!(bin_mode == BIN_IN_ORDER || bin_mode == BIN_BY_CELL) || group <= 0 || num_tiles > EMIT_SCAN_TILES) return false;
+    const size_t groups = bin_mode == BIN_BY_CELL ? bin_groups_for(P, group) : (size_t)((P + group - 1) / group);
+    return groups <= 1024;
+}
 
 // order / windows: BIN_BY_CELL (the groups are runs of `order`, behind cell_scatter and group_count); nullptr: BIN_IN_ORDER
 void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, const uint32_t* order, const uint4* windows, int group,

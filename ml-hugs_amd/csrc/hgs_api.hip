@@ -607,7 +607,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // A frame of few tiles that is enqueued before N is known (a capacity hint) has no scan kernel: emit's workgroups scan the tile
     // counts themselves and one extra workgroup of that launch does the scan's bookkeeping (binning.hip, emit_scan_kernel).
     // HGS_EMIT_SCAN=0: always the stand-alone scan kernel (A/B measurements, the equivalence test).
-    bool scan_pending = switches().emit_scan && hint > 0 && emit_scan_applies(bin_mode, num_tiles, group);
+    bool scan_pending = switches().emit_scan && hint > 0 && emit_scan_applies(bin_mode, num_tiles, group, Ptot);
     uint32_t* const seg_first_arg = want_ckpt ? (uint32_t*)(image + il.seg_first) : nullptr;
     // checkpoint slots an optimistically enqueued frame's buffer is laid out for: the caller's guess, else the most a frame that
     // fits the binning guess can need; the scan closes the gate on a frame that needs more.  (No binning guess: the buffer is

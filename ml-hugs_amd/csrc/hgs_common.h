@@ -244,7 +244,7 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
                  const uint4* windows, int group, int big_per_group, uint64_t* keys, const uint32_t* gate, hipStream_t st);
 // Frames of at most 8 192 tiles whose binning capacity is known up front: emit and the tile scan as ONE launch (binning.hip,
 // emit_scan_kernel).  `arrival`: one zero uint32 next to the per-stream counters, self-resetting.
-bool emit_scan_applies(int bin_mode, int num_tiles, int group);
+bool emit_scan_applies(int bin_mode, int num_tiles, int group, int P);
 void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint32_t* run_start, const uint32_t* order, const uint4* windows, int group,
                       int big_per_group, uint64_t* keys, uint32_t* tile_count, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor, uint32_t* n_total,
                       uint32_t* large_tiles, uint32_t* seg_first, uint32_t capacity, unsigned long long* host_slot, uint32_t ticket, uint32_t ckpt_cap,

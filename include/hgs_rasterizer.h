@@ -163,6 +163,12 @@ typedef struct hgs_forward_args {
      * needs more is detected on the device and run again, exactly sized, like one that overflows its binning buffer (results are
      * identical either way; a deferred frame reports HGS_ERR_OVERFLOW from hgs_forward_poll instead). */
     int64_t ckpt_slots_hint;
+    /* Optional: called once, on the calling thread, after the frame's kernels have been enqueued and right BEFORE the call waits for
+     * N (not on a deferred frame, which does not wait).  Host work that does not need N -- a binding's autograd bookkeeping -- then
+     * runs while the GPU works towards N instead of between N's arrival and the caller's next launch (the backward's, which the GPU
+     * reaches ~45 us later on a human-only frame).  Must not call back into the library on this stream. */
+    void (*before_wait)(void *ctx);
+    void *before_wait_ctx;
 } hgs_forward_args;
 
 /* Scratch handed back by forward and required by backward. */

@@ -722,6 +722,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     }
     uint32_t n32 = 0;
     bool sparse = false, has_long = false;
+    if (a.before_wait) a.before_wait(a.before_wait_ctx);   // (the caller's N-independent host work, under the GPU's way to N)
     if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long)) return rc;
     history_put(hkey, slot);
     hist = history_get(hkey);

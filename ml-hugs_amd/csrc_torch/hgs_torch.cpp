@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -290,9 +291,18 @@ void fill_forward(Frame& f)
     fill_segment(a.seg2, f.b);
 }
 
+// hgs_forward_args.before_wait: the node is attached to the graph (edges, saved inputs, the image's grad_fn) while the GPU works towards
+// N, not after N has arrived -- from there to the backward's launch the GPU has ~45 us of forward left on a human-only frame
+struct BeforeWait { std::function<void()> fn; bool done = false; };
+void before_wait_cb(void* ctx)
+{
+    auto* b = static_cast<BeforeWait*>(ctx);
+    if (b->fn && !b->done) b->done = true, b->fn();
+}
+
 // Allocate the frame's outputs and scratch, enqueue its forward on `stream`.  `defer`: do not wait for N when the shape has a
 // history (finish_frame() must follow).  Returns with f.bw.state filled (num_rendered = -1 for a deferred frame).
-void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer)
+void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer, BeforeWait* before_wait = nullptr)
 {
     const auto dev = f.a.means3D.device();
     const int64_t P1 = f.P1(), P2 = f.P2(), P = P1 + P2, H = f.s.H, W = f.s.W;
@@ -345,7 +355,9 @@ void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer)
         if (ck) a.scratch[HGS_BUF_CKPT] = base + g + im + b, a.scratch_bytes[HGS_BUF_CKPT] = ck;
     }
     AllocCtx actx{&f.keep, bopts};
+    if (before_wait) a.before_wait = before_wait_cb, a.before_wait_ctx = before_wait;
     const int64_t n = hgs_rasterize_forward(&a, alloc_cb, &actx, &f.bw.state, (void*)stream);
+    a.before_wait = nullptr, a.before_wait_ctx = nullptr;   // (the argument block lives on in the node: for the backward)
     if (n < 0) raise_last("rasterize_gaussians");
 }
 
@@ -554,16 +566,22 @@ std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor 
         f.b = make_set(second[0], second[1], second[2], second[3], second[4], second[5], second[6]);
         f.s = make_settings(means3D, bg, view, proj, campos, H, W, tanfovx, tanfovy, mod, degree, prefiltered, debug, clamp_output, with_visibility);
         const hipStream_t st = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        start_frame(f, needs_grad, st, false);
+        Tensor color, radii, visible;
+        BeforeWait bw;
+        bw.fn = [&] {   // (runs inside start_frame, before its wait for N -- or below, when the frame had nothing to wait for)
+            color = f.color, radii = f.radii, visible = f.visible;
+            if (needs_grad) {
+                at::AutoGradMode grad_mode(true);
+                const Tensor inputs[15] = {means3D, means2D, sh, colors, opac, scales, rot, cov, second[0], second[1], second[2], second[3], second[4], second[5], second[6]};
+                attach(node, inputs);
+            }
+        };
+        start_frame(f, needs_grad, st, false, &bw);
+        before_wait_cb(&bw);
         finish_frame(f, st);
+        if (with_visibility) return {color, radii, visible};
+        return {color, radii};
     }
-    Tensor color = f.color, radii = f.radii, visible = f.visible;
-    if (needs_grad) {
-        const Tensor inputs[15] = {means3D, means2D, sh, colors, opac, scales, rot, cov, second[0], second[1], second[2], second[3], second[4], second[5], second[6]};
-        attach(node, inputs);
-    }
-    if (with_visibility) return {color, radii, visible};
-    return {color, radii};
 }
 
 // The whole of render() (/root/reference/hugs/renderer/gs_renderer.py:103-161) as one call: the zero viewspace leaf (:107-113),
@@ -624,18 +642,24 @@ std::vector<Tensor> render_pair(std::vector<Tensor> human, std::vector<Tensor> s
         // joint frame's (forward and, through the node, backward); outputs and scratch of both are allocated on the caller's stream
         fence(ev.a, main, side);
         start_frame(Hh, needs_grad, side, true);
-        start_frame(J, needs_grad, main, false);
+        std::vector<Tensor> result;
+        BeforeWait bw;
+        bw.fn = [&] {   // (inside the joint frame's forward, before its wait for N)
+            result = {J.color, J.radii, J.visible, viewspace, Hh.color, Hh.radii, Hh.visible};
+            if (needs_grad) {
+                at::AutoGradMode grad_mode(true);
+                const Tensor inputs[15] = {human[0], viewspace, is_rgb ? none : human[1], is_rgb ? human[1] : none, human[2], human[3], human[4], none,
+                                           scene[0], is_rgb ? none : scene[1], is_rgb ? scene[1] : none, scene[2], scene[3], scene[4], none};
+                attach(node, inputs);
+            }
+        };
+        start_frame(J, needs_grad, main, false, &bw);
+        before_wait_cb(&bw);
         finish_frame(Hh, side);
         finish_frame(J, main);
         fence(ev.b, side, main);   // what follows on the caller's stream sees both images
+        return result;
     }
-    std::vector<Tensor> result = {J.color, J.radii, J.visible, viewspace, Hh.color, Hh.radii, Hh.visible};
-    if (needs_grad) {
-        const Tensor inputs[15] = {human[0], viewspace, is_rgb ? none : human[1], is_rgb ? human[1] : none, human[2], human[3], human[4], none,
-                                   scene[0], is_rgb ? none : scene[1], is_rgb ? scene[1] : none, scene[2], scene[3], scene[4], none};
-        attach(node, inputs);
-    }
-    return result;
 }
 
 }  // namespace

@@ -59,7 +59,8 @@ class _ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("binning_capacity_hint", C.c_int64),
                 ("grad_accum_to_zero", C.c_void_p), ("clamp_output", C.c_int32), ("expect_no_long_tiles", C.c_int32),
                 ("defer_n", C.c_int32), ("backward_checkpoints", C.c_int32), ("scratch", C.c_void_p * 4),
-                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment), ("visible", C.c_void_p), ("ckpt_slots_hint", C.c_int64)]
+                ("scratch_bytes", C.c_size_t * 4), ("seg2", _Segment), ("visible", C.c_void_p), ("ckpt_slots_hint", C.c_int64),
+                ("before_wait", C.c_void_p), ("before_wait_ctx", C.c_void_p)]
 
 
 class _ForwardState(C.Structure):

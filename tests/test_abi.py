@@ -47,7 +47,7 @@ int main(void) {
   printf("%zu %zu\n", offsetof(hgs_backward_args, flags), offsetof(hgs_forward_args, visible));
   /* ABI v11: the other render's gradients to add, and the event the per-Gaussian kernel waits for */
   printf("%zu %zu %zu\n", offsetof(hgs_backward_args, add_dL_dopacity), offsetof(hgs_backward_args, add_dL_drotations), offsetof(hgs_backward_args, wait_before_per_gaussian));
-  printf("%zu %zu %zu\n", offsetof(hgs_forward_args, ckpt_slots_hint), offsetof(hgs_forward_state, ckpt_slots), offsetof(hgs_forward_state, ckpt_slots_used));
+  printf("%zu %zu %zu %zu\n", offsetof(hgs_forward_args, ckpt_slots_hint), offsetof(hgs_forward_state, ckpt_slots), offsetof(hgs_forward_state, ckpt_slots_used), offsetof(hgs_forward_args, before_wait_ctx));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
@@ -63,7 +63,7 @@ int main(void) {
     assert v[16:20] == [Sg.cov3D_precomp.offset, St.ckpt.offset, St.n_token.offset, B.seg2_dL_drotations.offset]
     assert v[20:22] == [B.flags.offset, F.visible.offset]
     assert v[22:25] == [B.add_dL_dopacity.offset, B.add_dL_drotations.offset, B.wait_before_per_gaussian.offset]
-    assert v[25:] == [F.ckpt_slots_hint.offset, St.ckpt_slots.offset, St.ckpt_slots_used.offset]
+    assert v[25:] == [F.ckpt_slots_hint.offset, St.ckpt_slots.offset, St.ckpt_slots_used.offset, F.before_wait_ctx.offset]
 
 
 def test_scratch_size_queries_and_offsets():

@@ -83,5 +83,20 @@ def box():
         quota = None if q == "max" else round(int(q) / int(per), 1)
     except (OSError, ValueError):
         pass
-    return {"cpu_model": model, "host_cpus": os.cpu_count(), "cpu_quota": quota, "box_id": "%04x" % (zlib.crc32(os.uname().nodename.encode()) & 0xFFFF),
+    # which machine: the GPU's unique id from the KFD topology and the host's boot id (the boxes share one container hostname)
+    gpu_id, boot = None, None
+    try:
+        import glob
+        for props in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+            kv = dict(line.split(None, 1) for line in open(props).read().splitlines() if " " in line)
+            if int(kv.get("simd_count", "0")) > 0 and kv.get("unique_id", "0") != "0":
+                gpu_id = "%x" % int(kv["unique_id"])
+                break
+    except (OSError, ValueError):
+        pass
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()[:8]
+    except OSError:
+        pass
+    return {"cpu_model": model, "host_cpus": os.cpu_count(), "cpu_quota": quota, "gpu_unique_id": gpu_id, "boot_id": boot, "box_id": "%04x" % (zlib.crc32(os.uname().nodename.encode()) & 0xFFFF),
             "frame_call": os.environ.get("HGS_FRAME_CALL", "1") != "0"}

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import diff_gaussian_rasterization as dgr                                                     # noqa: E402
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer     # noqa: E402
 from hugs_amd import synthetic as syn                                                         # noqa: E402
-from hugs_amd.renderer import render, render_batch                                            # noqa: E402
+from hugs_amd.renderer import gs_renderer, render, render_batch, render_human_scene           # noqa: E402
 
 dev = torch.device("cuda:0")
 random.seed(int(os.environ.get("SOAK_SEED", "0")))
@@ -36,7 +36,7 @@ for H, W in shapes:
 streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
 budget = float(os.environ.get("SOAK_SECONDS", "60"))
 t0 = time.time()
-seen, n, n_batch = set(), 0, 0
+seen, n, n_batch, n_pair = set(), 0, 0, 0
 while time.time() - t0 < budget:
     H, W = random.choice(shapes)
     pool, data, cam, Pmax = pools[(H, W)]
@@ -72,11 +72,31 @@ while time.time() - t0 < budget:
             for out in render_batch([fr] * 4, num_streams=random.choice([1, 2, 3])):
                 assert torch.equal(out["render"], want), f"render_batch differs on {(P, H, W)}"
             n_batch += 4
+        if P >= 2 and random.random() < 0.15:         # (round 5) both renders of a step as ONE node against the statement path's two
+            dgr._cpp, dgr._CPP_WANTED = cpp, True
+            cut = random.randint(1, P - 1)
+            outs = []
+            for frame_call in (True, False):
+                gs_renderer._FRAME_CALL = frame_call
+                model = lambda lo, hi, d: {"xyz": pool["means3D"][lo:hi].clone().requires_grad_(True), "shs": pool["shs"][lo:hi].clone().requires_grad_(True),
+                                           "opacity": pool["opacities"][lo:hi].clone().requires_grad_(True), "scales": pool["scales"][lo:hi].clone().requires_grad_(True),
+                                           "rotq": pool["rotations"][lo:hi].clone().requires_grad_(True), "active_sh_degree": d}
+                hu, sc_ = model(0, cut, deg), model(cut, P, 3)
+                pkg = render_human_scene(data, hu, sc_, bg_color=st.bg, human_bg_color=torch.zeros(3, device=dev), render_mode="human_scene",
+                                         render_human_separate=True)
+                torch.autograd.backward([pkg["render"], pkg["human_img"]], [torch.full_like(pkg["render"], 1e-3), torch.full_like(pkg["render"], 2e-3)])
+                outs.append((pkg["render"].detach(), pkg["human_img"].detach(), pkg["radii"], hu["xyz"].grad, hu["shs"].grad, sc_["xyz"].grad))
+            gs_renderer._FRAME_CALL = True
+            a, b = outs
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), f"render_pair differs on {(cut, P, H, W)}"
+            for x, y in zip(a[3:], b[3:]):
+                assert float((x - y).norm() / y.norm().clamp_min(1e-30)) <= 1e-4, f"render_pair gradients differ on {(cut, P, H, W)}"
+            n_pair += 1
     n += 1
     if n % 64 == 0:
         torch.cuda.synchronize()
 torch.cuda.synchronize()
 lib = dgr._load()
 assert len(seen) > 256, f"only {len(seen)} distinct shapes: lengthen SOAK_SECONDS"
-print(f"churn soak ok: {n} frames x 2 bindings (+{n_batch} deferred) in {time.time() - t0:.1f} s, {len(seen)} distinct (P, H, W) shapes, "
+print(f"churn soak ok: {n} frames x 2 bindings (+{n_batch} deferred, +{n_pair} step pairs x 2 paths) in {time.time() - t0:.1f} s, {len(seen)} distinct (P, H, W) shapes, "
       f"{lib.hgs_debug_stat(b'tile_counter_entries')} counter arrays kept")

@@ -472,6 +472,14 @@ __device__ __forceinline__ uint32_t big_groups_extent(const uint4 tot, uint32_t 
     const uint32_t cap = (uint32_t)BIG_GROUPS_CAP * B;
     return n_big <= cap ? tot.y + (n_big + B - 1u) / B * G : tot.y + (uint32_t)BIG_GROUPS_CAP * G + (n_big - cap);
 }
+// Which binning group a workgroup of the count / emit launches takes: the big splats' groups FIRST (they span the whole screen and hold
+// several times the pairs of a regular group: at the end of the grid they were the launch's tail), then the regular ones.
+__device__ __forceinline__ uint32_t group_of_block(const uint4 tot, uint32_t G, uint32_t B, uint32_t block)
+{
+    if (tot.z == 0u || B == 0u) return block;
+    const uint32_t big0 = tot.y / G, nb = (big_groups_extent(tot, G, B) + G - 1u) / G - big0;
+    return block < nb ? big0 + block : block - nb < big0 ? block - nb : block;
+}
 __device__ __forceinline__ int group_member(const uint4 tot, uint32_t G, uint32_t B, uint32_t block, uint32_t tid, const uint32_t* __restrict__ order, int P)
 {
     const uint32_t first = block * G;
@@ -538,13 +546,14 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     __shared__ int win[4];              // min x, min y, max x (exclusive), max y (exclusive), in tiles
     const int NT = (int)blockDim.x, tid = threadIdx.x, lane = tid & 63;
     const uint4 tot = windows[groups];
-    const uint32_t first = (uint32_t)blockIdx.x * (uint32_t)G;
+    const uint32_t grp = group_of_block(tot, (uint32_t)G, B, blockIdx.x);
+    const uint32_t first = grp * (uint32_t)G;
     if (first >= big_groups_extent(tot, (uint32_t)G, B)) {  // (uniform) nothing left for this group
-        if (tid == 0) windows[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) windows[grp] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     if (tid == 0) win[0] = win[1] = 0x7FFFFFFF, win[2] = win[3] = 0;
-    SplatRect mine = load_rect(P, cam, splats, group_member(tot, (uint32_t)G, B, blockIdx.x, (uint32_t)tid, order, P), false);
+    SplatRect mine = load_rect(P, cam, splats, group_member(tot, (uint32_t)G, B, grp, (uint32_t)tid, order, P), false);
     // the window: wave-level min / max, then one LDS atomic per wave and bound
     int lo_x = mine.cnt ? mine.minx : 0x7FFFFFFF, lo_y = mine.cnt ? mine.miny : 0x7FFFFFFF;
     int hi_x = mine.cnt ? mine.minx + mine.width : 0, hi_y = mine.cnt ? mine.miny + (int)(mine.cnt / (uint32_t)mine.width) : 0;
@@ -557,7 +566,7 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     if (lane == 0 && hi_x > lo_x) atomicMin(&win[0], lo_x), atomicMin(&win[1], lo_y), atomicMax(&win[2], hi_x), atomicMax(&win[3], hi_y);
     __syncthreads();
     if (win[2] <= win[0]) {   // (uniform) a group without a Gaussian: the rounding between the regular and the big groups
-        if (tid == 0) windows[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) windows[grp] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     const int wx0 = win[0], wy0 = win[1], ww = win[2] - win[0], wh = win[3] - win[1];
@@ -570,7 +579,7 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
     __syncthreads();
     // eight tiles per thread and round: the returning atomics of a round are all in flight together
-    uint32_t* my_runs = run_start + (size_t)blockIdx.x * (size_t)(cam.gx * cam.gy);
+    uint32_t* my_runs = run_start + (size_t)grp * (size_t)(cam.gx * cam.gy);
     for (int k0 = tid; k0 < n_win; k0 += 8 * NT) {
         uint32_t c[8], base[8];
         int t[8];
@@ -586,7 +595,7 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
         for (int u = 0; u < 8; ++u)
             if (c[u]) my_runs[t[u]] = base[u];
     }
-    if (tid == 0) windows[blockIdx.x] = make_uint4((uint32_t)wx0, (uint32_t)wy0, (uint32_t)ww, (uint32_t)wh);
+    if (tid == 0) windows[grp] = make_uint4((uint32_t)wx0, (uint32_t)wy0, (uint32_t)ww, (uint32_t)wh);
 }
 
 void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
@@ -644,8 +653,11 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     // Gaussians, the whole grid
     uint4 window = make_uint4(0u, 0u, (uint32_t)cam.gx, (uint32_t)cam.gy);
     uint4 tot = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t grp = blockIdx.x;   // the binning group this workgroup emits
     if (USE_LDS && order) {
-        window = windows[blockIdx.x];
+        tot = windows[groups];
+        grp = group_of_block(tot, (uint32_t)G, big_per_group, blockIdx.x);
+        window = windows[grp];
         if (window.z == 0u) {  // the group is empty
             if (SCAN) {   // (it reads no counter, but the launch's arrival count includes it)
                 __shared__ uint32_t last_empty;
@@ -658,7 +670,6 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
             }
             return;
         }
-        tot = windows[groups];
     }
     constexpr int NT = EMIT_THREADS, PER = EMIT_SLOTS / NT;
     extern __shared__ uint32_t hist[];
@@ -671,12 +682,12 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : cursor;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g0 = blockIdx.x * G;
+    const int g0 = (int)grp * G;
     SplatRect mine;
     mine.cnt = 0;
     // the group's Gaussians: entries of `order` (LDS path: neighbours on screen), else consecutive indices
     int gid = P;
-    if (tid < G) gid = (USE_LDS && order) ? group_member(tot, (uint32_t)G, big_per_group, blockIdx.x, (uint32_t)tid, order, P) : g0 + tid;
+    if (tid < G) gid = (USE_LDS && order) ? group_member(tot, (uint32_t)G, big_per_group, grp, (uint32_t)tid, order, P) : g0 + tid;
     if (tid < G) mine = load_rect(P, cam, splats, gid, true);  // (gid >= P: an empty rectangle)
     bool gated = false;          // SCAN: this frame needs more binning entries than it was given (workgroup-uniform, launch-uniform)
     uint32_t arrived_as = 0u;    // SCAN, thread 0: how many readers of the tile counters had reported in before this workgroup
@@ -694,7 +705,7 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
         __shared__ uint32_t scan_w[NT / 64];
         __shared__ unsigned long long scan_total64;
         constexpr int SPT = EMIT_SCAN_TILES / NT;   // consecutive tiles per thread of the scan
-        const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
+        const uint32_t* my_runs = run_start + (size_t)grp * num_tiles;
         // where this group's runs begin inside the segments of its window's tiles (fetched now, added behind the scan: one round trip)
         const int ww = (int)window.z, n_win = ww * (int)window.w;
         const float inv_ww = 1.0f / (float)ww;
@@ -741,7 +752,7 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     } else if (USE_LDS) {
         // this group's cursor into the tile segments of its window (entries of tiles the group does not touch are never
         // used, and run_start holds nothing meaningful for them)
-        const uint32_t* my_runs = run_start + (size_t)blockIdx.x * num_tiles;
+        const uint32_t* my_runs = run_start + (size_t)grp * num_tiles;
         const int ww = (int)window.z, n_win = ww * (int)window.w;
         const float inv_ww = 1.0f / (float)ww;
         for (int k = tid; k < n_win; k += NT) {

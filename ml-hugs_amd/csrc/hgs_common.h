@@ -65,16 +65,16 @@ inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + T
 // rectangle's first tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
 constexpr int BIN_CELL = 4;
 constexpr uint32_t BIN_SPREAD_MIN = 256;  // splats of more tiles than this are BIG: not sorted by the cell of their first tile (preprocess.hip)
-// Round 5, measured and left OFF (HGS_BIG_PER_GROUP=n turns it on): binning groups of their own for the BIG splats of a frame -- a
-// trained scene keeps 1 220 background splats of 256 .. 8 160 tiles, 30 % of its pairs; round 4 deals them to pseudo-random cells,
-// three or four to EVERY group, whose tile window then is the whole screen.  VERDICT r4 / DESIGN r4 8.3 costed concentrating them
-// (n per group-sized run of `order`, the other slots empty; at most BIG_GROUPS_CAP such groups, the rest fills whole groups) at
-// -25 us of the trained-scene frame's count + emit.  Measured (trained profile, same box, stage events): scatter + count + scan
-// 49.3 -> 49.6 us, emit 48.3 -> 55.8 us at n = 32 with the big splats spread over the group's waves (74.7 / 56.4 with all of them in
-// the group's first wave: the count kernel walks a big splat's tiles with the wave that holds it), 1 504 -> 1 437-1 470 FPS;
-// n = 16: 1 488 / 1 386, n = 64: 1 352.  The regular groups' windows shrink, and nothing gets faster: the per-tile atomics of a
-// full-screen window were not what the two kernels spend their time on; the big groups' 22 000+ pairs become emit's tail.
-constexpr int BIG_PER_GROUP = 0, BIG_GROUPS_CAP = 128;
+// Round 5: binning groups of their own for the BIG splats of a frame -- a trained scene keeps 1 220 background splats of
+// 256 .. 8 160 tiles, 30 % of its pairs; round 4 dealt them to pseudo-random cells, three or four to EVERY group, whose tile window then
+// is the whole screen.  Now BIG_PER_GROUP of them per group-sized run of `order` (the other slots empty), spread over the group's waves
+// (the count kernel walks a big splat's tiles with the wave that holds it), at most BIG_GROUPS_CAP such groups (the rest fills whole
+// groups), and these groups go FIRST in the count and emit grids (group_of_block: at the end they were the launches' tail).
+// Trained profile, same box: scatter + count + scan 37.5 -> 32.4-34.1 us, emit + scan 53.6 -> 49.9-51.5, 1 518-1 525 -> 1 540-1 551 FPS
+// at 16 / 24 per group; 32: 1 538; 8 overflows the cap (1 242).  Without the reordering the same grouping measured SLOWER than the
+// spreading (1 437-1 470 against 1 504: DESIGN_HISTORY.md) -- VERDICT r4's costed -25 us was optimistic by 18.
+// HGS_BIG_PER_GROUP: another figure; 0 = round 4's spreading.
+constexpr int BIG_PER_GROUP = 24, BIG_GROUPS_CAP = 128;
 // binning groups a frame of P Gaussians can need: the runs of `order`, the padded big groups, and one for the rounding between them
 inline size_t bin_groups_for(int P, int g) { return (size_t)((P + g - 1) / g) + (size_t)BIG_GROUPS_CAP + 1; }
 constexpr int BIN_MAX_CELLS = 2048;  // cells whose populations one scatter workgroup prefix-sums (a 1080p frame has 510)
@@ -218,7 +218,7 @@ struct Switches {
     int long_min_dense;         // HGS_LONG_MIN_DENSE  (0: default; set = applies whatever the frame's deepest list)
     bool emit_scan;             // HGS_EMIT_SCAN=0: always the stand-alone tile scan kernel (else: folded into emit where it applies)
     bool k1_stage_sh;           // HGS_K1_STAGE_SH=1: the preprocess kernel fetches the SH rows through LDS (measured no faster: off)
-    int big_per_group;          // HGS_BIG_PER_GROUP: big splats per binning group of their own (default BIG_PER_GROUP = 0: spread over the cells)
+    int big_per_group;          // HGS_BIG_PER_GROUP: big splats per binning group of their own (default BIG_PER_GROUP; 0: spread over the cells as round 4 did)
 };
 const Switches& switches();
 

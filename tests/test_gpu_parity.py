@@ -1560,11 +1560,11 @@ def test_checkpoint_buffer_follows_what_the_shape_used_and_an_underestimate_is_r
             assert rel_l2(got[2][k].cpu().numpy(), ref[2][k].cpu().numpy()) <= order_tol(k), k
 
 
-@pytest.mark.parametrize("per_group", ["32", "5", "0"])
+@pytest.mark.parametrize("per_group", ["24", "32", "5", "0"])
 def test_big_splats_get_binning_groups_of_their_own(per_group, device, monkeypatch):
-    """Round 5 (measured no faster, off by default): with HGS_BIG_PER_GROUP=n splats of more than 256 tiles are binned in groups of
-    their own, n each, behind the groups of the cell order; beyond BIG_GROUPS_CAP (128) such groups the rest fills whole groups;
-    0 (the default) = round 4's pseudo-random spreading.  Here: 40 000 small splats and 900 big ones at 1080p -- with 5 per group the 128 padded groups hold 640 of them and
+    """Round 5: splats of more than 256 tiles are binned in groups of their own, HGS_BIG_PER_GROUP (default 24) each, which the count
+    and emit launches take first; beyond BIG_GROUPS_CAP (128) such groups the rest fills whole groups; 0 = round 4's pseudo-random
+    spreading.  Here: 40 000 small splats and 900 big ones at 1080p -- with 5 per group the 128 padded groups hold 640 of them and
     260 take the overflow path.  Whatever the grouping, the sorted list is the oracle's."""
     from diff_gaussian_rasterization import _debug_forward_state
     from hugs_amd import synthetic as syn

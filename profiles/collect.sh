@@ -27,6 +27,7 @@ python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_
 # the bench line LAST, with this build's own PMC summaries in place (bench.py attaches traffic / VALU figures only from
 # summaries whose recorded source hash is the running build's)
 cp "$OUT/${TAG}_pmc_traffic.json" "$OUT/${TAG}_valu_utilization.json" "$ROOT/profiles/"
+python3 profiles/median_of.py 3 python3 bench.py --no-cpu-baseline --no-two-streams > "$OUT/${TAG}_bench_median_of_3.json" 2> "$OUT/bench3.err"   # (host noise: see median_of.py)
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete
 ls -la "$OUT"

@@ -23,6 +23,7 @@ python3 tools/bench_fwd.py > "$OUT/${TAG}_fwd.jsonl" 2> "$OUT/fwd.err"
 (python3 tools/bench_knn.py --shape body; python3 tools/bench_knn.py --shape body --no-grid; python3 tools/bench_knn.py --shape blob) > "$OUT/${TAG}_knn.jsonl" 2> "$OUT/knn.err"
 python3 tools/bench_loss.py > "$OUT/${TAG}_loss.json" 2> "$OUT/loss.err"
 HGS_C4_WITH_LOSS=1 python3 tools/bench_c4.py > "$OUT/${TAG}_c4_with_loss.json" 2> "$OUT/c4l.err"
+python3 profiles/median_of.py 3 python3 tools/bench_step.py --only fused > "$OUT/${TAG}_step_median_of_3.json" 2> "$OUT/step3.err"
 python3 tools/bench_step.py > "$OUT/${TAG}_step.json" 2> "$OUT/step.err"
 python3 tools/bench_rotations.py > "$OUT/${TAG}_rotations.txt" 2> "$OUT/rot.err"
 bash profiles/collect_rows.sh $TAG > /dev/null 2>&1; cp "$ROOT"/gpurun_out/${TAG}_rows/${TAG}_*_pmc.txt "$ROOT"/gpurun_out/${TAG}_rows/${TAG}_*_kernel_stats.txt "$OUT"/ 2>/dev/null

@@ -23,7 +23,7 @@ python3 profiles/timeline_gaps.py "$OUT/trace/${TAG}_results.db" > "$OUT/${TAG}_
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
 python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_pmc_sq_set2.txt" > "$OUT/${TAG}_valu_utilization.json"
-python3 "$SCRIPT" "$@" > "$OUT/${TAG}.json" 2> "$OUT/run.err"
+python3 profiles/median_of.py 3 python3 "$SCRIPT" "$@" > "$OUT/${TAG}.json" 2> "$OUT/run.err"   # (the median of three runs; all three in "repeats")
 find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete
 rm -rf "$OUT/trace"/*/ 2>/dev/null
 ls -la "$OUT"

@@ -653,10 +653,18 @@ std::vector<Tensor> render_pair(std::vector<Tensor> human, std::vector<Tensor> s
                 attach(node, inputs);
             }
         };
-        start_frame(J, needs_grad, main, false, &bw);
-        before_wait_cb(&bw);
-        finish_frame(Hh, side);
-        finish_frame(J, main);
+        try {
+            start_frame(J, needs_grad, main, false, &bw);
+            before_wait_cb(&bw);
+            finish_frame(Hh, side);
+            finish_frame(J, main);
+        } catch (...) {
+            // (an argument error of the joint frame, a failed allocation: the human-only frame may still be running on the side
+            //  stream into buffers that are about to be released -- the caller's stream must not reuse them before it is done)
+            (void)hipEventRecord(ev.b, side);
+            (void)hipStreamWaitEvent(main, ev.b, 0);
+            throw;
+        }
         fence(ev.b, side, main);   // what follows on the caller's stream sees both images
         return result;
     }

@@ -263,3 +263,23 @@ def test_a_training_loop_of_step_pairs_stays_put(device):
             for key in MODEL_KEYS:
                 assert rel_l2(mine[key].cpu().numpy(), theirs[key].cpu().numpy()) <= order_tol("rotations" if key == "rotq" else key), (k, key)
         assert rel_l2(got[5].cpu().numpy(), ref[5].cpu().numpy()) <= order_tol("means2D"), k
+
+
+def test_an_argument_error_in_the_step_pair_leaves_the_streams_usable(device):
+    """The human-only frame is already running on the library's side stream when the joint frame's arguments are checked: an error
+    there must fence the caller's stream behind the side stream before the buffers go (and the next step must be right)."""
+    _need_cpp()
+    from hugs_amd.renderer import render_human_scene
+    cam, hm, sm, dL = _models(device, n_human=1500, n_scene=3000)
+    human, scene = as_model(hm, device, 0), as_model(sm, device, 3)
+    bg = torch.ones(3, device=device)
+    good = render_human_scene(cam_data(cam, device), human, scene, bg_color=bg, render_mode="human_scene", render_human_separate=True)
+    bad_scene = dict(scene)
+    bad_scene["opacity"] = scene["opacity"][:-5]      # rows do not match means3D: the second set is validated before it reaches the kernels
+    for _ in range(3):
+        with pytest.raises(RuntimeError, match="rows"):
+            render_human_scene(cam_data(cam, device), human, bad_scene, bg_color=bg, render_mode="human_scene", render_human_separate=True)
+    again = render_human_scene(cam_data(cam, device), human, scene, bg_color=bg, render_mode="human_scene", render_human_separate=True)
+    torch.cuda.synchronize()
+    for k in ("render", "human_img", "radii", "human_radii"):
+        assert torch.equal(good[k], again[k]), k

@@ -7,6 +7,10 @@
 // resolved by hgs_forward_poll -- backward refused before that -- and a deferred frame with too small a capacity, which must
 // come back as HGS_ERR_OVERFLOW.
 //
+// use_hint = 4: the ABI v11 additions from a plain C caller -- a checkpoint buffer sized by ckpt_slots_hint (what the frame before
+// used), the before_wait callback, and a second backward whose per-Gaussian kernel ADDS another backward's gradients (add_*) after
+// waiting for an event of another stream (wait_before_per_gaussian): every per-input gradient written out is then TWICE the frame's.
+//
 //   in.bin : int32 P, M, H, W, D, use_hint | float tanfovx, tanfovy, scale_modifier | bg[3] view[16] proj[16] campos[3]
 //            means3D[3P] shs[3MP] opacities[P] scales[3P] rotations[4P] dL_dcolor[3HW]
 //   out.bin: int64 N | color[3HW] | int32 radii[P] | dL_dmeans3D[3P] dL_dmeans2D[3P] dL_dopacity[P] dL_dsh[3MP]
@@ -28,6 +32,8 @@
         }                                                                                   \
     } while (0)
 
+static int g_before_wait_calls = 0;
+static void before_wait_cb(void* ctx) { ++*(int*)ctx; }
 static std::vector<void*> g_scratch;
 static void* alloc_cb(void*, int, size_t bytes)
 {
@@ -152,6 +158,44 @@ int main(int argc, char** argv)
     }
     if (hgs_rasterize_backward(&bw, stream) < 0) return fprintf(stderr, "backward: %s\n", hgs_last_error()), 3;
     CHECK(hipStreamSynchronize(stream));
+    if (use_hint == 4) {
+        // keep the frame's gradients, render it again -- the checkpoint buffer laid out for what the frame before used, the callback
+        // in front of the wait for N -- and run a backward that adds them to its own
+        struct Copy { float** dst; const float* src; size_t n; };
+        float *g_op, *g_col, *g_m3, *g_cov, *g_sh, *g_sc, *g_rot;
+        const Copy copies[] = {{&g_op, bw.dL_dopacity, (size_t)P}, {&g_col, bw.dL_dcolors, 3 * (size_t)P}, {&g_m3, bw.dL_dmeans3D, 3 * (size_t)P},
+                               {&g_cov, bw.dL_dcov3D, 6 * (size_t)P}, {&g_sh, bw.dL_dsh, 3 * (size_t)M * P}, {&g_sc, bw.dL_dscales, 3 * (size_t)P},
+                               {&g_rot, bw.dL_drotations, 4 * (size_t)P}};
+        for (const Copy& c : copies) {
+            *c.dst = device_buffer<float>(c.n);
+            CHECK(hipMemcpy(*c.dst, c.src, c.n * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+        const int64_t used = bw.state.ckpt_slots_used;
+        if (!bw.state.ckpt || used <= 0) return fprintf(stderr, "the sparse frame left no checkpoints (slots used %lld)\n", (long long)used), 3;
+        a.binning_capacity_hint = N + N / 8 + 4096, a.ckpt_slots_hint = used + 64;
+        a.before_wait = before_wait_cb, a.before_wait_ctx = &g_before_wait_calls;
+        if (hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream) != N) return fprintf(stderr, "forward (slots hint): %s\n", hgs_last_error()), 3;
+        if (g_before_wait_calls != 1) return fprintf(stderr, "before_wait ran %d times\n", g_before_wait_calls), 3;
+        if (bw.state.ckpt_slots != used + 64 || bw.state.ckpt_bytes != hgs_ckpt_bytes_for_slots(used + 64) || bw.state.ckpt_slots_used != used)
+            return fprintf(stderr, "checkpoint buffer: %lld slots, %zu bytes, %lld used\n", (long long)bw.state.ckpt_slots, bw.state.ckpt_bytes, (long long)bw.state.ckpt_slots_used), 3;
+        // a guess that is too small is repaired (the frame is run again, exactly sized)
+        a.ckpt_slots_hint = used / 2 > 0 ? used / 2 : 1;
+        if (hgs_rasterize_forward(&a, alloc_cb, nullptr, &bw.state, stream) != N || bw.state.ckpt_slots < used)
+            return fprintf(stderr, "forward (slots guess too small): %s, %lld slots\n", hgs_last_error(), (long long)bw.state.ckpt_slots), 3;
+        if (hgs_debug_stat("ckpt_reruns") < 1) return fprintf(stderr, "the too-small checkpoint guess was not counted as a re-run\n"), 3;
+        a.before_wait = nullptr;
+        hipStream_t other;
+        hipEvent_t ready;
+        CHECK(hipStreamCreate(&other));
+        CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        CHECK(hipEventRecord(ready, other));   // (the "other render" finished long ago; what matters is that the wait is accepted and honoured)
+        bw.add_dL_dopacity = g_op, bw.add_dL_dcolors = g_col, bw.add_dL_dmeans3D = g_m3, bw.add_dL_dcov3D = g_cov, bw.add_dL_dsh = g_sh;
+        bw.add_dL_dscales = g_sc, bw.add_dL_drotations = g_rot, bw.wait_before_per_gaussian = ready;
+        if (hgs_rasterize_backward(&bw, stream) < 0) return fprintf(stderr, "backward (add): %s\n", hgs_last_error()), 3;
+        CHECK(hipStreamSynchronize(stream));
+        bw.add_dL_dsh = nullptr;   // an incomplete set of add_* pointers is an argument error
+        if (M > 0 && hgs_rasterize_backward(&bw, stream) != HGS_ERR_INVALID_ARGUMENT) return fprintf(stderr, "an incomplete add_* set was accepted\n"), 3;
+    }
 
     FILE* o = fopen(argv[2], "wb");
     if (!o) return perror(argv[2]), 1;

@@ -29,7 +29,9 @@ def test_host_builds_against_the_header_and_library():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_hint", [0, 1, 2, 3])   # 2: plus deferred frames in caller-provided scratch; 3: the two-segment form
+# 2: plus deferred frames in caller-provided scratch; 3: the two-segment form; 4: ABI v11 (checkpoint slots guessed and repaired, the
+# before_wait callback, a backward that adds another backward's gradients behind an event): per-input gradients come out doubled
+@pytest.mark.parametrize("use_hint", [0, 1, 2, 3, 4])
 def test_c_host_matches_the_oracle(use_hint, device, tmp_path):
     sc = make_scene(**CASES["basic_d3"])
     inp = oracle_inputs(sc)
@@ -65,5 +67,6 @@ def test_c_host_matches_the_oracle(use_hint, device, tmp_path):
     rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b.reshape(a.shape)) / max(np.linalg.norm(b), 1e-30)
     for name, n, r in (("means3D", 3 * P, refg["means3D"]), ("means2D", 3 * P, refg["means2D"]), ("opacities", P, refg["opacities"]),
                        ("shs", 3 * M * P, refg["shs"]), ("scales", 3 * P, refg["scales"]), ("rotations", 4 * P, refg["rotations"])):
-        assert rel(take(n), r) <= 1e-3, name
+        factor = 2.0 if (use_hint == 4 and name != "means2D") else 1.0     # (dL/dmeans2D is not one of the added outputs)
+        assert rel(take(n), factor * r) <= 1e-3, name
     assert off == len(raw)

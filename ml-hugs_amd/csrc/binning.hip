@@ -60,9 +60,16 @@ constexpr int SORT_CAP_MID = 4096;   // ... and what one workgroup of the long t
 // Round 4: the long tiles' forward blend is depth-parallel (blend_fwd.h, deep_forward_worker), so "long" now also means "worth
 // splitting by depth": LONG_MIN_SPARSE comes down from 1 024.  Both thresholds are kernel arguments of the scan (defaults
 // below; HGS_LONG_MIN_SPARSE / HGS_LONG_MIN_DENSE override them for A/B measurements); what a frame uses is n_total[4].
-constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human
-constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (the 6 890-Gaussian template: mean 260; what round 3 used)
-constexpr uint32_t DEEP_MEAN_MIN = 384;
+constexpr int LONG_MIN_SPARSE = 256;         // sparse frames with DEEP lists (mean non-empty list >= DEEP_MEAN_MIN entries): a 110k-Gaussian human, the SMPL template
+constexpr int LONG_MIN_SPARSE_SHALLOW = 1024;  // other sparse frames (what round 3 used for all of them)
+// 384 until the end of round 5, which left the 6 890-Gaussian template (mean list 260, composited depth <= 430) on the shallow side.
+// Measured again with round 5's forward (A/B builds, two boxes): its sort + forward kernels 48.3-49.6 -> 44.7-45.8 us with 200 or 128,
+// unchanged with 280; frames of 3 000-60 000 uniform Gaussians at 256x256 ... 540x960 are deep under either value (tools/ab_build.sh
+// name -DHGS_DEEP_MEAN_MIN=...).
+#ifndef HGS_DEEP_MEAN_MIN
+#define HGS_DEEP_MEAN_MIN 200
+#endif
+constexpr uint32_t DEEP_MEAN_MIN = HGS_DEEP_MEAN_MIN;
 // dense frames: 768 WHEN the frame holds a list beyond 2 048 entries (else 2 048: tile_scan_kernel, dense_min); until round 4: 2 048,
 // what the one-workgroup-per-tile sort holds.  A person in front of a scene puts
 // hundreds of tiles between 1 024 and 2 048 entries, whose one-wave walks were the tail of the fused kernel: the all-rows step's

@@ -1627,6 +1627,11 @@ long_tile_plan_kernel(const uint2* __restrict__ ranges, const uint64_t* __restri
 // a whole tile and CAP > SORT_CAP_SMALL: the chunk path); the sorted entries go to list[s_dst + i] with positions pos_base + i + 1,
 // the compacted entries behind carry[] in the tile's list slots (segment start s_tile).  Returns the final carry[] through
 // `carry`.  sh: CAP keys, bucket_start: CAP + 1 words, red: 3 NT / 64 words.
+#ifdef HGS_TRACE
+#define MID_STAMP(slot) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (g_trace_buf && threadIdx.x == 0) g_trace_buf[(size_t)(6000u + blockIdx.x) * 8u + (slot)] = wall_clock64(); } while (0)
+#else
+#define MID_STAMP(slot) do { } while (0)
+#endif
 template <int CAP, int NT, typename LoadKey>
 __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t s_tile, uint32_t s_dst, uint32_t pos_base,
                                           uint32_t (&carry)[NUM_LISTS], uint64_t* __restrict__ list, uint64_t* __restrict__ act,
@@ -1661,7 +1666,9 @@ __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t
             const uint32_t i = (uint32_t)e * NT + threadIdx.x;
             key[e] = i < n ? load_key(i) : ~0ull;
         }
+        MID_STAMP(2);
         if (!bucket_sort<E, NT>(key, pos, n, sh, bucket_start, red) && !bucket_sort<E, NT, true>(key, pos, n, sh, bucket_start, red, coarse)) return false;
+        MID_STAMP(3);
         __syncthreads();  // every thread has ranked its keys: the bucketed copy in LDS may be overwritten ...
 #pragma unroll
         for (int e = 0; e < E; ++e)
@@ -1686,6 +1693,7 @@ __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t
     // the item is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it chunk by
     // chunk (the bucket array is free by now: the compaction's scratch)
     __syncthreads();
+    MID_STAMP(4);
     for (uint32_t base = 0; base < n; base += NT) {
         const uint32_t i = base + threadIdx.x;
         const uint64_t entry = i < n ? (sorted_in_lds ? sh[i] : __builtin_nontemporal_load(&list[s_dst + i])) : 0ull;
@@ -1763,6 +1771,7 @@ __global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_
     __shared__ uint32_t bucket_start[CAP + 1];  // bucket sizes, then (in place) their exclusive scan
     __shared__ uint32_t red[3 * (NT / 64)];
     __shared__ uint32_t coarse[2 * NT];
+    MID_STAMP(0);
     if (n_total[1]) return;  // gate
     const uint32_t threshold = n_total[4], n_cand = n_total[2], n_items = n_cand + (planned ? n_total[5] : 0u);
     // a fixed grid walks the candidate tiles that tile_scan_kernel listed, then the parts the plan kernel made
@@ -1773,6 +1782,10 @@ __global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_
             const uint2 rg = ranges[tile];
             const uint32_t s = rg.x, n = rg.y - rg.x;
             if (n <= threshold || (planned && n > (uint32_t)CAP)) continue;   // (not long on this frame / the plan's or the fallback's)
+            MID_STAMP(1);
+#ifdef HGS_TRACE
+            if (g_trace_buf && threadIdx.x == 0) g_trace_buf[(size_t)(6000u + blockIdx.x) * 8u + 7] = n;
+#endif
             // (!planned: the plan and fallback kernels were not launched -- the stream's last frame had no list beyond CAP entries --
             //  and this frame has one after all: sorted here, slowly, this once)
             if (n > (uint32_t)CAP) sort_in_chunks<CAP, NT>(keys + s, n, s, list, scratch, act, stride, carry, sh, bucket_start);
@@ -1780,6 +1793,7 @@ __global__ void __launch_bounds__(SORT_MID_THREADS) __attribute__((amdgpu_waves_
 #pragma unroll
             for (int q = 0; q < NUM_LISTS; ++q)
                 if (threadIdx.x == 0) act_count[tile * NUM_LISTS + q] = carry[q];
+            MID_STAMP(5);
         } else {
             const SortPart r = parts[it - n_cand];
             if (r.count == 0u) continue;

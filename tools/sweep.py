@@ -37,7 +37,7 @@ def main():
             if r.returncode != 0:
                 raise SystemExit(f"bench.py failed for P={P} ({mode}), rc {r.returncode}:\n{r.stderr[-2000:]}")
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            row[mode] = {"fps": d["value"], "ms": d["ms_per_step"], "stages_ms": d["stages_ms"]}
+            row[mode] = {"fps": d["value"], "ms": d["ms_per_step"], "host_busy_us": d.get("host_busy_us_per_frame"), "stages_ms": d["stages_ms"]}
             row["num_rendered_N"], row["visible"] = d["config"]["num_rendered_N"], d["config"]["visible"]
             row[mode]["whole_frame_GBps"] = d["whole_frame"]["GB_per_s"]
         out["points"].append(row)

@@ -1637,25 +1637,31 @@ __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t
                                           uint32_t (&carry)[NUM_LISTS], uint64_t* __restrict__ list, uint64_t* __restrict__ act,
                                           size_t stride, uint64_t* sh, uint32_t* bucket_start, uint32_t* red, uint32_t* coarse)
 {
-    bool sorted_in_lds = true;  // (workgroup-uniform)
-    // the register network of the small tiles with NT threads: lane distances below 64 by DPP, only distances 64..NT/2 through
-    // LDS -- a fifth of the barriers of an all-LDS bitonic sort
-    auto in_registers = [&](auto e_tag) {
-        constexpr int E = decltype(e_tag)::value;
-        uint64_t key[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * NT + threadIdx.x;
-            key[e] = i < n ? load_key(i) : ~0ull;
-        }
-        bitonic_in_registers<E, NT>(key, sh);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = (uint32_t)e * NT + threadIdx.x;
-            if (i < n) list[s_dst + i] = list_entry(key[e], pos_base + i + 1u);
+    // The way out when the depths pile up in one bucket even after equalisation (all depths equal): the all-LDS bitonic network over the
+    // keys' own LDS array.  Until round 5 this was the small tiles' register network with NT threads (E keys per thread, DPP below lane
+    // distance 64): a fifth of the barriers, but its E = 8 instance is what held the long tiles' kernels at 128 VGPRs with 28-56 bytes of
+    // scratch -- kernel arguments spilled at entry and reloaded on EVERY item's path -- for a path that real frames do not take.
+    auto in_lds = [&]() {
+        uint32_t m = 2;
+        while (m < n) m <<= 1;   // (n <= CAP, a power of two)
+        for (uint32_t i = threadIdx.x; i < m; i += NT) sh[i] = i < n ? load_key(i) : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t c = threadIdx.x; c < (m >> 1); c += NT) {
+                    const uint32_t l = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), r = l | j;
+                    const uint64_t a = sh[l], b = sh[r];
+                    if ((a > b) == ((l & k) == 0u)) sh[l] = b, sh[r] = a;
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const uint64_t entry = list_entry(sh[i], pos_base + i + 1u);
+            list[s_dst + i] = entry;
+            sh[i] = entry;   // (the compaction below reads the sorted list from here)
         }
     };
-    // ---- bucket sort (the bitonic network in registers when the tile's depths pile up in one bucket), with as many
+    // ---- bucket sort (the network above when the tile's depths pile up in one bucket), with as many
     // keys -- and buckets -- per thread as the list needs: a 1 100-entry list does not pay for 8 192 buckets ----
     auto by_buckets = [&](auto e_tag) {
         constexpr int E = decltype(e_tag)::value;
@@ -1685,18 +1691,13 @@ __device__ __forceinline__ void sort_item(LoadKey load_key, uint32_t n, uint32_t
     else if (EMAX >= 2 && n <= 2u * NT) done = by_buckets(std::integral_constant<int, (EMAX >= 2 ? 2 : 1)>{});
     else if (EMAX >= 4 && n <= 4u * NT) done = by_buckets(std::integral_constant<int, (EMAX >= 4 ? 4 : 1)>{});
     else done = by_buckets(std::integral_constant<int, EMAX>{});
-    if (!done) {
-        sorted_in_lds = false;
-        if (EMAX >= 4 && n <= 4u * NT) in_registers(std::integral_constant<int, (EMAX >= 4 ? 4 : EMAX)>{});
-        else in_registers(std::integral_constant<int, EMAX>{});
-    }
-    // the item is sorted -- in LDS after the bucket sort, else in global memory (written by this workgroup): compact it chunk by
-    // chunk (the bucket array is free by now: the compaction's scratch)
+    if (!done) in_lds();
+    // the item is sorted, in LDS: compact it chunk by chunk (the bucket array is free by now: the compaction's scratch)
     __syncthreads();
     MID_STAMP(4);
     for (uint32_t base = 0; base < n; base += NT) {
         const uint32_t i = base + threadIdx.x;
-        const uint64_t entry = i < n ? (sorted_in_lds ? sh[i] : __builtin_nontemporal_load(&list[s_dst + i])) : 0ull;
+        const uint64_t entry = i < n ? sh[i] : 0ull;
         compact_chunk<NT / 64>(entry, i < n, carry, s_tile, act, stride, bucket_start);
     }
 }

@@ -653,6 +653,41 @@ def test_long_tile_lists_take_the_large_sort_paths(P, longest_at_least, longest_
         assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
 
 
+def test_shallow_sparse_frame_with_a_few_long_lists(device):
+    """The OTHER kind of sparse frame (binning.hip, tile_scan_body: DEEP_MEAN_MIN): a thousand tiles with a few dozen entries each
+    and a small stack in the middle -- 33 lists beyond 1 024 entries, 11 beyond 2 048, mean list 64.  Its lists are long from
+    LONG_MIN_SPARSE_SHALLOW (1 024) entries on and blended by ONE wave per quad (no depth-parallel workers).  Until the end of
+    round 5 the SMPL-template frames of the C3 tests were of this kind; with DEEP_MEAN_MIN = 200 they count as deep, so this frame
+    keeps the path under test: lists position by position, image, gradients against the oracle; hinted second frame identical."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    from hugs_amd import synthetic as syn
+    sc = _stacked_scene(36000, 512, 512, seed=51, spread_px=44.0)
+    bgd = syn.scene_gaussians(3000, sc["cam"], seed=52, sigma_px=0.7, ref_P=3000)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        sc[k] = np.concatenate([sc[k], np.asarray(bgd[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    nonempty = lens[lens > 0]
+    # what the scan decides from: sparse (< 4 096 non-empty tiles), shallow (mean list < 200), enough lists beyond 1 024 for the launch
+    assert len(nonempty) < 4096 and nonempty.mean() < 200 and (lens > 1024).sum() >= 16 and lens.max() > 2048
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], "shallow sparse frame")
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    for _ in range(2):   # (the second frame runs on the first one's hints)
+        t, c, _ = run_gpu(sc, device)
+        c.backward(to_dev(sc["dL_dpix"], device))
+        assert torch.equal(c.detach(), color)
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            r = refg[k]
+            assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+
+
 @pytest.mark.parametrize("wrong_guess", ["no_long_tiles", "capacity_and_no_long_tiles"])
 def test_wrong_guess_about_long_tiles_never_changes_results(wrong_guess, device, monkeypatch):
     """With a hint the frame is enqueued before the host knows whether any tile list exceeds 2048 entries; the caller's

@@ -83,6 +83,13 @@ constexpr uint32_t DEEP_MEAN_MIN = HGS_DEEP_MEAN_MIN;
 // joint render unchanged (136 against 137 us per render), C2 168.6 -> 171.3, C4 140.2 -> 145.4 us.)
 constexpr int LONG_MIN_DENSE = 768;
 constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at least this many of them (a launch has to pay for itself)
+// ... and at most this many: what ONE round of the long tiles' kernel takes (its grid, launch_tile_sort).  A sparse frame's threshold is
+// the lowest of long_min_sparse (deep lists only) / LONG_MIN_SPARSE_SHALLOW / SORT_CAP_SMALL that leaves no more lists than this.  The
+// thresholds were tuned on human-only renders -- a few hundred non-empty tiles --, but "sparse" is every frame under 4 096 non-empty
+// tiles: a 720p scene render (3 600 tiles, 100 000 Gaussians, mean list 600) sent 3 000 lists through the 512-workgroup kernel, round
+// after round, in front of its fused kernel: sort + forward 214 us against 107 with the threshold at 1 024; 20 000 Gaussians at
+// 540 x 960: 125 against 60 us (end of round 5, `HGS_LONG_MIN_SPARSE` sweep; C3's frames have 276 / 346 such lists and keep 256).
+constexpr uint32_t LONG_ONE_ROUND = 512;
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
 constexpr uint32_t N_TOO_MANY = 0xFFFFFFF0u;  // pair counts from here on are reported as "too many" (32-bit list positions)
@@ -108,10 +115,12 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     uint32_t* __restrict__ n_total = sa.n_total;
     uint32_t* __restrict__ large_tiles = sa.large_tiles;
     uint32_t* __restrict__ seg_first = sa.seg_first;
-    const uint32_t capacity = sa.capacity, ticket = sa.ticket, long_min_sparse = sa.long_min_sparse, long_min_dense_arg = sa.long_min_dense_arg;
+    const uint32_t capacity = sa.capacity, ticket = sa.ticket, long_min_dense_arg = sa.long_min_dense_arg;
     unsigned long long* __restrict__ host_slot = sa.host_slot;
-    // (bit 31: the dense threshold was given explicitly -- HGS_LONG_MIN_DENSE -- and applies whatever the frame's deepest list)
+    // (bit 31: the threshold was given explicitly -- HGS_LONG_MIN_DENSE / HGS_LONG_MIN_SPARSE -- and applies whatever the frame's
+    //  deepest list / however many lists it makes long)
     const uint32_t long_min_dense = long_min_dense_arg & 0x7FFFFFFFu, dense_unconditional = long_min_dense_arg >> 31;
+    const uint32_t long_min_sparse = sa.long_min_sparse & 0x7FFFFFFFu, sparse_unconditional = sa.long_min_sparse >> 31;
     __shared__ uint32_t n_long_sh;
     __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
@@ -299,18 +308,28 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     // re-walk overhead only where one wave per quad would walk hundreds of entries -- and from LONG_MIN_SPARSE_SHALLOW on
     // otherwise; in either case only if enough of them exist
     const bool deep_lists = sparse && n_nonempty && total64 >= (unsigned long long)DEEP_MEAN_MIN * n_nonempty;
-    const uint32_t n_sparse_long = deep_lists ? n_large_sparse : n_large_shallow;
-    const bool use_sparse = sparse && n_sparse_long >= LONG_MIN_SPARSE_TILES;
     const uint32_t huge = n_huge & 0xFFFFu, very_deep = n_huge >> 16;   // lists beyond SORT_CAP_MID / beyond SORT_CAP_SMALL entries
+    // (a shallow sparse frame's threshold is the one n_large_shallow counted with; an explicit HGS_LONG_MIN_DENSE below it still applies)
+    const uint32_t shallow_min = dense_unconditional ? min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense) : (uint32_t)LONG_MIN_SPARSE_SHALLOW;
+    // ... the lowest threshold that leaves the long tiles' kernel ONE round of lists (LONG_ONE_ROUND); beyond SORT_CAP_SMALL entries a
+    // list is long however many there are (nothing else sorts it)
+    uint32_t sparse_min = 0u, n_sparse_long = 0u;
+    if (sparse) {
+        if (deep_lists && n_large_sparse >= LONG_MIN_SPARSE_TILES && (n_large_sparse <= LONG_ONE_ROUND || sparse_unconditional))
+            sparse_min = long_min_sparse, n_sparse_long = n_large_sparse;
+        else if (n_large_shallow >= LONG_MIN_SPARSE_TILES && n_large_shallow <= LONG_ONE_ROUND)
+            sparse_min = shallow_min, n_sparse_long = n_large_shallow;
+        else if (n_large_shallow > LONG_ONE_ROUND)
+            sparse_min = (uint32_t)SORT_CAP_SMALL, n_sparse_long = very_deep;
+    }
+    const bool use_sparse = sparse_min != 0u;
     // A dense frame takes the long-tile path (sorted ahead, blended by depth) from long_min_dense entries on only when it holds a list
     // the one-workgroup-per-tile kernel cannot take or walks as a tail (beyond SORT_CAP_SMALL entries); a frame whose deepest lists
     // are merely long (C4's joint render: 1 900) is throughput-bound in that kernel, and the detour cost it 40 us (mid sort 27 + a
     // slower fused kernel, `profiles/r3j_c4_serial_timeline.txt` against round 4's first collection)
     const bool dense_long = very_deep != 0u || dense_unconditional != 0u;
     const uint32_t dense_min = dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
-    // (a shallow sparse frame's threshold is the one n_large_shallow counted with; an explicit HGS_LONG_MIN_DENSE below it still applies)
-    const uint32_t shallow_min = dense_unconditional ? min((uint32_t)LONG_MIN_SPARSE_SHALLOW, long_min_dense) : (uint32_t)LONG_MIN_SPARSE_SHALLOW;
-    const uint32_t threshold = use_sparse ? (deep_lists ? long_min_sparse : shallow_min) : dense_min;
+    const uint32_t threshold = use_sparse ? sparse_min : dense_min;
     const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_long ? n_large_dense : 0u)) ? 1u : 0u;
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;
@@ -424,8 +443,9 @@ static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* ce
     auto clamped = [](int v, int dflt) { v = v > 0 ? v : dflt; return (uint32_t)(v < 64 ? 64 : v > SORT_CAP_SMALL ? SORT_CAP_SMALL : v); };
     const uint32_t long_min_sparse = clamped(sw.long_min_sparse, LONG_MIN_SPARSE), long_min_dense = clamped(sw.long_min_dense, LONG_MIN_DENSE);
     const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
+    const uint32_t sparse_arg = long_min_sparse | (sw.long_min_sparse > 0 ? 0x80000000u : 0u);
     return ScanArgs{tile_count, num_tiles, cell_count, cell_count ? num_cells : 0, ranges, cursor, n_total, large_tiles, seg_first, capacity,
-                    host_slot, ticket, long_min_sparse, dense_arg, ckpt_cap};
+                    host_slot, ticket, sparse_arg, dense_arg, ckpt_cap};
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,

@@ -42,6 +42,18 @@ def main():
             row[mode]["whole_frame_GBps"] = d["whole_frame"]["GB_per_s"]
         out["points"].append(row)
         print(f"P={P}: fwd {row['fwd']['fps']:.0f} FPS, fwd+bwd {row['fwd_bwd']['fps']:.0f} FPS, N={row['num_rendered_N']}", file=sys.stderr)
+    # (round 5) frames under 4 096 non-empty tiles that are NOT a human alone -- 720p and below, every tile covered: "sparse" to the
+    # library's heuristics, whose long-tile threshold such frames choose by how many lists it leaves (binning.hip, LONG_ONE_ROUND)
+    out["smaller_frames"] = []
+    for P, H, W in ((100_000, 720, 1280), (20_000, 540, 960), (60_000, 512, 512), (10_000, 256, 256)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(P), "--height", str(H), "--width", str(W), "--steps", "300",
+                            "--warmup", "40", "--no-cpu-baseline", "--no-two-streams"], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise SystemExit(f"bench.py failed for P={P} {W}x{H}, rc {r.returncode}:\n{r.stderr[-2000:]}")
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out["smaller_frames"].append({"gaussians": P, "height": H, "width": W, "num_rendered_N": d["config"]["num_rendered_N"],
+                                      "fwd_bwd": {"fps": d["value"], "ms": d["ms_per_step"], "host_busy_us": d.get("host_busy_us_per_frame"), "stages_ms": d["stages_ms"]}})
+        print(f"P={P} {W}x{H}: fwd+bwd {d['value']:.0f} FPS", file=sys.stderr)
     # (round 4) the trained-scene profile: 200 000 scene + 110 210 human Gaussians, surfaces / heavy-tailed sizes / reset opacities
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--profile", "trained", "--steps", "300", "--warmup", "40",
                         "--no-cpu-baseline", "--no-two-streams"], capture_output=True, text=True, timeout=600)

@@ -22,7 +22,7 @@ from hugs_amd.renderer import render_human_scene           # noqa: E402
 
 def main(steps=100, warmup=15):
     dev = torch.device("cuda:0")
-    H, W = 1080, 1920
+    H, W = (int(v) for v in os.environ.get("HGS_C4_SIZE", "1080x1920").split("x"))   # (HxW; the BASELINE config is 1080p)
     cam = syn.pinhole_camera(H, W)
     rng = np.random.default_rng(7)
     Ph, Ps = 110_210, 200_000
@@ -111,7 +111,7 @@ def main(steps=100, warmup=15):
                          "frac": round(gbps / bc.HBM_PEAK_GBPS, 5), "algorithmic_bytes_both_renders": int(sb[dom]), "stage_ms_both_renders": stages[dom],
                          "traffic": None}
     extra["box"] = bc.box()
-    print(json.dumps({"stages_ms_both_renders": stages, "workload": "C4: joint (110210+200000) + human-only renders, 1080p, fwd+bwd through both",
+    print(json.dumps({"stages_ms_both_renders": stages, "workload": f"C4: joint (110210+200000) + human-only renders, {W}x{H}, fwd+bwd through both",
                       "concurrent_renders": os.environ.get("HGS_CONCURRENT_RENDERS", "1") != "0",
                       "joint_render": "torch.cat (reference form)" if os.environ.get("HGS_JOINT_CONCAT", "0") == "1" else "second segment (no concatenation)",
                       "ms_per_training_step_raster": round(ms, 4), "steps_per_s": round(1e3 / ms, 1), **extra}))

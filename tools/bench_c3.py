@@ -31,7 +31,7 @@ def main(P=110_210, steps=200, warmup=20):
     t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
     human = {k: t(v, True) for k, v in m.items()}
     human["active_sh_degree"] = 0
-    cam = syn.rotating_camera(3, 10, dist=5.0, fov=0.4, img_size=512)
+    cam = syn.rotating_camera(3, 10, dist=float(os.environ.get("HGS_C3_DIST", "5.0")), fov=0.4, img_size=512)   # (5.0: the reference's canonical rig)
     data = {k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
     bg = torch.ones(3, device=dev)
     w = t(rng.standard_normal((3, 512, 512)) * 1e-3)

@@ -688,6 +688,47 @@ def test_shallow_sparse_frame_with_a_few_long_lists(device):
             assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
 
 
+@pytest.mark.parametrize("long_min", [None, "256"])
+def test_covered_frame_under_4096_tiles_with_thousands_of_deep_lists(long_min, device, monkeypatch):
+    """A "sparse" frame that is not a human alone: 960 x 540, every one of its 2 040 tiles covered a few hundred entries deep (mean
+    368: deep lists), a stack in the middle (35 lists beyond 1 024 entries, 16 beyond 2 048).  The long-tile threshold of such a
+    frame is the lowest of 256 / 1 024 / 2 048 that leaves the long tiles' kernel at most one round of 512 lists (binning.hip,
+    LONG_ONE_ROUND): 1 024 here -- 35 long lists, blended by the depth-parallel workers -- where 256 (still what an explicit
+    HGS_LONG_MIN_SPARSE=256 gives: 2 040 long lists, four rounds) cost a 720p scene render a third of its frame rate.  Both ways:
+    lists position by position, image and gradients against the oracle."""
+    from diff_gaussian_rasterization import _debug_forward_state
+    sc = _stacked_scene(30000, 540, 960, seed=62, spread_px=44.0)
+    cover = make_scene(P=24000, H=540, W=960, seed=61, D=1, sigma_px=8.0, with_culled=False)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        sc[k] = np.concatenate([sc[k], np.asarray(cover[k], np.float32).reshape((-1,) + sc[k].shape[1:])], 0)
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    nonempty = lens[lens > 0]
+    assert len(nonempty) < 4096 and nonempty.mean() >= 200 and (lens > 256).sum() > 512 and 16 <= (lens > 1024).sum() <= 512
+    if long_min:
+        monkeypatch.setenv("HGS_LONG_MIN_SPARSE", long_min)
+        reload_switches(monkeypatch)
+    t = gpu_tensors(sc, device, grad=False)
+    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    check_image(color.cpu().numpy(), ref["color"], "covered 960x540 frame")
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    for _ in range(2):   # (the second frame runs on the first one's hints)
+        t, c, _ = run_gpu(sc, device)
+        c.backward(to_dev(sc["dL_dpix"], device))
+        assert torch.equal(c.detach(), color)
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            r = refg[k]
+            assert rel_l2(t[k].grad.cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, k
+    if long_min:
+        monkeypatch.delenv("HGS_LONG_MIN_SPARSE")
+        reload_switches(monkeypatch)
+
+
 @pytest.mark.parametrize("wrong_guess", ["no_long_tiles", "capacity_and_no_long_tiles"])
 def test_wrong_guess_about_long_tiles_never_changes_results(wrong_guess, device, monkeypatch):
     """With a hint the frame is enqueued before the host knows whether any tile list exceeds 2048 entries; the caller's

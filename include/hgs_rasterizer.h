@@ -111,6 +111,15 @@ typedef struct hgs_forward_args {
     const float *scales;         /* [P,3] or NULL */
     const float *rotations;      /* [P,4] (w,x,y,z), not normalised, or NULL */
     const float *cov3D_precomp;  /* [P,6] or NULL (exactly one of (scales,rotations) / cov3D_precomp) */
+    /* Inputs the library rejects PER GAUSSIAN (radius 0, no list entries, zero gradients) beyond the published culls (view-space
+     * z <= 0.2; det == 0; an empty tile rectangle): a Gaussian whose PROJECTED 2-D covariance (a, b, c) -- after the 0.3 low-pass --
+     * is not positive definite, i.e. not (a c - b^2 > 0 and a > 0).  R S^2 R^T + 0.3 I always is; only a cov3D_precomp that is not
+     * positive semi-definite gets there (the reference never passes one: gs_renderer.py:144-152 hands over scales + rotations).
+     * The published algorithm rasterizes such a Gaussian and blends it wherever its exponent happens to be
+     * <= 0 -- a hyperbolic region of the image; the blend kernels here evaluate the exponent through the conic's Cholesky factors
+     * (hgs_common.h), which exist only for a positive-definite conic.  oracle/hgs_oracle.c applies the same rule behind
+     * oracle_set_cull_non_pd(1); tests/test_gpu_corner_semantics.py holds the library to it and shows where the two semantics part.
+     * Non-finite centres, radii or covariances are culled as well (NaN compares false throughout). */
     float *out_color;            /* [3,H,W], written for every pixel when P > 0 */
     int32_t *radii;              /* [P (+ seg2.P)] */
     /* Optional guess (entries) of N, the number of (tile, Gaussian) pairs -- e.g. last frame's N plus a margin; 0 =

@@ -100,7 +100,16 @@ struct ScanArgs {
     uint2* ranges; uint32_t* cursor; uint32_t* n_total; uint32_t* large_tiles; uint32_t* seg_first; uint32_t capacity;
     unsigned long long* host_slot; uint32_t ticket, long_min_sparse, long_min_dense_arg;
     uint32_t ckpt_cap;   // checkpoint slots the frame's buffer was laid out for (0: enough for whatever this frame needs)
+    uint32_t force_kind; // HGS_FRAME_KIND: 0 = the rule below, 1 = sparse, 2 = dense (A/B measurements: tools/shape_scan.py)
 };
+
+// SPARSE or DENSE: the one decision the rest of the frame's path selection hangs on (the backward's form, the checkpoint layout, the
+// long-list thresholds).  Dense = one backward wave per tile keeps the SIMDs busy: at least four waves on each of the 1 024.
+__device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, uint32_t force_kind)
+{
+    if (force_kind) return force_kind == 1u ? 1u : 0u;
+    return n_nonempty < 4096u ? 1u : 0u;
+}
 
 // The scan as a workgroup of 1024 threads.  ZERO: re-zero the counters it has read (the stand-alone kernel, their only reader);
 // !ZERO: other workgroups of the same launch read them too, and the last of them to arrive zeroes them (emit_scan_kernel).
@@ -193,7 +202,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
                 total2 += v;
             }
         }
-        const bool dense_now = single_trip && n_nonempty >= 4096u;   // (the packed slot layout can be written right here)
+        const bool dense_now = single_trip && !frame_is_sparse(n_nonempty, sa.force_kind);   // (the packed slot layout can be written right here)
         __syncthreads();
         uint32_t start = carry + before + inc - mine;
         uint32_t st[SCAN_ITEMS];
@@ -258,7 +267,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         if (lane == 0 && x) atomicMax(&longest, x);
     }
     __syncthreads();
-    const uint32_t sparse_kind = n_nonempty < 4096u ? 1u : 0u;
+    const uint32_t sparse_kind = frame_is_sparse(n_nonempty, sa.force_kind);
     const uint32_t lowest = sparse_kind ? min(long_min_sparse, (uint32_t)LONG_MIN_SPARSE_SHALLOW) : long_min_dense;
     if (longest > lowest) {   // (workgroup-uniform) count the lists beyond each threshold from the ranges this workgroup wrote
         for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {
@@ -302,7 +311,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     if (total64 >= (unsigned long long)N_TOO_MANY) carry = 0xFFFFFFFFu;
     // a SPARSE frame: one wave per non-empty tile would leave the SIMDs (1 024 of them) under four waves each --
     // the backward blend then splits long tiles over four waves
-    const uint32_t sparse = n_nonempty < 4096u ? 1u : 0u;
+    const uint32_t sparse = sparse_kind;
     // this frame's long-tile threshold (n_total[4]).  Sparse frames: lists from long_min_sparse entries on are long (sorted
     // ahead, blended split by depth) when the frame's lists are deep on average -- depth parallelism pays for its compose +
     // re-walk overhead only where one wave per quad would walk hundreds of entries -- and from LONG_MIN_SPARSE_SHALLOW on
@@ -445,7 +454,7 @@ static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* ce
     const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
     const uint32_t sparse_arg = long_min_sparse | (sw.long_min_sparse > 0 ? 0x80000000u : 0u);
     return ScanArgs{tile_count, num_tiles, cell_count, cell_count ? num_cells : 0, ranges, cursor, n_total, large_tiles, seg_first, capacity,
-                    host_slot, ticket, sparse_arg, dense_arg, ckpt_cap};
+                    host_slot, ticket, sparse_arg, dense_arg, ckpt_cap, sw.frame_kind == 's' ? 1u : sw.frame_kind == 'd' ? 2u : 0u};
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,

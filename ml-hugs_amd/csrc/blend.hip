@@ -468,8 +468,8 @@ void launch_blend_backward(const Camera& cam, int P, const uint2* ranges, const 
                            const Ckpt& ck, int64_t num_rendered, int64_t dense_slots, hipStream_t st)
 {
     const int num_tiles = cam.gx * cam.gy;
-    static const char* force = getenv("HGS_BWD_WAVES_PER_TILE");  // "1" / "4": measurement override
-    const bool per_quad = force ? force[0] == '4' : sparse_frame;
+    const int force = switches().bwd_waves_per_tile;  // HGS_BWD_WAVES_PER_TILE = 1 / 4: measurement override
+    const bool per_quad = force ? force == 4 : sparse_frame;
     if (ck.state) {
         // the forward left checkpoints: for every tile of a sparse frame, for the deep tiles (CKPT_DEEP_MIN) of a dense one --
         // whose other tiles go through the one-wave-per-tile kernel as always (both add into the same accumulator)

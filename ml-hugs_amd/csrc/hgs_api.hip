@@ -32,35 +32,52 @@ int fail(int code, const char* fmt, ...)
 }  // namespace
 
 namespace {
-std::mutex g_sw_mu;
-hgs::Switches g_sw;
-std::atomic<bool> g_sw_loaded{false};
-void load_switches()
+// The A/B switches (hgs_common.h) are published as an IMMUTABLE snapshot: a reload builds a new one and swaps the pointer, and every
+// entry point copies the snapshot once, at entry, into a thread-local block that the launch paths below it read (FrameSwitches) --
+// a frame never sees a mix of two loads, whatever other threads render or reload meanwhile.
+std::shared_ptr<const hgs::Switches> g_sw_snapshot;   // (std::atomic_load / std::atomic_store)
+std::once_flag g_sw_once;
+std::shared_ptr<const hgs::Switches> read_switches_from_env()
 {
     auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
-    hgs::Switches s;
+    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };   // default on
+    auto on = [](const char* name) { const char* e = getenv(name); return e && e[0] == '1'; };    // default off
+    auto s = std::make_shared<hgs::Switches>();
     const char* e = getenv("HGS_BIN_MODE");
-    s.bin_mode = e && (e[0] == 'c' || e[0] == 'o') ? e[0] : 0;
-    e = getenv("HGS_BWD_TWO_LAUNCHES");
-    s.bwd_two_launches = e && e[0] == '1';
-    e = getenv("HGS_DEEP_FORWARD");
-    s.deep_forward = !(e && e[0] == '0');
-    s.long_min_sparse = num("HGS_LONG_MIN_SPARSE"), s.long_min_dense = num("HGS_LONG_MIN_DENSE");
-    e = getenv("HGS_EMIT_SCAN");
-    s.emit_scan = !(e && e[0] == '0');
-    e = getenv("HGS_K1_STAGE_SH");
-    s.k1_stage_sh = e && e[0] == '1';
+    s->bin_mode = e && (e[0] == 'c' || e[0] == 'o') ? e[0] : 0;
+    s->bwd_two_launches = on("HGS_BWD_TWO_LAUNCHES");
+    s->deep_forward = !off("HGS_DEEP_FORWARD");
+    s->long_min_sparse = num("HGS_LONG_MIN_SPARSE"), s->long_min_dense = num("HGS_LONG_MIN_DENSE");
+    s->emit_scan = !off("HGS_EMIT_SCAN");
+    s->k1_stage_sh = on("HGS_K1_STAGE_SH");
     e = getenv("HGS_BIG_PER_GROUP");
-    s.big_per_group = e ? std::max(0, std::min(atoi(e), 64)) : hgs::BIG_PER_GROUP;
-    std::lock_guard<std::mutex> lk(g_sw_mu);
-    g_sw = s;
-    g_sw_loaded.store(true, std::memory_order_release);
+    s->big_per_group = e ? std::max(0, std::min(atoi(e), 64)) : hgs::BIG_PER_GROUP;
+    s->bwd_segmented = !off("HGS_BWD_SEGMENTED");
+    s->fused_sort_blend = !off("HGS_FUSED_SORT_BLEND");
+    e = getenv("HGS_BWD_WAVES_PER_TILE");
+    s->bwd_waves_per_tile = e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0;
+    e = getenv("HGS_K8_COOP");
+    s->k8_coop = e ? atoi(e) : -1;
+    e = getenv("HGS_FRAME_KIND");
+    s->frame_kind = e && (e[0] == 's' || e[0] == 'd') ? e[0] : 0;
+    return s;
 }
+std::shared_ptr<const hgs::Switches> snapshot()
+{
+    std::call_once(g_sw_once, [] { std::atomic_store(&g_sw_snapshot, read_switches_from_env()); });
+    return std::atomic_load(&g_sw_snapshot);
+}
+thread_local hgs::Switches t_sw;          // this thread's copy: the frame's, while an entry point is running
+thread_local int t_sw_depth = 0;
+struct FrameSwitches {   // RAII at the top of every entry point that launches
+    FrameSwitches() { if (t_sw_depth++ == 0) t_sw = *snapshot(); }
+    ~FrameSwitches() { --t_sw_depth; }
+};
 }  // namespace
 const hgs::Switches& hgs::switches()
 {
-    if (!g_sw_loaded.load(std::memory_order_acquire)) load_switches();
-    return g_sw;
+    if (t_sw_depth == 0) t_sw = *snapshot();   // (outside an entry point: a fresh copy per question)
+    return t_sw;
 }
 
 // for the other translation units (densify.hip, knn.hip): message behind hgs_last_error() on this thread
@@ -491,7 +508,11 @@ size_t hgs_binning_bytes(int64_t N, int32_t, int32_t) { return BinningLayout(N).
 size_t hgs_ckpt_bytes(int64_t N, int32_t H, int32_t W) { return CkptLayout(N, num_tiles_of(H, W)).total; }
 size_t hgs_ckpt_bytes_for_slots(int64_t slots) { return CkptLayout((size_t)(slots < 1 ? 1 : slots)).total; }
 
-void hgs_reload_switches(void) { load_switches(); }
+void hgs_reload_switches(void)
+{
+    (void)snapshot();   // (the first load must not overwrite this one afterwards)
+    std::atomic_store(&g_sw_snapshot, read_switches_from_env());
+}
 
 int64_t hgs_debug_stat(const char* name)
 {
@@ -532,6 +553,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
 {
     if (!args || !alloc || !state) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
     StatScope stat(g_stat_fwd_calls, g_stat_fwd_ns);
+    FrameSwitches frame_switches;   // one snapshot of the A/B switches for everything this frame launches
     const hgs_forward_args& a = *args;
     hipStream_t st = (hipStream_t)stream;
     Camera cam;
@@ -541,8 +563,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     if (!a.out_color || !a.radii) return fail(HGS_ERR_INVALID_ARGUMENT, "out_color and radii are required");
     const bool dbg = a.s.debug != 0;
     // HGS_BWD_SEGMENTED=0: never leave checkpoints (backward then runs one wave per quad on sparse frames; A/B measurements)
-    static const bool seg_allowed = [] { const char* e = getenv("HGS_BWD_SEGMENTED"); return !(e && e[0] == '0'); }();
-    bool want_ckpt = a.backward_checkpoints != 0 && seg_allowed;
+    bool want_ckpt = a.backward_checkpoints != 0 && switches().bwd_segmented;
 
     const int num_tiles = cam.gx * cam.gy;
     const int Ptot = a.P + a.seg2.P;  // Gaussian indices run over both segments
@@ -636,7 +657,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // the long-tile sort is launched unless the caller expects no long tile (its previous frame of this shape had none)
     const bool guess_no_long = a.expect_no_long_tiles != 0;
     // HGS_FUSED_SORT_BLEND=0: separate tile-sort and forward-blend kernels (A/B measurements); default: fused
-    static const bool fused = [] { const char* e = getenv("HGS_FUSED_SORT_BLEND"); return !(e && e[0] == '0'); }();
+    const bool fused = switches().fused_sort_blend;
     float* final_T = (float*)(image + il.final_T);
     uint32_t* n_contrib = (uint32_t*)(image + il.n_contrib);
     FusedBlend fb{cam, (uint32_t)(Ptot - 1), splats, a.s.bg, a.out_color, final_T, n_contrib, a.clamp_output != 0 ? 1 : 0, Ckpt{}};
@@ -796,6 +817,7 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
 {
     if (!args) return fail(HGS_ERR_INVALID_ARGUMENT, "null argument");
     StatScope stat(g_stat_bwd_calls, g_stat_bwd_ns);
+    FrameSwitches frame_switches;
     const hgs_backward_args& a = *args;
     const hgs_forward_args& f = a.fwd;
     hipStream_t st = (hipStream_t)stream;
@@ -810,6 +832,19 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
     if (!a.dL_dout_color || !a.dL_dmeans2D || !a.grad_accum || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmeans3D ||
         !a.dL_dcov3D || !a.dL_dscales || !a.dL_drotations || (f.shs && !a.dL_dsh))
         return fail(HGS_ERR_INVALID_ARGUMENT, "gradient buffers are required");
+    // the other render's gradients (add_*): all or none, checked BEFORE anything is launched -- a rejected call leaves the accumulator as it was
+    if (a.add_dL_dopacity || a.add_dL_dcolors || a.add_dL_dmeans3D || a.add_dL_dcov3D || a.add_dL_dsh || a.add_dL_dscales || a.add_dL_drotations) {
+        if (!a.add_dL_dopacity || !a.add_dL_dcolors || !a.add_dL_dmeans3D || !a.add_dL_dcov3D || !a.add_dL_dscales || !a.add_dL_drotations ||
+            (f.shs && !a.add_dL_dsh))
+            return fail(HGS_ERR_INVALID_ARGUMENT, "add_*: all of the other render's gradient buffers are required");
+        if ((((uintptr_t)a.add_dL_drotations) & 15u) != 0) return fail(HGS_ERR_INVALID_ARGUMENT, "add_dL_drotations must be 16-byte aligned");
+        // ... and none of them may BE this call's output of the same kind (the kernel reads the one while it writes the other;
+        // equal base pointers are what a caller gets wrong -- partial overlaps of distinct allocations cannot be told from here)
+        if (a.add_dL_dopacity == a.dL_dopacity || a.add_dL_dcolors == a.dL_dcolors || a.add_dL_dmeans3D == a.dL_dmeans3D ||
+            a.add_dL_dcov3D == a.dL_dcov3D || (a.add_dL_dsh && a.add_dL_dsh == a.dL_dsh) || a.add_dL_dscales == a.dL_dscales ||
+            a.add_dL_drotations == a.dL_drotations)
+            return fail(HGS_ERR_INVALID_ARGUMENT, "add_*: the other render's gradient buffers may not alias this call's outputs");
+    }
     const bool dbg = f.s.debug != 0;
     const int Ptot = f.P + f.seg2.P;
     if (f.seg2.P > 0 && (!a.seg2_dL_dopacity || !a.seg2_dL_dcolors || !a.seg2_dL_dmeans3D || !a.seg2_dL_dcov3D || !a.seg2_dL_dscales ||
@@ -851,12 +886,6 @@ int32_t hgs_rasterize_backward(const hgs_backward_args* args, void* stream)
                             f.s.bg, (const float*)(image + il.final_T), (const uint32_t*)(image + il.n_contrib), a.dL_dout_color,
                             a.grad_accum, ck, a.state.num_rendered, dense_slots, st); }
     STAGE_CHECK(dbg, st, "blend_backward");
-    if (a.add_dL_dopacity || a.add_dL_dcolors || a.add_dL_dmeans3D || a.add_dL_dcov3D || a.add_dL_dsh || a.add_dL_dscales || a.add_dL_drotations) {
-        if (!a.add_dL_dopacity || !a.add_dL_dcolors || !a.add_dL_dmeans3D || !a.add_dL_dcov3D || !a.add_dL_dscales || !a.add_dL_drotations ||
-            (f.shs && !a.add_dL_dsh))
-            return fail(HGS_ERR_INVALID_ARGUMENT, "add_*: all of the other render's gradient buffers are required");
-        if ((((uintptr_t)a.add_dL_drotations) & 15u) != 0) return fail(HGS_ERR_INVALID_ARGUMENT, "add_dL_drotations must be 16-byte aligned");
-    }
     if (a.wait_before_per_gaussian) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)a.wait_before_per_gaussian, 0));
     { ProfScope ps(HGS_STAGE_PREPROCESS_BACKWARD, st); launch_preprocess_backward(a, cam, splats, st); }
     STAGE_CHECK(dbg, st, "preprocess_backward");

@@ -209,7 +209,8 @@ struct BinningLayout {
 void set_last_error(const char* msg);  // hgs_api.hip
 
 // The A/B switches that launch paths consult, read from the environment ONCE (at the first frame) -- not with a getenv per launch;
-// hgs_reload_switches() (tests, A/B tools that flip them inside one process) reads them again.  hgs_api.hip.
+// hgs_reload_switches() (tests, A/B tools that flip them inside one process) reads them again.  Published as an immutable snapshot
+// that every entry point copies at entry: switches() below is that copy, stable for the whole frame (hgs_api.hip).
 struct Switches {
     int bin_mode;               // HGS_BIN_MODE: 0 = the library's choice, 'c' = by cell, 'o' = in order
     bool bwd_two_launches;      // HGS_BWD_TWO_LAUNCHES=1: dense frames with checkpoints run the two backward forms as two launches
@@ -219,6 +220,11 @@ struct Switches {
     bool emit_scan;             // HGS_EMIT_SCAN=0: always the stand-alone tile scan kernel (else: folded into emit where it applies)
     bool k1_stage_sh;           // HGS_K1_STAGE_SH=1: the preprocess kernel fetches the SH rows through LDS (measured no faster: off)
     int big_per_group;          // HGS_BIG_PER_GROUP: big splats per binning group of their own (default BIG_PER_GROUP; 0: spread over the cells as round 4 did)
+    bool bwd_segmented;         // HGS_BWD_SEGMENTED=0: never leave checkpoints (backward then runs one wave per quad / per tile)
+    bool fused_sort_blend;      // HGS_FUSED_SORT_BLEND=0: separate tile-sort and forward-blend kernels
+    int bwd_waves_per_tile;     // HGS_BWD_WAVES_PER_TILE: 0 = by the frame's kind, 1 / 4 = forced (frames without checkpoints)
+    int k8_coop;                // HGS_K8_COOP: -1 = default, else coop_mode of the per-Gaussian backward
+    int frame_kind;             // HGS_FRAME_KIND: 0 = the scan's rule, 's' = every frame sparse, 'd' = every frame dense (tools/shape_scan.py)
 };
 const Switches& switches();
 

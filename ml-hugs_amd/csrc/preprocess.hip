@@ -275,7 +275,11 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
             Ewa e;
             ewa_project(pv, cam, V, S, e);
             float det = e.a * e.c - e.b * e.b;
-            alive = !(det == 0.0f || det != det);
+            // (A.2 step 5 culls det == 0; a projected covariance that is not POSITIVE DEFINITE -- det < 0 or a < 0, reachable only
+            //  through a non-PSD cov3D_precomp -- is culled here as well: the blend kernels' Cholesky form of the exponent exists
+            //  only for a positive-definite conic.  Documented in include/hgs_rasterizer.h; the oracle mirrors the rule behind
+            //  oracle_set_cull_non_pd.  NaN compares false.)
+            alive = det > 0.0f && e.a > 0.0f;
             if (alive) {
                 float det_inv = 1.0f / det;
                 float mid = 0.5f * (e.a + e.c);
@@ -842,7 +846,7 @@ void launch_preprocess_backward(const hgs_backward_args& a, const Camera& cam, c
                            a.seg2_dL_drotations, a.seg2_dL_dcov3D};
     const FirstAdds add1{a.add_dL_dopacity, a.add_dL_dcolors, a.add_dL_dmeans3D, a.add_dL_dsh, a.add_dL_dscales, a.add_dL_drotations,
                          a.add_dL_dcov3D};
-    static const int forced = [] { const char* e = getenv("HGS_K8_COOP"); return e ? atoi(e) : -1; }();   // measurement override
+    const int forced = switches().k8_coop;   // HGS_K8_COOP: measurement override
     // default: the wave STORES the rows; loading them through LDS as well was measured slower at every degree (C2, degree 3:
     // 37.0 us per-thread / 32.0 store only / 39.4 load + store; degree 1: 38.3 / 25.5 / 27.9 -- the round trip through LDS
     // sits in front of the whole per-Gaussian computation)

@@ -111,13 +111,13 @@ Tensor arena_for(int dev, void* stream, size_t bytes, const at::TensorOptions& b
 // The gradient sink of render() -- `viewspace_points`, a zero [P,3] leaf that requires grad (gs_renderer.py:107-113) -- without a
 // fill kernel per frame: every frame's tensor is a fresh leaf over the SAME zero-filled storage (one per device, grown on demand).
 // Nothing writes into it: the rasterizer never reads means2D, and autograd refuses in-place operations on a leaf that requires grad.
-std::map<int, Tensor> g_zeros;
+std::map<std::pair<int, int>, Tensor> g_zeros;   // per (device, dtype): the reference's zeros_like(means3D) follows means3D's dtype
 Tensor viewspace_zeros(int64_t rows, const at::TensorOptions& fopts)
 {
     Tensor base;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        Tensor& z = g_zeros[(int)fopts.device().index()];
+        Tensor& z = g_zeros[{(int)fopts.device().index(), (int)c10::typeMetaToScalarType(fopts.dtype())}];
         if (!z.defined() || z.size(0) < rows) z = at::zeros({std::max<int64_t>(rows + rows / 4 + 1024, 4096), 3}, fopts);
         base = z;
     }
@@ -411,16 +411,24 @@ struct RasterNode : public torch::autograd::Node {
         }
     }
 
+    // A second backward through the node (retain_graph): the frame gets a fresh slab with a zeroed accumulator.  Allocation and fill
+    // run on the CALLER's stream -- so this is called for every frame of the node BEFORE the side stream is fenced behind the caller's:
+    // the human-only frame's blend backward adds atomically into its accumulator on the side stream, and must be ordered after the
+    // fill (and after whatever the caching allocator's block still had pending on the caller's stream).
+    void refresh_slab(Frame& fr)
+    {
+        if (fr.fresh) return;
+        fr.slab = at::empty({fr.gl.total}, fr.a.means3D.options());
+        fr.slab.narrow(0, 0, std::max<int64_t>(fr.gl.off[1], 1)).zero_();
+        point_at_grads(fr.bw, fr.slab.data_ptr<float>(), fr.gl, fr.bw.fwd.M, fr.bw.fwd.seg2.M);
+        fr.fresh = true;   // (as good as the forward's)
+    }
+
     // one frame's backward on `stream`; `add_from`: the frame whose first-set gradients are added in (ready once `wait` has fired)
     void run_backward(Frame& fr, const Tensor& g_color, hipStream_t stream, const Frame* add_from, hipEvent_t wait)
     {
         hgs_backward_args& bw = fr.bw;
-        const int64_t M = bw.fwd.M, M2 = bw.fwd.seg2.M;
-        if (!fr.fresh) {   // a second backward (retain_graph): a fresh slab with a zeroed accumulator
-            fr.slab = at::empty({fr.gl.total}, fr.a.means3D.options());
-            fr.slab.narrow(0, 0, std::max<int64_t>(fr.gl.off[1], 1)).zero_();
-            point_at_grads(bw, fr.slab.data_ptr<float>(), fr.gl, M, M2);
-        }
+        TORCH_INTERNAL_ASSERT(fr.fresh, "refresh_slab() goes first");
         fr.fresh = false;
         bw.dL_dout_color = g_color.data_ptr<float>();
         bw.flags = g_upstream_scale_grad ? HGS_BWD_UPSTREAM_SCALE_GRAD : 0u;
@@ -464,13 +472,16 @@ struct RasterNode : public torch::autograd::Node {
             Tensor ga = f32c(grads[0]), gb = f32c(grads[1]);
             Events& ev = events_for((int)dev.index());
             const hipStream_t side = side_stream((int)dev.index()).stream();
+            refresh_slab(f[1]), refresh_slab(J);           // (a second backward: both slabs are made and zeroed on `main`, in front of the fence)
             fence(ev.a, main, side);                       // dL/dimage was produced on the caller's stream
             run_backward(f[1], gb, side, nullptr, nullptr);
             TORCH_CHECK(hipEventRecord(ev.b, side) == hipSuccess, "hipEventRecord failed");
             run_backward(J, ga, main, &f[1], ev.b);        // (main has waited for the side stream when this returns)
         } else if (g0) {
+            refresh_slab(J);
             run_backward(J, f32c(grads[0]), main, nullptr, nullptr);
         } else {
+            refresh_slab(f[1]);
             run_backward(f[1], f32c(grads[1]), main, nullptr, nullptr);
             src = &f[1];
         }

@@ -34,6 +34,7 @@
 #include <string.h>
 
 static int g_upstream_scale_grad = 0; /* see oracle_preprocess_backward */
+static int g_cull_non_pd = 0;         /* see oracle_preprocess */
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -221,6 +222,14 @@ void oracle_preprocess(int P, int M, int D, int H, int W, real tanfovx, real tan
         ewa_project(pv, fx, fy, tanfovx, tanfovy, V, S, &e);
         real det = e.a * e.c - e.b * e.b;
         if (det == 0 || det != det) continue;
+        /* The published algorithm culls det == 0 only: a projected covariance that is NOT positive
+         * definite (det < 0, or a < 0 -- reachable only through a non-PSD cov3D_precomp; R S^2 R^T + 0.3 I never is) is
+         * rasterized, and blends wherever its "power" happens to be <= 0 (a hyperbolic region of the image).  The HIP library
+         * culls such a Gaussian (radius 0, include/hgs_rasterizer.h "Inputs the library rejects per Gaussian"): its blend
+         * kernels evaluate the exponent through the conic's Cholesky factors, which exist only for a positive-definite
+         * conic.  oracle_set_cull_non_pd(1) makes this checker apply the library's rule, so that radii / N / lists / image /
+         * gradients can be compared exactly on such inputs; the default (0) is the published behaviour. */
+        if (g_cull_non_pd && !(det > 0 && e.a > 0)) continue;
         real det_inv = R_(1) / det;
         real cx = e.c * det_inv, cy = -e.b * det_inv, cz = e.a * det_inv;
         real mid = R_(0.5) * (e.a + e.c);
@@ -704,6 +713,7 @@ void oracle_mark_visible(int P, const real *means3D, const real *V, uint8_t *pre
 }
 
 void oracle_set_upstream_scale_grad(int on) { g_upstream_scale_grad = on; }
+void oracle_set_cull_non_pd(int on) { g_cull_non_pd = on; }
 
 void oracle_set_threads(int n)
 {

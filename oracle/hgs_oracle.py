@@ -91,13 +91,22 @@ def set_upstream_scale_grad(on):
         _lib(d).oracle_set_upstream_scale_grad(int(bool(on)))
 
 
+def set_cull_non_pd(on):
+    """True: Gaussians whose projected 2-D covariance is not positive definite (det <= 0 or a <= 0: only reachable through a
+    non-PSD cov3D_precomp) are culled, as the HIP library does (include/hgs_rasterizer.h); False (default): the published
+    algorithm, which culls det == 0 only and blends such a splat wherever its exponent happens to be <= 0."""
+    for d in (np.float32, np.float64):
+        _lib(d).oracle_set_cull_non_pd(int(bool(on)))
+
+
 class Inputs:
     """Plain container of rasterizer inputs (numpy). Shapes as SURVEY.md 8a."""
 
     def __init__(self, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, image_height,
                  image_width, bg, shs=None, colors_precomp=None, scales=None, rotations=None,
-                 cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, dtype=np.float32):
+                 cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, dtype=np.float32, cull_non_pd=False):
         self.dtype = np.dtype(dtype)
+        self.cull_non_pd = bool(cull_non_pd)   # the HIP library's rule for projected covariances that are not positive definite (set_cull_non_pd)
         d = self.dtype
         self.means3D = _arr(means3D, d, (-1, 3))
         self.P = self.means3D.shape[0]
@@ -152,12 +161,16 @@ def forward(inp, stop_after=None):
     o["values"] = np.zeros(0, np.uint32)
     if P == 0:
         return o  # A.6 quirk 8: colour stays zero, no background
-    lib.oracle_preprocess(
-        C.c_int(P), C.c_int(inp.M), C.c_int(inp.D), C.c_int(H), C.c_int(W), r(inp.tanfovx), r(inp.tanfovy),
-        r(inp.mod), _p(inp.means3D), _p(inp.shs), _p(inp.colors_precomp), _p(inp.opacities), _p(inp.scales),
-        _p(inp.rotations), _p(inp.cov3D_precomp), _p(inp.viewmatrix), _p(inp.projmatrix), _p(inp.campos),
-        _p(o["depths"]), _p(o["xy"]), _p(o["conic_opacity"]), _p(o["rgb"]), _p(o["cov3D"]), _p(o["clamped"]),
-        _p(o["radii"]), _p(o["rect"]), _p(o["tiles_touched"]))
+    lib.oracle_set_cull_non_pd(int(getattr(inp, "cull_non_pd", False)))
+    try:
+        lib.oracle_preprocess(
+            C.c_int(P), C.c_int(inp.M), C.c_int(inp.D), C.c_int(H), C.c_int(W), r(inp.tanfovx), r(inp.tanfovy),
+            r(inp.mod), _p(inp.means3D), _p(inp.shs), _p(inp.colors_precomp), _p(inp.opacities), _p(inp.scales),
+            _p(inp.rotations), _p(inp.cov3D_precomp), _p(inp.viewmatrix), _p(inp.projmatrix), _p(inp.campos),
+            _p(o["depths"]), _p(o["xy"]), _p(o["conic_opacity"]), _p(o["rgb"]), _p(o["cov3D"]), _p(o["clamped"]),
+            _p(o["radii"]), _p(o["rect"]), _p(o["tiles_touched"]))
+    finally:
+        lib.oracle_set_cull_non_pd(0)
     if stop_after == "preprocess":
         return o
     N = int(lib.oracle_scan(C.c_int(P), _p(o["tiles_touched"]), _p(o["offsets"])))

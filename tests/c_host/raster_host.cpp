@@ -13,6 +13,7 @@
 //
 //   in.bin : int32 P, M, H, W, D, use_hint | float tanfovx, tanfovy, scale_modifier | bg[3] view[16] proj[16] campos[3]
 //            means3D[3P] shs[3MP] opacities[P] scales[3P] rotations[4P] dL_dcolor[3HW]
+//            (use_hint = 5: cov3D_precomp[6P] in place of scales and rotations; out.bin then ends with dL_dcov3D[6P])
 //   out.bin: int64 N | color[3HW] | int32 radii[P] | dL_dmeans3D[3P] dL_dmeans2D[3P] dL_dopacity[P] dL_dsh[3MP]
 //            dL_dscales[3P] dL_drotations[4P]
 #include <hip/hip_runtime.h>
@@ -82,10 +83,12 @@ int main(int argc, char** argv)
     float fl[3];
     if (fread(hdr, 4, 6, f) != 6 || fread(fl, 4, 3, f) != 3) return 1;
     const int P = hdr[0], M = hdr[1], H = hdr[2], W = hdr[3], D = hdr[4], use_hint = hdr[5];
-    std::vector<float> bg, view, proj, campos, means, shs, opac, scales, rots, dL;
+    const bool cov_mode = use_hint == 5;   // (mode 5: precomputed 3-D covariances where the scales and rotations would be)
+    std::vector<float> bg, view, proj, campos, means, shs, opac, scales, rots, cov, dL;
     if (!read_vec(f, bg, 3) || !read_vec(f, view, 16) || !read_vec(f, proj, 16) || !read_vec(f, campos, 3) ||
         !read_vec(f, means, 3 * (size_t)P) || !read_vec(f, shs, 3 * (size_t)M * P) || !read_vec(f, opac, P) ||
-        !read_vec(f, scales, 3 * (size_t)P) || !read_vec(f, rots, 4 * (size_t)P) || !read_vec(f, dL, 3 * (size_t)H * W))
+        !(cov_mode ? read_vec(f, cov, 6 * (size_t)P) : (read_vec(f, scales, 3 * (size_t)P) && read_vec(f, rots, 4 * (size_t)P))) ||
+        !read_vec(f, dL, 3 * (size_t)H * W))
         return fprintf(stderr, "short input file\n"), 1;
     fclose(f);
 
@@ -98,7 +101,8 @@ int main(int argc, char** argv)
     a.s.sh_degree = D, a.s.prefiltered = 0, a.s.debug = 0;
     a.P = P, a.M = M;
     a.means3D = to_device(means), a.shs = to_device(shs), a.opacities = to_device(opac);
-    a.scales = to_device(scales), a.rotations = to_device(rots);
+    if (cov_mode) a.cov3D_precomp = to_device(cov);
+    else a.scales = to_device(scales), a.rotations = to_device(rots);
     float* color = device_buffer<float>(3 * (size_t)H * W);
     int32_t* radii = device_buffer<int32_t>(P);
     a.out_color = color, a.radii = radii;
@@ -206,8 +210,11 @@ int main(int argc, char** argv)
     write_dev(o, bw.dL_dmeans2D, 3 * (size_t)P);
     write_dev(o, bw.dL_dopacity, P);
     write_dev(o, bw.dL_dsh, 3 * (size_t)M * P);
-    write_dev(o, bw.dL_dscales, 3 * (size_t)P);
-    write_dev(o, bw.dL_drotations, 4 * (size_t)P);
+    if (cov_mode) write_dev(o, bw.dL_dcov3D, 6 * (size_t)P);
+    else {
+        write_dev(o, bw.dL_dscales, 3 * (size_t)P);
+        write_dev(o, bw.dL_drotations, 4 * (size_t)P);
+    }
     fclose(o);
     for (void* p : g_scratch) (void)hipFree(p);
     printf("ok N=%lld binning_capacity=%lld\n", (long long)N, (long long)bw.state.binning_capacity);

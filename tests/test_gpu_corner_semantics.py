@@ -1,0 +1,286 @@
+"""The places where the HIP path's semantics could differ from its checker's, pinned one by one.
+
+1. A projected 2-D covariance that is NOT positive definite (det < 0, b^2 >> ac, a < 0): only reachable through a non-PSD
+   `cov3D_precomp`, a documented API input the reference never passes (/root/reference/hugs/renderer/gs_renderer.py:144-152 hands over
+   scales + rotations).  The published algorithm culls det == 0 only and blends such a splat wherever its exponent
+   happens to be <= 0; the library CULLS it (radius 0) -- include/hgs_rasterizer.h states the rule, `oracle_set_cull_non_pd` makes the
+   checker follow it.  Here: the library against the rule-following oracle on every bar of the parity tests, through both bindings and the
+   torch-free C host; and against the published behaviour, to show that the case is real and where exactly the two part.
+2. The three branch points of the blend: `power > 0`, `alpha < 1/255`, `T (1 - alpha) < 1e-4`.  The device evaluates
+   alpha = exp2(L - (la dx + lb dy)^2 - (lc dy)^2) with v_exp_f32 where the oracle computes opacity * expf(power); a pixel that sits ON a
+   threshold can take the other branch.  Pixels are constructed on each threshold (to the ulp) and the image is held to the allowance
+   the parity tests grant: what a flip can cost is bounded by the threshold itself, and is said here.
+"""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hgs_oracle as ho
+from scenes import CASES, make_scene, oracle_inputs
+from test_gpu_parity import (COLOR_TOL, GRAD_REL_TOL, _force_ctypes_binding, check_image, gpu_settings, gpu_tensors, rel_l2, run_gpu, to_dev)
+
+gpu = pytest.mark.gpu   # (the two tests that only check the constructions run on the CPU)
+
+
+# ------------------------------------------------------------------------------------------------ 1. non-positive-definite covariances
+def test_the_non_pd_scene_is_what_it_says():
+    """(no GPU needed, but it belongs with the rest) a quarter of the Gaussians carry a covariance whose projection has det < 0; the
+    published algorithm rasterizes 40 of them, the library's rule none; the two images differ on most pixels."""
+    sc = make_scene(**CASES["precomp_cov_indefinite"])
+    idx = sc["non_pd_candidates"]
+    pub, lib = ho.forward(oracle_inputs(sc, cull_non_pd=False)), ho.forward(oracle_inputs(sc, cull_non_pd=True))
+    f64 = ho.forward(oracle_inputs(sc, dtype=np.float64, cull_non_pd=False))
+    co = f64["conic_opacity"][idx]
+    seen = f64["radii"][idx] > 0
+    det = 1.0 / (co[seen, 0] * co[seen, 2] - co[seen, 1] ** 2)           # (conic = (c, -b, a) / det: det(conic) = 1 / det)
+    assert seen.sum() >= 30 and (det < 0).all(), "the published algorithm rasterizes the indefinite ones"
+    assert (pub["radii"][idx] > 0).sum() >= 30 and (lib["radii"][idx] > 0).sum() == 0
+    others = np.setdiff1d(np.arange(sc["means3D"].shape[0]), idx)
+    assert np.array_equal(pub["radii"][others], lib["radii"][others])
+    assert lib["N"] < pub["N"]
+    assert (np.abs(pub["color"] - lib["color"]).max(0) > 1e-3).mean() > 0.5, "where power <= 0 the published algorithm blends them"
+
+
+@gpu
+@pytest.mark.parametrize("binding", ["cpp", "ctypes"])
+def test_non_pd_covariances_are_culled_exactly_as_documented(binding, device, monkeypatch):
+    from diff_gaussian_rasterization import _debug_forward_state
+    if binding == "ctypes":
+        _force_ctypes_binding(monkeypatch)
+    sc = make_scene(**CASES["precomp_cov_indefinite"])
+    inp = oracle_inputs(sc)
+    assert inp.cull_non_pd
+    ref = ho.forward(inp)
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    # forward, through whichever binding: radii / image against the rule-following oracle
+    t, color, radii = run_gpu(sc, device)
+    color.backward(to_dev(sc["dL_dpix"], device))
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    assert (radii.cpu().numpy()[sc["non_pd_candidates"]] == 0).all()
+    assert torch.isfinite(color).all()
+    check_image(color.detach().cpu().numpy(), ref["color"], "non-PD scene colour")
+    for label, g, r in (("means3D", t["means3D"].grad, refg["means3D"]), ("means2D", t["means2D"].grad, refg["means2D"]),
+                        ("opacities", t["opacities"].grad, refg["opacities"]), ("shs", t["shs"].grad, refg["shs"]),
+                        ("cov3D_precomp", t["cov3D_precomp"].grad, refg["cov3D"])):
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all(), label
+        assert rel_l2(g.reshape(r.shape), r) <= GRAD_REL_TOL, label
+        assert not g.reshape(g.shape[0], -1)[sc["non_pd_candidates"]].any(), f"{label}: a culled Gaussian has no gradient"
+    # ... and the lists, exactly (the stage-level introspection runs through the ctypes binding either way)
+    tt = gpu_tensors(sc, device, grad=False)
+    _c, _r, st = _debug_forward_state(tt["means3D"], tt["opacities"], gpu_settings(sc, device), shs=tt["shs"], cov3D_precomp=tt["cov3D_precomp"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    assert np.array_equal(st["tiles_touched"].cpu().numpy().view(np.uint32), ref["tiles_touched"])
+
+
+@gpu
+def test_non_pd_covariances_through_the_c_host(device, tmp_path):
+    """the same rule through the C ABI with no torch in the process (tests/c_host/raster_host.cpp, mode 5: cov3D_precomp)"""
+    from test_c_host import build_host
+    sc = make_scene(**CASES["precomp_cov_indefinite"])
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    refg = ho.backward(inp, ref, sc["dL_dpix"])
+    P, M, H, W = sc["means3D"].shape[0], sc["shs"].shape[1], sc["H"], sc["W"]
+    cam = sc["cam"]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([P, M, H, W, sc["D"], 5], np.int32).tofile(f)
+        np.array([sc["tanfovx"], sc["tanfovy"], sc["scale_modifier"]], np.float32).tofile(f)
+        for a in (sc["bg"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], sc["means3D"], sc["shs"],
+                  sc["opacities"], sc["cov3D_precomp"], sc["dL_dpix"]):
+            np.ascontiguousarray(a, dtype=np.float32).tofile(f)
+    out = subprocess.run([build_host(), fin, fout], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    raw = open(fout, "rb").read()
+    assert int(np.frombuffer(raw, np.int64, 1)[0]) == ref["N"]
+    off = 8
+
+    def take(n, dt=np.float32):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += a.nbytes
+        return a
+
+    color = take(3 * H * W).reshape(3, H, W)
+    radii = take(P, np.int32)
+    assert np.array_equal(radii, ref["radii"])
+    check_image(color, ref["color"], "non-PD scene through the C host")
+    for name, n, r in (("means3D", 3 * P, refg["means3D"]), ("means2D", 3 * P, refg["means2D"]), ("opacities", P, refg["opacities"]),
+                       ("shs", 3 * M * P, refg["shs"]), ("cov3D", 6 * P, refg["cov3D"])):
+        assert rel_l2(take(n).reshape(r.shape), r) <= GRAD_REL_TOL, name
+    assert off == len(raw)
+
+
+# ------------------------------------------------------------------------------------------------ 2. the blend's branch points
+F32 = np.float32
+A_MIN = F32(1.0) / F32(255.0)
+T_STOP = F32(0.0001)
+W_IMG = H_IMG = 64
+DEPTH = 4.0          # z + 1e-7 == z in fp32 from z = 4 on: 1 / (w + 1e-7) is exactly 0.25
+
+
+def _exact_camera():
+    """tan(fov / 2) = 1 and the identity pose: hom.x = x, hom.w = z exactly, so that x = (2 m - 63) / 16 at z = 4 lands on pixel m
+    EXACTLY (px = ((ndc + 1) W - 1) / 2 with ndc = (2 m + 1) / W - 1)."""
+    from hugs_amd import synthetic as syn
+    return syn.camera_from_w2c(np.eye(4), math.pi / 2, math.pi / 2, H_IMG, W_IMG)
+
+
+def _mean_for_pixel(m, n, z=DEPTH, shift_px=0.0):
+    k = z / 4.0
+    return [k * (2 * (m + shift_px) - (W_IMG - 1)) / 16.0, k * (2 * n - (H_IMG - 1)) / 16.0, z]
+
+
+def _stop_opacities():
+    """fp32 opacity triples (o1, o2, o3), all below the 0.99 cap, for which (1 - o1) (1 - o2) (1 - o3) -- the transmittance test of the
+    third of three splats centred on one pixel, multiplied in that order -- is the fp32 1e-4 itself, one ulp below it, one ulp above"""
+    o1 = F32(0.3) + np.arange(4096, dtype=np.float32) * F32(2.0 ** -25)
+    o2 = F32(0.986)
+    o3 = F32(0.9898) - np.arange(2048, dtype=np.float32) * F32(2.0 ** -24)
+    T2 = (F32(1.0) - o1) * (F32(1.0) - o2)
+    prod = T2[:, None] * (F32(1.0) - o3)[None, :]
+    out = {}
+    for name, want in (("below", np.nextafter(T_STOP, F32(0))), ("at", T_STOP), ("above", np.nextafter(T_STOP, F32(1)))):
+        i, j = np.argwhere(prod == want)[0]
+        out[name] = (o1[i], o2, o3[j], T2[i])
+    return out
+
+
+def _branch_scene(alpha_pixels, stop_pixels, power_pixels):
+    """Tiny isotropic splats (their 2-D covariance is the 0.3 low-pass: conic 1 / 0.3, reach two pixels) centred EXACTLY on the given
+    pixels, colours within 0.5 of the white background.  -> (scene dict like tests/scenes.py, {pixel: kind})"""
+    rng = np.random.default_rng(77)
+    means, opac, kinds = [], [], {}
+    a_vals = {"below": np.nextafter(A_MIN, F32(0)), "at": A_MIN, "above": np.nextafter(A_MIN, F32(1))}
+    for k, (m, n) in enumerate(alpha_pixels):
+        name = ("below", "at", "above")[k % 3]
+        means.append(_mean_for_pixel(m, n)), opac.append(a_vals[name])
+        kinds[(m, n)] = "alpha_" + name
+    stops = _stop_opacities()
+    for k, (m, n) in enumerate(stop_pixels):
+        name = ("below", "at", "above")[k % 3]
+        means.append(_mean_for_pixel(m, n, z=4.0)), opac.append(stops[name][0])   # T1 = 1 - o1
+        means.append(_mean_for_pixel(m, n, z=8.0)), opac.append(stops[name][1])   # T2 = T1 (1 - o2)
+        means.append(_mean_for_pixel(m, n, z=16.0)), opac.append(stops[name][2])  # T2 (1 - o3) on the threshold
+        means.append(_mean_for_pixel(m, n, z=32.0)), opac.append(F32(0.5))        # and one more behind (never added: the pixel is done)
+        kinds[(m, n)] = "stop_" + name
+    for k, (m, n) in enumerate(power_pixels):
+        means.append(_mean_for_pixel(m, n, shift_px=(1e-4, -1e-4, 2e-4)[k % 3])), opac.append(F32(0.7))
+        kinds[(m, n)] = "power"
+    P = len(means)
+    sc = {"means3D": np.asarray(means, np.float32), "opacities": np.asarray(opac, np.float32)[:, None], "shs": None,
+          "colors_precomp": (0.5 + 0.5 * rng.uniform(0, 1, (P, 3))).astype(np.float32), "cov3D_precomp": None,
+          "scales": np.full((P, 3), 1e-4, np.float32), "rotations": np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1)),
+          "cam": _exact_camera(), "H": H_IMG, "W": W_IMG, "D": 0, "M": 0, "bg": np.ones(3, np.float32), "scale_modifier": 1.0,
+          "tanfovx": 1.0, "tanfovy": 1.0}
+    return sc, kinds
+
+
+def _run_branch_scene(sc, device):
+    inp = oracle_inputs(sc)
+    ref = ho.forward(inp)
+    t, color, radii = run_gpu(sc, device)
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    return ref, color.detach().cpu().numpy()
+
+
+def test_the_branch_pixels_sit_on_their_thresholds():
+    """the construction itself, against the oracle's own numbers (CPU): centres exactly on pixels, alpha and T (1 - alpha) exactly at /
+    one ulp either side of the thresholds, |power| < 1e-7 where a centre is a hair off its pixel"""
+    sc, kinds = _branch_scene([(8, 8), (20, 8), (32, 8)], [(8, 30), (20, 30), (32, 30)], [(8, 50), (20, 50), (32, 50)])
+    ref = ho.forward(oracle_inputs(sc))
+    xy = ref["xy"]
+    on_pixel = list(range(3 + 12))   # the alpha and stop splats
+    assert np.array_equal(xy[on_pixel], np.round(xy[on_pixel])), "centres exactly on pixel centres"
+    assert np.allclose(ref["conic_opacity"][:, 0], 1 / 0.3, rtol=1e-5) and np.abs(ref["conic_opacity"][:, 1]).max() < 1e-5
+    # alpha == opacity at the centre pixel (expf(0) == 1): below / at / above 1/255 -> skipped / blended / blended
+    fT = ref["final_T"]
+    assert fT[8, 8] == 1 and fT[8, 20] == F32(1) - A_MIN and fT[8, 32] == F32(1) - np.nextafter(A_MIN, F32(1))
+    # the stop: below -> the third splat stops the pixel BEFORE it is added, T stays (1 - o1) (1 - o2); at / above -> it is added (and
+    # the fourth, behind it, stops the pixel)
+    stops = _stop_opacities()
+    assert fT[30, 8] == stops["below"][3]
+    assert fT[30, 20] == T_STOP and fT[30, 32] == np.nextafter(T_STOP, F32(1))
+    for k, m in enumerate((8, 20, 32)):
+        g = 15 + k
+        dx, dy = xy[g, 0] - F32(m), xy[g, 1] - F32(50)
+        co = ref["conic_opacity"][g]
+        power = F32(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy
+        assert dx != 0 and abs(float(power)) < 1e-7 and power <= 0
+
+
+@gpu
+def test_two_threshold_pixels_stay_inside_the_parity_allowance(device):
+    """ONE pixel on the alpha threshold, ONE on the transmittance stop, three with |power| < 1e-7: whatever branch the device takes there,
+    the image passes the very check the parity tests apply (>= 99.98 % of pixels within 1e-4 or at most two outside, none beyond 2/255)."""
+    for pick in range(3):   # (below / at / above the thresholds)
+        alpha_px = [(-100, -100)] * pick + [(10, 10)]      # (placeholders keep the k % 3 cycle of _branch_scene)
+        stop_px = [(-100, -100)] * pick + [(40, 12)]
+        sc, kinds = _branch_scene([p for p in alpha_px], [p for p in stop_px], [(10, 40), (30, 40), (50, 40)])
+        ref, color = _run_branch_scene(sc, device)
+        check_image(color, ref["color"], f"branch pixels ({('below', 'at', 'above')[pick]})")
+
+
+@gpu
+def test_many_threshold_pixels_flip_by_no_more_than_the_threshold_allows(device):
+    """Fifty-four pixels on the thresholds.  Off the constructed pixels the image is within 1e-4 everywhere; ON them a flip changes the
+    pixel by at most what the skipped / added splat weighs:
+        alpha threshold:  alpha T |c - bg| <= (1/255) |c - bg|
+        T stop:           alpha T |c - bg| with T (1 - alpha) = 1e-4, i.e. (T - 1e-4) |c - bg| <= 0.0099 |c - bg|  (alpha <= 0.99, so T <= 0.01 there)
+    -- so `every pixel within 2/255` holds for |c - bg| <= 0.79 (here <= 0.5), and a pixel that flips AT THE STOP under a splat of
+    maximal contrast can differ by 0.0099: said here, and in DESIGN.md, rather than hidden in the allowance."""
+    grid = [(6 + 9 * i, 6 + 9 * j) for j in range(6) for i in range(6)]
+    alpha_px, stop_px, power_px = grid[:18], grid[18:27], grid[27:]
+    sc, kinds = _branch_scene(alpha_px, stop_px, power_px)
+    ref, color = _run_branch_scene(sc, device)
+    d = np.abs(color.astype(np.float64) - ref["color"]).max(0)          # [H, W]
+    on = np.zeros_like(d, bool)
+    for (m, n) in kinds:
+        on[n, m] = True
+    assert d[~on].max() <= COLOR_TOL, f"off the threshold pixels: {d[~on].max():.3e}"
+    flips = {"alpha": 0, "stop": 0, "power": 0}
+    for (m, n), kind in kinds.items():
+        base = kind.split("_")[0]
+        bound = {"alpha": 0.5 / 255.0, "stop": 0.0099 * 0.5, "power": COLOR_TOL}[base]
+        assert d[n, m] <= bound * 1.02 + 1e-6, f"pixel ({m},{n}) [{kind}]: {d[n, m]:.3e} > {bound:.3e}"
+        flips[base] += d[n, m] > COLOR_TOL
+    assert flips["power"] == 0
+    print(f"flipped: {flips['alpha']} of {len(alpha_px)} alpha-threshold pixels, {flips['stop']} of {len(stop_px)} stop pixels")
+
+
+@gpu
+def test_a_needle_splat_follows_the_fp64_exponent_not_the_fp32_noise(device):
+    """`power > 0` in the published algorithm is a guard against ROUNDING: for a positive-definite conic the exponent is <= 0.  On a splat
+    of extreme anisotropy (eigenvalue ratio > 1e7) the fp32 expression -0.5 (cx dx^2 + cz dy^2) - cy dx dy is rounding noise along the
+    major axis -- sign included -- and the fp32 oracle skips pixels there that the fp64 oracle blends.  The library evaluates the
+    exponent through the conic's Cholesky factors (never above L, no cancellation): it follows the fp64 evaluation."""
+    from hugs_amd import synthetic as syn
+    H = W = 64
+    cam = syn.pinhole_camera(H, W, focal_frac=0.6)
+    ang = math.radians(27.0)
+    q = np.array([[math.cos(ang / 2), 0.0, 0.0, math.sin(ang / 2)]], np.float32)      # rotation about the view axis
+    sc = {"means3D": np.array([[0.013, -0.007, 4.0]], np.float32), "opacities": np.array([[0.6]], np.float32), "shs": None,
+          "colors_precomp": np.array([[0.2, 0.4, 0.9]], np.float32), "cov3D_precomp": None,
+          "scales": np.array([[400.0, 1e-5, 1e-5]], np.float32), "rotations": q, "cam": cam, "H": H, "W": W, "D": 0, "M": 0,
+          "bg": np.ones(3, np.float32), "scale_modifier": 1.0, "tanfovx": math.tan(cam["fovx"] * 0.5), "tanfovy": math.tan(cam["fovy"] * 0.5)}
+    f32, f64 = ho.forward(oracle_inputs(sc)), ho.forward(oracle_inputs(sc, dtype=np.float64))
+    assert f32["radii"][0] > 0
+    t, color, radii = run_gpu(sc, device)
+    torch.cuda.synchronize()
+    img = color.detach().cpu().numpy().astype(np.float64)
+    noisy = np.abs(f32["color"].astype(np.float64) - f64["color"]).max(0) > 1e-3
+    d64 = np.abs(img - f64["color"]).max(0)
+    print(f"fp32 oracle differs from fp64 on {int(noisy.sum())} pixels; device vs fp64: max {d64.max():.3e}")
+    # the device agrees with the fp64 exponent wherever the conic itself (an fp32 quantity, shared by all three) resolves the pixel:
+    # at least nine pixels in ten, and everywhere the fp32 oracle's own answer is not noise
+    assert (d64 <= 1e-3).mean() >= 0.9
+    assert (d64[~noisy] <= 1e-3).mean() >= 0.98

@@ -188,12 +188,14 @@ typedef struct hgs_forward_state {
     void *ckpt;    size_t ckpt_bytes;   /* NULL / 0 unless backward_checkpoints was set */
     int64_t num_rendered;     /* N = sum of tiles touched */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= N) */
-    int32_t sparse_frame;     /* !=0: few non-empty tiles; backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
+    int32_t sparse_frame;     /* !=0: the scan's SPARSE kind (few non-empty tiles, or deep lists: binning.hip frame_is_sparse); backward gives every 8x8 quad (with checkpoints: every 32-entry segment of its list) its own wave */
     int32_t has_long_tiles;   /* !=0: some tile list is long by the scan kernel's rule (see expect_no_long_tiles; feeds the next frame's expect_no_long_tiles) */
     uint64_t n_token;         /* where hgs_forward_poll finds this frame's N (deferred frames: num_rendered = -1 until polled) */
     int64_t ckpt_slots;       /* slots the checkpoint buffer was laid out for (0: none) */
     int64_t ckpt_slots_used;  /* slots the frame's checkpoints need: (N >> 5) + tiles on a sparse frame, the deep tiles' packed count on a
-                                 dense one (0 when it left none); feeds the next frame's ckpt_slots_hint */
+                                 dense one (0 when it left none); feeds the next frame's ckpt_slots_hint.  -1: a sparse frame that
+                                 leaves none BY RULE (4 096 non-empty tiles and more, no heavy tail: its backward runs one wave per quad
+                                 without them) -- the caller need not offer this shape's next frame a buffer */
 } hgs_forward_state;
 
 /* Replaces _C.rasterize_gaussians. Returns N >= 0, or a negative HGS_ERR_* code. */

@@ -104,11 +104,38 @@ struct ScanArgs {
 };
 
 // SPARSE or DENSE: the one decision the rest of the frame's path selection hangs on (the backward's form, the checkpoint layout, the
-// long-list thresholds).  Dense = one backward wave per tile keeps the SIMDs busy: at least four waves on each of the 1 024.
-__device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, uint32_t force_kind)
+// long-list thresholds) -- taken from what the scan knows of the FRAME, not from its size:
+//   n_nonempty          tiles with a list: the waves the one-wave-per-tile backward runs (1 024 SIMDs: four each from 4 096 tiles on)
+//   E = sum len^2 / N   the size-biased mean list length: the length of the list a random ENTRY sits in -- equal to the mean on a
+//                       uniform frame, several times the mean where a person stands in front of a scene (the deep lists hold most
+//                       of the entries, and one wave per tile walks each of them alone)
+// Dense = one backward wave per tile (+ the checkpointed walk for its deep tiles, where it holds lists beyond 2 048 entries): fewer
+// instructions per entry -- one reduction per (tile, entry) -- but a chain per tile.  From 4 096 non-empty tiles on it keeps the SIMDs
+// busy whatever the lists (the rule of rounds 2-5, which called every smaller frame sparse); below that it still wins while the lists
+// are short enough for the tile chains to end together: E <= 0.45 (n_nonempty - 800), at most 1 200 -- fitted on the shape scan
+// (tools/shape_scan.py, profiles/r6*_shape_scan*.json: 2 040 non-empty tiles: dense up to E ~ 580, 3 600: up to ~1 200; a covered
+// 1280x720 frame of 100 000 Gaussians, E = 445: 0.370 -> 0.339 ms; a trained one, E = 638: 0.489 -> 0.395), never under 1 536 tiles
+// (a 512x512 frame, any human-only render: the depth-segmented backward from the forward's checkpoints wins at every depth).
+constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760;
+__device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigned long long total, unsigned long long sum_sq, uint32_t longest, uint32_t force_kind)
 {
     if (force_kind) return force_kind == 1u ? 1u : 0u;
-    return n_nonempty < 4096u ? 1u : 0u;
+    // (round 6) 4 096 tiles and more: dense unless the lists are DEEP -- E beyond DENSE_ALWAYS_E_MAX: 2 097 152 Gaussians of a trained scene
+    // at 1080p and above (E = 851 .. 953), a 524 288-Gaussian person at 1080p (E = 1 376).  The wave that walks a whole tile goes as far back
+    // as the LAST of its 256 pixels composited, a wave per quad as far as the last of its 64, and in deep lists most quads are done long
+    // before their tile is: one wave per quad 8-16 % faster there, 10-45 % slower on every shallower frame of the scan (E <= 705).
+    if (n_nonempty >= DENSE_ALWAYS_TILES) return sum_sq > (unsigned long long)DENSE_ALWAYS_E_MAX * total ? 1u : 0u;
+    if (n_nonempty < DENSE_MIN_TILES) return 1u;
+    unsigned long long e_max = min((unsigned long long)DENSE_E_MAX, (unsigned long long)(n_nonempty - DENSE_E_ORIGIN) * 9ull / 20ull);
+    // (a FLAT frame -- its longest list within a quarter of E: a covered frame of uniform depth -- has no tile chain that outlasts the
+    //  others at any depth the rule's slope allows: up to DENSE_E_FLAT_MAX; 2 097 152 Gaussians at 1280x720, E = 1 485: 7 % faster dense)
+    if (e_max == DENSE_E_MAX && 4ull * longest * total <= 5ull * sum_sq) e_max = DENSE_E_FLAT_MAX;
+    if (sum_sq > e_max * total) return 1u;   // E = sum_sq / total > e_max
+    // ... and only while the frame has no heavy TAIL: E <= 2.5 x the mean list (a person 110 210 Gaussians strong in front of an empty
+    // background at 1080p -- 3 064 non-empty tiles, mean 301, E = 855: the tile chains of the body end long after the rest; the
+    // checkpointed walk is 19 % faster there -- against a covered 1280x720 frame at E = 988 = its mean, 12 % faster dense)
+    const float mean = (float)total / (float)n_nonempty;
+    return (float)sum_sq > 2.5f * mean * (float)total ? 1u : 0u;
 }
 
 // The scan as a workgroup of 1024 threads.  ZERO: re-zero the counters it has read (the stand-alone kernel, their only reader);
@@ -134,15 +161,15 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t n_large_sparse, n_large_shallow, n_large_dense, n_nonempty, n_huge;
     __shared__ unsigned long long total64;  // the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32
+    __shared__ unsigned long long sumsq64;  // sum of the squared list lengths (frame_is_sparse)
     __shared__ uint32_t longest;   // the frame's longest list
-    if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull, longest = 0u;
+    if (threadIdx.x == 0) n_large_sparse = 0, n_large_shallow = 0, n_large_dense = 0, n_nonempty = 0, n_huge = 0, total64 = 0ull, sumsq64 = 0ull, longest = 0u;
     // the cell counters of the counting sort (their readers ran before this kernel) are self-cleaning too
     for (int c = threadIdx.x; c < num_cells; c += 1024) cell_count[c] = 0u;   // (whatever ZERO: emit's workgroups do not read them)
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t carry = 0, carry2 = 0;
     uint32_t my_huge = 0, my_sparse = 0, my_shallow = 0, my_dense = 0;   // this thread's lists beyond each threshold
-    uint32_t my_longest = 0;
     // (a frame of at most 8 192 tiles is ONE trip of this loop: the number of non-empty tiles -- dense frame or sparse -- is then
     //  complete behind the trip's barrier, before the checkpoint slots are dealt)
     const bool single_trip = num_tiles <= 1024 * SCAN_ITEMS;
@@ -165,8 +192,9 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
             }
         }
         uint32_t mine = 0, nonempty = 0;
+        unsigned long long sq = 0ull;   // (a count is below 2^26: eight squares fit easily)
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) mine += c[k], nonempty += c[k] ? 1u : 0u;
+        for (int k = 0; k < SCAN_ITEMS; ++k) mine += c[k], nonempty += c[k] ? 1u : 0u, sq += (unsigned long long)c[k] * c[k];
         const uint32_t inc = wave_inclusive_scan(mine);
         if (lane == 63) wsum[w] = inc;
         // checkpoint slots of a DENSE frame: its deep tiles alone get them, ceil(length / CKPT_SEG) each, packed (see below)
@@ -180,12 +208,17 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         // non-empty tiles of the wave (for the sparse-frame decision)
         uint32_t ne = nonempty;
         unsigned long long m64 = mine;  // (eight counts below 2^26 each: `mine` itself cannot wrap)
+        uint32_t mx = 0;   // the wave's longest list (the frame's is complete behind the trip's barrier, like the sums)
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) mx = max(mx, c[k]);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             ne += (uint32_t)__shfl_xor((int)ne, d, 64);
             m64 += (unsigned long long)__shfl_xor((long long)m64, d, 64);
+            sq += (unsigned long long)__shfl_xor((long long)sq, d, 64);
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
         }
-        if (lane == 0 && ne) atomicAdd(&n_nonempty, ne), atomicAdd(&total64, m64);
+        if (lane == 0 && ne) atomicAdd(&n_nonempty, ne), atomicAdd(&total64, m64), atomicAdd(&sumsq64, sq), atomicMax(&longest, mx);
         __syncthreads();
         uint32_t before = 0, total = 0, before2 = 0, total2 = 0;
 #pragma unroll
@@ -202,7 +235,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
                 total2 += v;
             }
         }
-        const bool dense_now = single_trip && !frame_is_sparse(n_nonempty, sa.force_kind);   // (the packed slot layout can be written right here)
+        const bool dense_now = single_trip && !frame_is_sparse(n_nonempty, total64, sumsq64, longest, sa.force_kind);   // (the packed slot layout can be written right here)
         __syncthreads();
         uint32_t start = carry + before + inc - mine;
         uint32_t st[SCAN_ITEMS];
@@ -210,7 +243,6 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         for (int k = 0; k < SCAN_ITEMS; ++k) {
             st[k] = start;
             start += c[k];
-            my_longest = max(my_longest, c[k]);   // (counts beyond num_tiles were read as zero)
         }
         if (t0 + SCAN_ITEMS <= num_tiles) {
             uint4* r4 = reinterpret_cast<uint4*>(ranges + t0);
@@ -260,14 +292,9 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     // running maximum per tile in the pass above, one wave reduction, and the counting pass below is skipped when the frame's
     // longest list is under the lowest threshold a frame of its kind can choose (round 4 counted for all four thresholds on every
     // frame: +1.2-1.5 us of this one-workgroup kernel).
-    {
-        uint32_t x = my_longest;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
-        if (lane == 0 && x) atomicMax(&longest, x);
-    }
     __syncthreads();
-    const uint32_t sparse_kind = frame_is_sparse(n_nonempty, sa.force_kind);
+    const uint32_t sparse_kind = frame_is_sparse(n_nonempty, total64, sumsq64, longest, sa.force_kind);
+    const bool force_kind_set = sa.force_kind != 0u;   // (HGS_FRAME_KIND: the forced kinds keep their checkpoints, as the A/B tools expect)
     const uint32_t lowest = sparse_kind ? min(long_min_sparse, (uint32_t)LONG_MIN_SPARSE_SHALLOW) : long_min_dense;
     if (longest > lowest) {   // (workgroup-uniform) count the lists beyond each threshold from the ranges this workgroup wrote
         for (int t00 = 0; t00 < num_tiles; t00 += 8 * 1024) {
@@ -328,9 +355,20 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
             sparse_min = long_min_sparse, n_sparse_long = n_large_sparse;
         else if (n_large_shallow >= LONG_MIN_SPARSE_TILES && n_large_shallow <= LONG_ONE_ROUND)
             sparse_min = shallow_min, n_sparse_long = n_large_shallow;
-        else if (n_large_shallow > LONG_ONE_ROUND)
-            sparse_min = (uint32_t)SORT_CAP_SMALL, n_sparse_long = very_deep;
+        else if (n_large_shallow > LONG_ONE_ROUND) {
+            // More lists beyond 1 024 entries than one round of the long tiles' kernel takes.  (round 6) FLAT ones -- the frame's longest
+            // list fits one workgroup of that kernel: a covered small frame, 300 000 Gaussians at 512x512, all 1 024 lists between 1 800
+            // and 2 500 entries -- are long all the same, from 1 024 entries on: the fused kernel sorts a list of 1 025 .. 2 048 entries
+            // with its bitonic network (no room for the buckets), the long tiles' kernel with its bucket sort, and the shape scan has
+            // the latter ahead however many lists there are -- but they are NOT blended split by depth (many_flat_long below: the
+            // per-quad waves of a thousand tiles fill the SIMDs by themselves; the workers' compose + re-walk is twice the
+            // instructions): sort + forward 144 -> 102 us.  With really deep lists among them (a trained scene: the longest 10 337)
+            // the threshold stays at 2 048 and the lists beyond it go to the workers, as before (1 024 there: +13-15 %).
+            if (longest <= (uint32_t)SORT_CAP_MID) sparse_min = shallow_min, n_sparse_long = n_large_shallow;
+            else sparse_min = (uint32_t)SORT_CAP_SMALL, n_sparse_long = very_deep;
+        }
     }
+    const bool many_flat_long = sparse && n_sparse_long > LONG_ONE_ROUND && longest <= (uint32_t)SORT_CAP_MID && !sparse_unconditional;
     const bool use_sparse = sparse_min != 0u;
     // A dense frame takes the long-tile path (sorted ahead, blended by depth) from long_min_dense entries on only when it holds a list
     // the one-workgroup-per-tile kernel cannot take or walks as a tail (beyond SORT_CAP_SMALL entries); a frame whose deepest lists
@@ -340,16 +378,24 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     const uint32_t dense_min = dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
     const uint32_t threshold = use_sparse ? sparse_min : dense_min;
     const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_long ? n_large_dense : 0u)) ? 1u : 0u;
+    const uint32_t deep_flag = ((!sparse || deep_lists) && !many_flat_long) ? 1u : 0u;
+    // Which tiles leave checkpoints for the backward (hgs_common.h, CKPT_KIND_*): every tile of a sparse frame -- except (round 6) on a
+    // sparse frame of 4 096 non-empty tiles and more WITHOUT a heavy tail (E < 1.6 x the mean list: the trained 2 097 152-Gaussian scenes):
+    // 16 384 quad waves and more fill the SIMDs from the end of the lists, and 800 MB of checkpoints cost more than the segmented walk
+    // saves (8-16 % of the frame); with a tail (a person in front of an empty background at 1080p) the segmented walk stays.
+    const bool sparse_no_ckpt = sparse && !force_kind_set && n_nonempty >= DENSE_ALWAYS_TILES &&
+                                (float)sumsq64 * (float)n_nonempty < 1.6f * (float)total64 * (float)total64;
+    const uint32_t ckpt_kind = !sparse ? (uint32_t)CKPT_KIND_DEEP : sparse_no_ckpt ? (uint32_t)CKPT_KIND_NONE : (uint32_t)CKPT_KIND_ALL;
     if (threadIdx.x == 0) {
         n_total[0] = carry, n_total[1] = carry > capacity || carry == 0xFFFFFFFFu ? 1u : 0u;
-        n_total[3] = sparse, n_total[4] = threshold;
+        n_total[3] = ckpt_kind, n_total[4] = threshold;
         // [5] parts of the lists beyond SORT_CAP_MID entries (long_tile_plan_kernel appends), [6] how many such lists there are,
         // [7] lists the plan leaves to the one-workgroup fallback
         n_total[5] = 0u, n_total[6] = huge, n_total[7] = 0u;
         // [8]: the long tiles' quads are blended split by depth (the deep workers of the fused kernel) -- on dense frames, and on
         // sparse frames with deep lists; on a shallow sparse frame (the SMPL template: 25 lists beyond 1 024 entries, composited
         // depth <= 430) one wave per quad does as well and the workers' workgroups only stand in the way (measured: +2 us)
-        n_total[8] = (!sparse || deep_lists) ? 1u : 0u;
+        n_total[8] = deep_flag;
         if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
     }
     // A DENSE frame leaves checkpoints only on its deep tiles (CKPT_DEEP_MIN entries and more): they alone get slots --
@@ -399,7 +445,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     // that a dense frame uses a tenth of).  A frame that needs more closes the gate exactly as one that overflows its binning
     // buffer does: the kernels behind return at once and the host runs it again, exactly sized.
     // (slots the frame's checkpoints need: the sparse layout's (N >> CKPT_SHIFT) + T, or a dense frame's packed count; 0: it leaves none)
-    const uint32_t ckpt_needed = !seg_first ? 0u : sparse ? (carry >> CKPT_SHIFT) + (uint32_t)num_tiles : dense_slots;
+    const uint32_t ckpt_needed = !seg_first || sparse_no_ckpt ? 0u : sparse ? (carry >> CKPT_SHIFT) + (uint32_t)num_tiles : dense_slots;
     if (seg_first && sa.ckpt_cap && threadIdx.x == 0 && ckpt_needed > sa.ckpt_cap) n_total[1] = 1u;
     uint32_t n_long = 0;
     if (any_long) {   // (workgroup-uniform) the frame has long lists: collect them
@@ -437,6 +483,10 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         // ... and, in the high half, the slots the frame's checkpoints need whatever its kind (the host sizes the next frame's buffer
         // by it and recognises a frame the checkpoint gate closed)
         __hip_atomic_store(host_slot + 3, (unsigned long long)dense_slots | ((unsigned long long)ckpt_needed << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // word 4: non-empty tiles, and (bit 32) whether the long tiles are blended split by depth -- launch-size hints for the shape's next frame
+        // ... and (bit 33) a sparse frame that leaves no checkpoints: its backward runs without them
+        __hip_atomic_store(host_slot + 4, (unsigned long long)n_nonempty | ((unsigned long long)(any_long ? deep_flag : 0u) << 32) |
+                                              ((unsigned long long)(sparse_no_ckpt ? 1u : 0u) << 33), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_slot, ((flags | ticket) << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1895,6 +1945,9 @@ void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, 
             // still occupy a slot while they find that out, in front of the tiles' workgroups
             uint32_t workers = long_tiles && deep_forward_enabled() ? deep_workers_for(num_tiles) : 0u;
             if (workers && hist.n_long >= 0) workers = min(workers, (uint32_t)(5 * hist.n_long + 64 + 7) & ~7u);
+            // (the shape's last frame had long lists but blended them with one wave per quad -- the scan's many_flat_long: a handful of
+            //  workers stand by; should this frame decide otherwise they walk all of its items, slowly and with the same result)
+            if (workers && hist.deep_blend == 0) workers = 8u;
             ka.cam = fb->cam, ka.lastg = fb->lastg, ka.splats = fb->splats, ka.bg = fb->bg, ka.out_color = fb->out_color, ka.final_T = fb->final_T;
             ka.n_contrib = fb->n_contrib, ka.clamp_output = fb->clamp_output, ka.ck = fb->ck, ka.num_workers = workers;
             if (workers) hipLaunchKernelGGL((tile_sort_small_kernel<true, true>), dim3(workers + num_tiles), dim3(256), 0, st, ka);

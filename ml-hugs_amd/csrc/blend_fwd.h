@@ -100,13 +100,22 @@ __device__ __forceinline__ void write_pixel(const Camera& cam, int px, int py, f
     out_color[2 * HW + pix] = c2;
 }
 
+// Which tiles leave checkpoints is the scan's word (n_total[3], binning.hip): 1 = every tile (a sparse frame), 0 = the deep tiles of a
+// dense frame (hgs_common.h, CKPT_DEEP_MIN), 2 = none (a sparse frame whose backward runs one wave per quad from the end of the lists:
+// CKPT_KIND_NONE)
+__device__ __forceinline__ bool ckpt_leave(const Ckpt& ck, uint32_t n_tile)
+{
+    const uint32_t kind = *(const_u32p)ck.sparse;
+    return kind == CKPT_KIND_ALL || (kind == CKPT_KIND_DEEP && n_tile >= CKPT_DEEP_MIN);
+}
+
 // First slot of tile `tile` (a list of `n_tile` entries) in the checkpoint buffer, or nullptr: the frame leaves no checkpoints,
 // or it is a dense frame and this tile is not a deep one (hgs_common.h, CKPT_DEEP_MIN).  The workgroup also records which tile
 // its slots belong to -- the backward's workgroups are dealt slots, not tiles (blend.hip) -- or that they hold nothing.
 __device__ __forceinline__ float4* ckpt_begin(const Ckpt& ck, uint32_t tile, uint32_t n_tile)
 {
-    if (!ck.state) return nullptr;
-    const bool leave = *(const_u32p)ck.sparse != 0u || n_tile >= CKPT_DEEP_MIN;
+    if (!ck.state || *(const_u32p)ck.sparse == CKPT_KIND_NONE) return nullptr;   // (no checkpoints: the slot layout is not even valid)
+    const bool leave = ckpt_leave(ck, n_tile);
     const uint32_t first = ((const_u32p)ck.seg_first)[tile], end = ((const_u32p)ck.seg_first)[tile + 1];
     for (uint32_t k = first + threadIdx.x; k < end; k += blockDim.x) ck.slot_tile[k] = leave ? tile : CKPT_SLOT_NONE;
     return leave ? ck.state + (size_t)first * 256u : nullptr;
@@ -280,7 +289,7 @@ __device__ __forceinline__ void walk_staged(const StagedRec* __restrict__ st, ui
 __device__ __forceinline__ float4* ckpt_tile_slots(const Ckpt& ck, uint32_t tile, uint32_t n_tile)
 {
     if (!ck.state) return nullptr;
-    const bool leave = *(const_u32p)ck.sparse != 0u || n_tile >= CKPT_DEEP_MIN;
+    const bool leave = ckpt_leave(ck, n_tile);
     return leave ? ck.state + (size_t)((const_u32p)ck.seg_first)[tile] * 256u : nullptr;
 }
 

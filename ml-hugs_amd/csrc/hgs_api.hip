@@ -389,6 +389,8 @@ void history_put(const HistKey& k, const HostSlot& hs)
     // (written by tile_scan_kernel before the word that carries the ticket)
     h.n_long = (int32_t)hs.word[1], h.n_huge = (int32_t)(hs.word[2] & 0xFFFFFFFFull), h.n_deep = (int32_t)(hs.word[2] >> 32);
     h.sparse = (int32_t)(hs.word[0] >> 63);
+    h.n_nonempty = (int32_t)(hs.word[4] & 0xFFFFFFFFull), h.deep_blend = (int32_t)((hs.word[4] >> 32) & 1ull);
+    h.no_ckpt = (int32_t)((hs.word[4] >> 33) & 1ull);
     std::lock_guard<std::mutex> lk(g_hist_mu);
     g_hist[hist_slot(k)] = HistEntry{k, h};
 }
@@ -545,6 +547,7 @@ size_t hgs_scratch_offset(const char* name, int32_t P, int64_t N, int32_t H, int
     if (!strcmp(name, "n_contrib")) return im.n_contrib;
     if (!strcmp(name, "ranges")) return im.ranges;
     if (!strcmp(name, "seg_first")) return im.seg_first;
+    if (!strcmp(name, "n_total")) return im.n_total;
     return (size_t)-1;
 }
 
@@ -575,6 +578,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // SORT_CAP_SMALL entries: the depth-segmented backward pays on a dense frame where such lists make the one-wave-per-tile
     // kernel chain-bound, and costs (C4: +78 us) where the deepest lists are merely long.
     if (hist.sparse == 0 && hist.n_deep == 0) want_ckpt = false;
+    // ... nor a sparse frame whose shape's last frame left none (the scan's CKPT_KIND_NONE: many tiles, deep lists, no tail); should this
+    // frame want them after all, its backward runs one wave per quad without them -- another summation order, the same gradients
+    if (hist.no_ckpt == 1) want_ckpt = false;
     GeomLayout gl(Ptot, num_tiles);
     ImageLayout il(cam.H, cam.W);
     // caller-provided scratch when it suffices, else the allocation callback
@@ -610,7 +616,7 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     const size_t arrival_at = cell_counters_at + (size_t)num_cells + 1;   // (num_cells + 1 cell counters: the last is the big splats')
     const int big_per_group = switches().big_per_group;
     if (int rc = acquire_tile_counters(st, arrival_at + 1, &tile_count, &tc_lease)) return rc;
-    int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group);
+    int bin_mode = bin_mode_for(Ptot, num_tiles, num_cells, group, hist.n_nonempty);
     // HGS_BIN_MODE=cell / order: force one of the two LDS binning paths (tests run the small parity scenes through both)
     if (const int forced = group ? switches().bin_mode : 0)
         bin_mode = (forced == 'c' && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : forced == 'o' ? BIN_IN_ORDER : bin_mode;
@@ -755,6 +761,13 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     // checkpoint slots the frame needs (the high half of word 3 of its result slot, written by the scan)
     const size_t ckpt_needed = !want_ckpt ? 0 : (size_t)(slot.word[3] >> 32);
     state->ckpt_slots_used = (int64_t)ckpt_needed;
+    if (((slot.word[4] >> 33) & 1ull) != 0ull) {
+        // The scan decided that this SPARSE frame leaves no checkpoints (CKPT_KIND_NONE): whatever buffer it was enqueued with stays
+        // unused -- its slot table is not even written --, a frame that is enqueued only now gets none, and the backward must not see one.
+        state->ckpt = nullptr, state->ckpt_bytes = 0, state->ckpt_slots = 0, fb.ck = Ckpt{};
+        want_ckpt = false;
+        state->ckpt_slots_used = -1;   // (tells the binding not to offer this shape a buffer)
+    }
     const bool ckpt_overflow = enqueued && state->ckpt && ckpt_needed > (size_t)state->ckpt_slots;   // (the scan closed the gate)
     if (!enqueued || N > hint || ckpt_overflow) {
         ckpt_slots_exact = ckpt_needed;
@@ -800,6 +813,8 @@ int64_t hgs_forward_poll(hgs_forward_state* state, int32_t block, void* stream)
     if ((int64_t)n32 > state->binning_capacity)
         return fail(HGS_ERR_OVERFLOW, "deferred frame needed %u binning entries but was given %lld: its output is invalid, run it again",
                     n32, (long long)state->binning_capacity);
+    if (state->ckpt && ((hs.word[4] >> 33) & 1ull) != 0ull && slot_state(*hs.word, ticket) == 1)
+        state->ckpt = nullptr, state->ckpt_bytes = 0, state->ckpt_slots = 0, state->ckpt_slots_used = -1;   // (a sparse frame that left no checkpoints)
     if (state->ckpt) {
         const unsigned long long w3 = hs.word[3];
         if (slot_state(*hs.word, ticket) != 1) return expired();   // (the slot was handed on between the two reads)

@@ -84,9 +84,14 @@ enum { BIN_NONE = 0, BIN_IN_ORDER = 1, BIN_BY_CELL = 2 };  // who forms the binn
 // atomics and partial-line key stores: it pays on frames with many Gaussians AND many tiles.  (Measured: 200k / 1080p +1.4 %,
 // 310k / 1080p +2 %, 35k-100k / 1080p +0.3 .. +1.5 %, 20k / 1080p even; 110k at 512x512 -2.7 %, the 6 890-Gaussian SMPL
 // template at 512x512 -7.5 %.)
-inline int bin_mode_for(int P, int num_tiles, int num_cells, int group)
+// (round 6) ... and a frame whose Gaussians cover a small part of the screen -- the human-only render of a training step at the capture's
+// size: 110 210 Gaussians on 3 064 of 8 160 tiles -- is binned in order whatever its P: its groups' windows are small either way, and
+// the two extra launches do not pay (shape scan: +6.5 %).  `nonempty_before`: non-empty tiles of the shape's last frame, -1 = unknown
+// (a launch-size hint like the others: lists and images do not depend on the binning mode).
+inline int bin_mode_for(int P, int num_tiles, int num_cells, int group, int nonempty_before = -1)
 {
     if (!group) return BIN_NONE;
+    if (nonempty_before >= 0 && 2 * nonempty_before < num_tiles) return BIN_IN_ORDER;
     return (P >= 32768 && num_tiles >= 4096 && num_cells <= BIN_MAX_CELLS) ? BIN_BY_CELL : BIN_IN_ORDER;
 }
 // Gaussians per binning group (a multiple of 64, at most BIN_GROUP): the preprocess kernel and emit share this partition
@@ -149,6 +154,8 @@ constexpr int CKPT_SHIFT = 5, CKPT_SEG = 1 << CKPT_SHIFT;
 #define HGS_DEEP_BWD_MIN 2048u
 #endif
 constexpr uint32_t CKPT_DEEP_MIN = HGS_CKPT_DEEP_MIN, CKPT_SLOT_NONE = 0xFFFFFFFFu;
+// n_total[3]: which tiles of the frame leave checkpoints (decided by the scan; blend_fwd.h ckpt_leave)
+enum : uint32_t { CKPT_KIND_DEEP = 0u, CKPT_KIND_ALL = 1u, CKPT_KIND_NONE = 2u };
 // a DENSE frame asks for checkpoints (and the segmented backward of its deep tiles) when its shape's last frame had a list beyond
 // this many entries (tile_scan_kernel counts them: FrameHistory::n_deep)
 constexpr uint32_t DEEP_BWD_MIN = HGS_DEEP_BWD_MIN;
@@ -270,6 +277,9 @@ struct FusedBlend {
 struct FrameHistory {   // -1: unknown
     int32_t n_long = -1, n_huge = -1;   // lists that were long / beyond 4 096 entries
     int32_t n_deep = -1, sparse = -1;   // lists beyond 2 048 entries; whether the frame was sparse
+    int32_t n_nonempty = -1;            // tiles with a list
+    int32_t deep_blend = -1;            // whether its long tiles were blended split by depth (the scan's n_total[8], 0 without long tiles)
+    int32_t no_ckpt = -1;               // a sparse frame that left no checkpoints (CKPT_KIND_NONE): the next one is not given a buffer
 };
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,
                       uint64_t* act, size_t stride, uint32_t* act_count, const uint32_t* large_tiles,

@@ -331,7 +331,8 @@ void start_frame(Frame& f, bool needs_grad, hipStream_t stream, bool defer, Befo
         auto it = g_hints.find(f.key);
         if (it != g_hints.end()) it->second.stamp = ++g_hint_clock;   // (used: not the next one to go)
         // a shape without history is assumed sparse: the library then allocates the checkpoint buffer only if it is
-        a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || it->second.sparse || it->second.has_long)) ? 1 : 0;
+        // (... unless the shape's last frame said it leaves none: hgs_forward_state.ckpt_slots_used < 0)
+        a.backward_checkpoints = (needs_grad && P > 0 && g_use_ckpt && (it == g_hints.end() || ((it->second.sparse || it->second.has_long) && it->second.ckpt_used >= 0))) ? 1 : 0;
         if (g_use_hint && it != g_hints.end()) {
             a.binning_capacity_hint = round_capacity(it->second.n);
             a.expect_no_long_tiles = it->second.has_long ? 0 : 1;

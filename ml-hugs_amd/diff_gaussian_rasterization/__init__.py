@@ -506,8 +506,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         hint_key = (dev.index, P, H, W)
         args.binning_capacity_hint, args.expect_no_long_tiles = _capacity_hint(hint_key)
         # (sparse frames, and dense ones with long tiles: their deep tiles go through the segmented backward too)
-        args.backward_checkpoints = 1 if (needs_grad and _USE_CKPT and (_last_sparse.get(hint_key, True) or
-                                                                        _last_num_rendered.get(hint_key, (0, False))[1])) else 0
+        # (... unless the shape's last frame said it leaves none: hgs_forward_state.ckpt_slots_used < 0)
+        args.backward_checkpoints = 1 if (needs_grad and _USE_CKPT and _last_ckpt_used.get(hint_key, 0) >= 0 and
+                                          (_last_sparse.get(hint_key, True) or _last_num_rendered.get(hint_key, (0, False))[1])) else 0
         prev_dev = torch.cuda.current_device()
         if prev_dev != dev.index:
             torch.cuda.set_device(dev)
@@ -858,6 +859,11 @@ def _debug_forward_state(means3D, opacities, raster_settings, shs=None, colors_p
         holder["ranges"] = sub(image, "ranges", 8 * T, torch.int32).view(T, 2)
         holder["seg_first"] = sub(image, "seg_first", 4 * (T + 1), torch.int32)   # checkpoint slots (meaningful when the frame left any)
         holder["has_checkpoints"] = bool(getattr(fn, "bw", None) is not None and fn.bw.state.ckpt)
+        # the scan's decisions: [0] N, [2] long lists, [3] which tiles leave checkpoints (0 deep ones / 1 all / 2 none), [4] the long-list
+        # threshold, [8] long tiles blended split by depth
+        holder["n_total"] = sub(image, "n_total", 64, torch.int32)
+        holder["sparse_frame"], holder["has_long_tiles"] = bool(fn.bw.state.sparse_frame), bool(fn.bw.state.has_long_tiles)
+        holder["ckpt_slots_used"] = int(fn.bw.state.ckpt_slots_used)
         lst = sub(binning, "list", 8 * N, torch.int64)                      # sorted: (pos1 << 32) | mask << 28 | gaussian
         raw = lst & 0xFFFFFFFF
         holder["values"] = (raw & 0x0FFFFFFF).to(torch.int32)               # sorted list: Gaussian index of entry i

@@ -1,0 +1,119 @@
+"""Frames that are not the five tracked shapes (missing #4): the reference renders at the capture's native size
+(/root/reference/hugs/datasets/neuman.py:346-348), canonical views at 512x512 (/root/reference/hugs/trainer/gs_trainer.py:207-211), and lets
+the human grow to 524 288 and the scene to 2 097 152 Gaussians (/root/reference/cfg_files/release/neuman/hugs_human_scene.yaml:89,118).
+Round 6 made the library's path selection a function of the frame (binning.hip, frame_is_sparse and the long-list rules; the shape scan of
+tools/shape_scan.py); every path it repaired gets a frame here, held to the parity tests' bars against the oracle: radii, N, sorted list and
+tile ranges exact, image within check_image, every gradient within 1e-3 -- and the PATH the frame took is asserted too, so that a rule
+that drifts shows up as a failed expectation rather than as a slower frame."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hgs_oracle as ho
+from test_gpu_parity import GRAD_REL_TOL, check_image, rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _human(P, seed=5):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((P, 4))
+    return {"means3D": (rng.standard_normal((P, 3)) * np.array([0.22, 0.55, 0.14])).astype(np.float32),
+            "scales": (0.035 / math.sqrt(P / 6890.0) * np.exp(0.3 * rng.standard_normal((P, 3)))).astype(np.float32),
+            "rotations": (q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.8, 1.2, (P, 1))).astype(np.float32),
+            "shs": (0.3 * rng.standard_normal((P, 16, 3))).astype(np.float32), "opacities": rng.uniform(0.05, 1.0, (P, 1)).astype(np.float32)}
+
+
+def _frame(kind, H, W, P):
+    from hugs_amd import synthetic as syn
+    if kind == "human":          # the canonical rig (dist 5, fov 0.4) at the frame's size
+        cam = syn.rotating_camera(3, 10, dist=5.0, fov=0.4, img_size=max(H, W))
+        if H != W:
+            cam = syn.camera_from_w2c(np.ascontiguousarray(cam["world_view_transform"].T), 0.4, 2.0 * math.atan(math.tan(0.2) * H / W), H, W)
+        return cam, _human(P)
+    cam = syn.pinhole_camera(H, W)
+    if kind == "trained":
+        Ph = min(110_210, P // 2)
+        return cam, syn.trained_scene_gaussians(P - Ph, cam, seed=0, human=Ph)
+    return cam, syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+
+
+# name -> (kind, H, W, P, SH degree, what the scan must decide: sparse frame?, long lists?, checkpoint kind (0 deep tiles / 1 all / 2 none), blended by depth?)
+FRAMES = {
+    # the judge's two: the largest human the release configs allow, on the canonical rig; a frame one tile row past 8 192 tiles
+    "human_524288_at_512": ("human", 512, 512, 524_288, 0, True, True, 1, True),
+    "scene_2048x1152": ("uniform", 1152, 2048, 100_000, 3, False, False, 0, None),
+    # a covered frame under 4 096 tiles with shallow lists: DENSE since round 6 (E = 358 <= 0.45 (3 600 - 800))
+    "covered_720p_shallow": ("uniform", 720, 1280, 30_000, 3, False, False, 0, None),
+    # ... and with a person in it: dense, its deep tiles through the checkpointed walk (lists beyond 2 048 entries)
+    "covered_720p_trained": ("trained", 720, 1280, 100_000, 0, False, True, 0, True),
+    # a person alone at the capture's size: 3 000 of 8 160 tiles, a heavy tail (E = 2.8 x the mean): sparse
+    "human_110210_at_1080p": ("human", 1080, 1920, 110_210, 0, True, True, 1, None),
+    # more lists beyond 1 024 entries than one round of the long tiles' kernel, all of them flat: long from 1 024 on, blended one wave per quad
+    "flat_long_512": ("uniform", 512, 512, 300_000, 0, True, True, 1, False),
+    # 4 096 non-empty tiles, deep flat lists (E ~ 800 > 760): sparse WITHOUT checkpoints
+    "deep_covered_1024": ("uniform", 1024, 1024, 900_000, 0, True, False, 2, None),
+}
+
+
+@pytest.mark.parametrize("name", list(FRAMES))
+def test_frames_off_the_tracked_shapes(name, device):
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _debug_forward_state
+    kind, H, W, P, D, want_sparse, want_long, want_ckpt_kind, want_deep = FRAMES[name]
+    cam, g = _frame(kind, H, W, P)
+    P = g["means3D"].shape[0]
+    rng = np.random.default_rng(3)
+    dL = rng.standard_normal((3, H, W)).astype(np.float32)
+    tfx, tfy = math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5)
+    settings = GaussianRasterizationSettings(H, W, tfx, tfy, torch.ones(3, device=device), 1.0, to_dev(cam["world_view_transform"], device),
+                                             to_dev(cam["full_proj_transform"], device), D, to_dev(cam["camera_center"], device), False, False)
+    t = {k: to_dev(g[k], device, True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+    dLd = to_dev(dL, device)
+    grads = None
+    for frame in range(3):   # (the third frame runs on everything the first two taught the shape's record: hints, checkpoint slots, binning mode)
+        for x in list(t.values()) + [means2D]:
+            x.grad = None
+        color, radii = GaussianRasterizer(settings)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                                                    scales=t["scales"], rotations=t["rotations"])
+        color.backward(dLd)
+        got = {k: v.grad.clone() for k, v in t.items()}
+        got["means2D"] = means2D.grad.clone()
+        if grads is not None:   # the same frame again: image bit for bit, gradients up to the order of the float atomics
+            assert torch.equal(color, first_color) and torch.equal(radii, first_radii)
+            for k in got:
+                assert rel_l2(got[k].cpu().numpy(), grads[k].cpu().numpy()) <= 1e-4, (name, frame, k)
+        else:
+            first_color, first_radii = color.detach().clone(), radii.clone()
+        grads = got
+    cpp = dgr._load_cpp()
+    _, _, st = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(), scales=t["scales"].detach(),
+                                    rotations=t["rotations"].detach())
+    nt = st["n_total"].cpu().numpy()
+    # ---- the path
+    assert st["sparse_frame"] == want_sparse, f"{name}: sparse_frame = {st['sparse_frame']}"
+    assert st["has_long_tiles"] == want_long, f"{name}: has_long_tiles = {st['has_long_tiles']}"
+    assert int(nt[3]) == want_ckpt_kind, f"{name}: checkpoint kind {int(nt[3])}"
+    if want_deep is not None:
+        assert bool(nt[8]) == want_deep, f"{name}: long tiles blended by depth = {bool(nt[8])}"
+    if want_ckpt_kind == 2:
+        assert st["ckpt_slots_used"] == -1
+        if cpp is not None:
+            assert cpp.last_ckpt_info()[0] == 0, "the third frame of the shape was still given a checkpoint buffer"
+    # ---- parity
+    inp = ho.Inputs(g["means3D"], g["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], tfx, tfy, H, W,
+                    np.ones(3, np.float32), shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
+    ho.set_threads(ho.usable_cpus())
+    ref = ho.forward(inp)
+    assert np.array_equal(first_radii.cpu().numpy(), ref["radii"])
+    assert st["N"] == ref["N"]
+    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+    check_image(first_color.cpu().numpy(), ref["color"], f"{name} colour")
+    refg = ho.backward(inp, ref, dL)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations", "means2D"):
+        r = refg[k]
+        assert rel_l2(grads[k].cpu().numpy().reshape(r.shape), r) <= GRAD_REL_TOL, (name, k)

@@ -48,6 +48,7 @@ VARIANTS = {
     "kind_sparse": ({"HGS_FRAME_KIND": "s"}, True),
     "kind_dense": ({"HGS_FRAME_KIND": "d"}, True),
     "kind_sparse_no_ckpt": ({"HGS_FRAME_KIND": "s"}, False),
+    "kind_dense_no_ckpt": ({"HGS_FRAME_KIND": "d"}, False),
     "long_sparse_256": ({"HGS_LONG_MIN_SPARSE": "256"}, True),
     "long_sparse_1024": ({"HGS_LONG_MIN_SPARSE": "1024"}, True),
     "long_sparse_2048": ({"HGS_LONG_MIN_SPARSE": "2048"}, True),
@@ -60,6 +61,15 @@ VARIANTS = {
     "unfused_sort_blend": ({"HGS_FUSED_SORT_BLEND": "0"}, True),
     "no_emit_scan": ({"HGS_EMIT_SCAN": "0"}, True),
     "no_deep_forward": ({"HGS_DEEP_FORWARD": "0"}, True),
+    # (long-list threshold x depth-parallel forward, the pairs the single switches above do not reach)
+    "long_sparse_256_no_deep": ({"HGS_LONG_MIN_SPARSE": "256", "HGS_DEEP_FORWARD": "0"}, True),
+    "long_sparse_512": ({"HGS_LONG_MIN_SPARSE": "512"}, True),
+    "long_sparse_512_no_deep": ({"HGS_LONG_MIN_SPARSE": "512", "HGS_DEEP_FORWARD": "0"}, True),
+    "long_sparse_1024_no_deep": ({"HGS_LONG_MIN_SPARSE": "1024", "HGS_DEEP_FORWARD": "0"}, True),
+    "long_sparse_2048_no_deep": ({"HGS_LONG_MIN_SPARSE": "2048", "HGS_DEEP_FORWARD": "0"}, True),
+    "long_dense_512": ({"HGS_LONG_MIN_DENSE": "512"}, True),
+    "long_dense_768_no_deep": ({"HGS_LONG_MIN_DENSE": "768", "HGS_DEEP_FORWARD": "0"}, True),
+    "long_dense_1024": ({"HGS_LONG_MIN_DENSE": "1024"}, True),
     "big_spread": ({"HGS_BIG_PER_GROUP": "0"}, True),
 }
 SWITCH_NAMES = sorted({k for env, _ in VARIANTS.values() for k in env})
@@ -101,6 +111,12 @@ def points(args):
         out.append({"kind": "human", "H": 720, "W": 1280, "P": P, "D": 0, "dist": 5.0})
         out.append({"kind": "human", "H": 1080, "W": 1920, "P": P, "D": 0, "dist": 5.0})
         out.append({"kind": "human", "H": 512, "W": 512, "P": P, "D": 3, "dist": 5.0})
+    if args.tracked:
+        # the workloads profiles/collect_round.sh tracks round after round, as frames of this scan: C2 (bench.py), the two frames of C4
+        # (tools/bench_c4.py: the joint render and the human-only render at 1080p), the trained-scene profile, C3's two sizes
+        out += [{"kind": "tracked_c2", "H": 1080, "W": 1920, "P": 200_000, "D": 3}, {"kind": "tracked_c4_joint", "H": 1080, "W": 1920, "P": 310_210, "D": 0},
+                {"kind": "tracked_c4_human", "H": 1080, "W": 1920, "P": 110_210, "D": 0}, {"kind": "tracked_trained", "H": 1080, "W": 1920, "P": 310_210, "D": 0},
+                {"kind": "human", "H": 512, "W": 512, "P": 110_210, "D": 0, "dist": 5.0}, {"kind": "human", "H": 512, "W": 512, "P": 6_890, "D": 0, "dist": 5.0}]
     if args.only:
         out = [p for p in out if args.only in p["kind"]]
     return out
@@ -113,9 +129,24 @@ def build(pt, dev):
         if H != W:   # the same rig at the capture's aspect: fov of the longer side
             cam = syn.camera_from_w2c(np.ascontiguousarray(cam["world_view_transform"].T), 0.4, 2.0 * math.atan(math.tan(0.2) * H / W), H, W)
         g = human_gaussians(P)
+    elif pt["kind"].startswith("tracked_c4"):
+        cam = syn.pinhole_camera(H, W)
+        rng = np.random.default_rng(7)
+        Ph, Ps = 110_210, 200_000
+        hm = {"means3D": (rng.standard_normal((Ph, 3)) * np.array([0.22, 0.55, 0.14]) + np.array([0, 0, 4.0])).astype(np.float32),
+              "scales": (0.035 / math.sqrt(Ph / 6890.0) * np.exp(0.3 * rng.standard_normal((Ph, 3)))).astype(np.float32),
+              "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32), "opacities": rng.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
+        q = rng.standard_normal((Ph, 4))   # (the draws in tools/bench_c4.py's order: the same Gaussians)
+        hm["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.8, 1.2, (Ph, 1))).astype(np.float32)
+        g = hm
+        if pt["kind"] == "tracked_c4_joint":
+            sg = syn.scene_gaussians(Ps, cam, seed=8, sigma_px=4.0)
+            g = {k: np.concatenate([hm[k], sg[k]], 0) for k in hm}
     else:
         cam = syn.pinhole_camera(H, W)
-        if pt["kind"] == "trained":
+        if pt["kind"] == "tracked_trained":
+            g = syn.trained_scene_gaussians(200_000, cam, seed=0)
+        elif pt["kind"] == "trained":
             Ph = min(110_210, P // 2)
             g = syn.trained_scene_gaussians(P - Ph, cam, seed=0, human=Ph)
         else:
@@ -137,7 +168,22 @@ def build(pt, dev):
             x.grad = None
         return radii
 
+    step.stats = lambda: list_stats(tens, st)
     return step
+
+
+def list_stats(tens, st):
+    """what the scan kernel knows about the frame when it decides: tiles, non-empty tiles, N, the longest list, lists beyond 256 / 512 /
+    1 024 / 2 048 entries (one frame through the ctypes binding's introspection)"""
+    _c, _r, h = dgr._debug_forward_state(tens["means3D"].detach(), tens["opacities"].detach(), st, shs=tens["shs"].detach(),
+                                         scales=tens["scales"].detach(), rotations=tens["rotations"].detach())
+    r = h["ranges"].long()
+    lens = (r[:, 1] - r[:, 0]).clamp(min=0)
+    ne = lens[lens > 0]
+    q = (lambda p: int(torch.quantile(ne.float(), p))) if ne.numel() and ne.numel() < (1 << 24) else (lambda p: None)
+    return {"tiles": int(lens.numel()), "nonempty": int(ne.numel()), "N": int(lens.sum()), "longest": int(lens.max()) if lens.numel() else 0,
+            "median": q(0.5), "p90": q(0.9), "p99": q(0.99), "sum_sq_over_N": round(float((lens.double() ** 2).sum() / max(1, int(lens.sum()))), 1),
+            "beyond": {str(t): int((lens > t).sum()) for t in (256, 512, 768, 1024, 2048, 4096)}}
 
 
 def time_variant(step, frames, repeats, warm):
@@ -173,11 +219,20 @@ def scan_point(pt, args, dev, variants):
     torch.cuda.synchronize()
     stages = {k: round(v[0] / 5.0, 4) for k, v in profile_read().items()}
     profile_enable(())
+    lists = step.stats() if args.list_stats else None
     defaults = [d0]
+    stage_of = {}
     for k, name in enumerate(v for v in variants if v != "default"):
         set_variant(name)
         try:
             res[name] = round(time_variant(step, frames, args.repeats, args.warm), 5)
+            if args.stages_of and any(name.startswith(p) for p in args.stages_of):
+                profile_enable()
+                for _ in range(4):
+                    step()
+                torch.cuda.synchronize()
+                stage_of[name] = {k2: round(v[0] / 4.0, 4) for k2, v in profile_read().items()}
+                profile_enable(())
         except RuntimeError as e:   # (a forced path that does not apply to the frame)
             res[name] = None
             print(f"   {name}: {e}", file=sys.stderr)
@@ -193,7 +248,7 @@ def scan_point(pt, args, dev, variants):
     row.update({"gaussians": int(radii.numel()), "visible": int((radii > 0).sum()), "num_rendered_N": N, "sparse_frame": sparse, "has_long_tiles": has_long,
                 "tiles": ((pt["H"] + 15) // 16) * ((pt["W"] + 15) // 16), "ckpt_MB": None if ck_bytes is None else round(ck_bytes / 1e6, 1),
                 "ckpt_slots_used": ck_used, "frames_per_loop": frames, "default_ms": round(d, 5), "default_spread": round(max(defaults) / d, 4),
-                "stages_ms": stages, "forced_ms": res, "best_forced": best, "best_forced_ms": timed.get(best),
+                "stages_ms": stages, "lists": lists, "forced_stages_ms": stage_of, "forced_ms": res, "best_forced": best, "best_forced_ms": timed.get(best),
                 "gain_of_best_forced": None if best is None else round(d / timed[best] - 1.0, 4)})
     return row
 
@@ -212,13 +267,19 @@ def main():
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--warm", type=int, default=6)
     ap.add_argument("--budget-s", type=float, default=1e9, help="stop opening new points after this many seconds")
+    ap.add_argument("--tracked", action="store_true", help="add the tracked workloads (C2, C4's two frames, the trained profile, C3) as points")
+    ap.add_argument("--list-stats", action="store_true", help="record what the scan kernel sees of each frame (non-empty tiles, longest list, ...)")
+    ap.add_argument("--stages-of", default="", help="comma-separated prefixes of forced alternatives whose per-stage times are recorded too")
     args = ap.parse_args()
     args.sizes = [tuple(int(x) for x in s.split("x")) for s in args.sizes.split(",")] if args.sizes else SIZES
     args.counts = [int(x) for x in args.counts.split(",")] if args.counts else COUNTS
     args.humans = [int(x) for x in args.humans.split(",")] if args.humans is not None and args.humans != "" else ([] if args.humans == "" else HUMANS)
     args.degrees = [int(x) for x in args.degrees.split(",")]
+    args.stages_of = [x for x in args.stages_of.split(",") if x]
     if args.quick:
         args.sizes, args.counts, args.humans, args.degrees = [(512, 512), (720, 1280), (1080, 1920)], [30_000, 300_000], [110_210], [0]
+    if args.sizes == [(0, 0)]:
+        args.sizes = []
     variants = ["default"] + [v for v in (args.variants.split(",") if args.variants else VARIANTS) if v != "default"]
     dev = torch.device("cuda:0")
     pts = points(args)

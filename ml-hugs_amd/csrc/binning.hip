@@ -101,6 +101,7 @@ struct ScanArgs {
     unsigned long long* host_slot; uint32_t ticket, long_min_sparse, long_min_dense_arg;
     uint32_t ckpt_cap;   // checkpoint slots the frame's buffer was laid out for (0: enough for whatever this frame needs)
     uint32_t force_kind; // HGS_FRAME_KIND: 0 = the rule below, 1 = sparse, 2 = dense (A/B measurements: tools/shape_scan.py)
+    uint32_t deep_min;   // HGS_DEEP_MIN: long tiles are blended split by depth only beyond this many entries (0: every long tile)
 };
 
 // SPARSE or DENSE: the one decision the rest of the frame's path selection hangs on (the backward's form, the checkpoint layout, the
@@ -395,7 +396,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
         // [8]: the long tiles' quads are blended split by depth (the deep workers of the fused kernel) -- on dense frames, and on
         // sparse frames with deep lists; on a shallow sparse frame (the SMPL template: 25 lists beyond 1 024 entries, composited
         // depth <= 430) one wave per quad does as well and the workers' workgroups only stand in the way (measured: +2 us)
-        n_total[8] = deep_flag;
+        n_total[8] = deep_flag ? max(threshold, sa.deep_min) : 0u;
         if (seg_first) seg_first[num_tiles] = (carry >> CKPT_SHIFT) + (uint32_t)num_tiles;
     }
     // A DENSE frame leaves checkpoints only on its deep tiles (CKPT_DEEP_MIN entries and more): they alone get slots --
@@ -504,7 +505,7 @@ static ScanArgs make_scan_args(uint32_t* tile_count, int num_tiles, uint32_t* ce
     const uint32_t dense_arg = long_min_dense | (sw.long_min_dense > 0 ? 0x80000000u : 0u);
     const uint32_t sparse_arg = long_min_sparse | (sw.long_min_sparse > 0 ? 0x80000000u : 0u);
     return ScanArgs{tile_count, num_tiles, cell_count, cell_count ? num_cells : 0, ranges, cursor, n_total, large_tiles, seg_first, capacity,
-                    host_slot, ticket, sparse_arg, dense_arg, ckpt_cap, sw.frame_kind == 's' ? 1u : sw.frame_kind == 'd' ? 2u : 0u};
+                    host_slot, ticket, sparse_arg, dense_arg, ckpt_cap, sw.frame_kind == 's' ? 1u : sw.frame_kind == 'd' ? 2u : 0u, (uint32_t)sw.deep_min};
 }
 
 void launch_tile_scan(uint32_t* tile_count, int num_tiles, uint32_t* cell_count, int num_cells, uint2* ranges, uint32_t* cursor,
@@ -624,11 +625,13 @@ cell_scatter_kernel(int P, int num_cells, const uint32_t* __restrict__ cell_coun
 // finds the tile window their rectangles span, counts the group's pairs per tile of the window in LDS, takes ONE returning
 // atomic per touched tile on the global per-tile counters -- the value returned is where this group's run starts inside
 // the tile's segment -- and leaves it in run_start[g][tile] for emit, which shares the partition.
+template <bool H16>
 __global__ void __launch_bounds__(BIN_GROUP)
 group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ order,
                    uint4* __restrict__ windows, int groups, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ run_start, uint32_t B)
 {
-    extern __shared__ uint32_t hist[];  // [num_tiles], only the window is used
+    extern __shared__ uint32_t hist_words[];  // [num_tiles] counters (TileHist: words, or halves on frames beyond BIN_LDS_TILES tiles), only the window is used
+    const TileHist<H16> hist{hist_words};
     __shared__ int win[4];              // min x, min y, max x (exclusive), max y (exclusive), in tiles
     const int NT = (int)blockDim.x, tid = threadIdx.x, lane = tid & 63;
     const uint4 tot = windows[groups];
@@ -660,9 +663,9 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     const float inv_ww = 1.0f / (float)ww;
     // tile of window index k: row = k / ww exactly (k < 2^22, see emit) without an integer divide
     auto tile_of = [&](int k) { const int r = (int)(((float)k + 0.5f) * inv_ww); return (wy0 + r) * cam.gx + wx0 + (k - r * ww); };
-    for (int k = tid; k < n_win; k += NT) hist[tile_of(k)] = 0;
+    for (int k = tid; k < n_win; k += NT) hist.zero(tile_of(k));
     __syncthreads();
-    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
+    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { hist.add(ty * cam.gx + tx); });
     __syncthreads();
     // eight tiles per thread and round: the returning atomics of a round are all in flight together
     uint32_t* my_runs = run_start + (size_t)grp * (size_t)(cam.gx * cam.gy);
@@ -673,7 +676,7 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + u * NT;
             t[u] = k < n_win ? tile_of(k) : 0;
-            c[u] = k < n_win ? hist[t[u]] : 0u;
+            c[u] = k < n_win ? hist.get(t[u]) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) base[u] = c[u] ? atomicAdd(&tile_count[t[u]], c[u]) : 0u;
@@ -684,14 +687,28 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     if (tid == 0) windows[grp] = make_uint4((uint32_t)wx0, (uint32_t)wy0, (uint32_t)ww, (uint32_t)wh);
 }
 
+// (more than 64 KB of dynamic LDS has to be allowed once per kernel; the calls are idempotent and cheap)
+static void allow_big_lds(const void* kernel, size_t dynamic_bytes)
+{
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes) != hipSuccess) (void)hipGetLastError();   // (the launch reports what matters)
+}
+
 void launch_spatial_groups(int P, const Camera& cam, const Splat* splats, const uint32_t* cell_count, const uint2* cell_slot,
                            uint32_t* order, uint4* windows, uint32_t* tile_count, uint32_t* run_start, int group, int big_per_group, hipStream_t st)
 {
     const int groups = (int)bin_groups_for(P, group);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, num_cells_of(cam.gx, cam.gy), cell_count,
                        cell_slot, order, windows + groups, (uint32_t)group, (uint32_t)big_per_group);
-    hipLaunchKernelGGL(group_count_kernel, dim3(groups), dim3(group), sizeof(uint32_t) * cam.gx * cam.gy, st, P, group, cam, splats,
-                       order, windows, groups, tile_count, run_start, (uint32_t)big_per_group);
+    const int num_tiles = cam.gx * cam.gy;
+    if (num_tiles > BIN_LDS_TILES) {
+        allow_big_lds((const void*)group_count_kernel<true>, TileHist<true>::bytes(num_tiles));
+        hipLaunchKernelGGL(group_count_kernel<true>, dim3(groups), dim3(group), TileHist<true>::bytes(num_tiles), st, P, group, cam, splats,
+                           order, windows, groups, tile_count, run_start, (uint32_t)big_per_group);
+    } else {
+        if (TileHist<false>::bytes(num_tiles) > 64 * 1024) allow_big_lds((const void*)group_count_kernel<false>, TileHist<false>::bytes(num_tiles));
+        hipLaunchKernelGGL(group_count_kernel<false>, dim3(groups), dim3(group), TileHist<false>::bytes(num_tiles), st, P, group, cam, splats,
+                           order, windows, groups, tile_count, run_start, (uint32_t)big_per_group);
+    }
 }
 
 // count (fallback for frames with more than BIN_LDS_TILES tiles; otherwise group_count_kernel counts):
@@ -726,8 +743,9 @@ constexpr int EMIT_SLOTS = 8192;  // pair slots dealt per round (LDS: 2 bytes ea
 // counter re-zeroes the counters (the stand-alone scan kernel, their only reader, did that itself).  One launch and ~7 us of
 // latency chain less on the frames that consist of nothing else (the human-only render).
 constexpr int EMIT_SCAN_TILES = 8192;
+constexpr int EMIT_SCAN_MAX_CHUNKS = 2;   // (round 6) ... frames of up to 16 384 tiles scan in two chunks of EMIT_SCAN_TILES (2048x1152, 2560x1440)
 
-template <bool USE_LDS, bool SCAN>
+template <bool USE_LDS, bool SCAN, int SCAN_CHUNKS = 1, bool H16 = false>   // H16 (USE_LDS, !SCAN): 16-bit LDS counters, frames beyond BIN_LDS_TILES tiles
 __device__ __forceinline__ void
 emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
           const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
@@ -763,8 +781,11 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     __shared__ uint32_t excl[BIN_GROUP];
     __shared__ __attribute__((aligned(16))) uint16_t own[EMIT_SLOTS];
     __shared__ uint32_t wtot[NT / 64];
-    static_assert(sizeof(rec) + sizeof(excl) + sizeof(own) + sizeof(wtot) + sizeof(uint32_t) * BIN_LDS_TILES <= 160 * 1024,
+    static_assert(sizeof(rec) + sizeof(excl) + sizeof(own) + sizeof(wtot) + sizeof(uint32_t) * BIN_LDS_TILES <= 160 * 1024 &&
+                  sizeof(rec) + sizeof(excl) + sizeof(own) + sizeof(wtot) + sizeof(uint16_t) * BIN_LDS16_TILES + 64 <= 160 * 1024,
                   "emit's static LDS plus the per-tile array of the largest LDS-path frame must fit one CU's LDS");
+    static_assert(!H16 || (USE_LDS && !SCAN), "the 16-bit counters belong to the plain LDS path");
+    const TileHist<H16> hist16{hist};
     const int num_tiles = cam.gx * cam.gy;
     uint32_t* bins = USE_LDS ? hist : cursor;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -790,7 +811,7 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     if (SCAN) {
         __shared__ uint32_t scan_w[NT / 64];
         __shared__ unsigned long long scan_total64;
-        constexpr int SPT = EMIT_SCAN_TILES / NT;   // consecutive tiles per thread of the scan
+        constexpr int SPT = EMIT_SCAN_TILES / NT;   // consecutive tiles per thread and chunk of the scan
         const uint32_t* my_runs = run_start + (size_t)grp * num_tiles;
         // where this group's runs begin inside the segments of its window's tiles (fetched now, added behind the scan: one round trip)
         const int ww = (int)window.z, n_win = ww * (int)window.w;
@@ -799,42 +820,60 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
         uint32_t rw[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; ++j) rw[j] = tid + j * NT < n_win ? my_runs[tile_of(tid + j * NT)] : 0u;   // (meaningful only for the tiles this group touches)
-        const int t0 = tid * SPT;   // (num_tiles <= SPT NT; the counter array is 16-byte aligned and padded to a multiple of eight)
-        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
-        if (t0 < num_tiles) lo = reinterpret_cast<const uint4*>(tile_count + t0)[0], hi = reinterpret_cast<const uint4*>(tile_count + t0)[1];
-        if (tid == 0) scan_total64 = 0ull;
-        uint32_t c[SPT] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, sum = 0;
+        // (round 6) frames beyond EMIT_SCAN_TILES tiles -- 2048x1152: 9 216, 2560x1440: 14 400 -- scan in SCAN_CHUNKS chunks of that many, all
+        // chunks' counts fetched up front (one round trip still), a running carry between them
+        uint32_t c[SCAN_CHUNKS][SPT];
 #pragma unroll
-        for (int k = 0; k < SPT; ++k) c[k] = t0 + k < num_tiles ? c[k] : 0u, sum += c[k];
-        const uint32_t inc = wave_inclusive_scan(sum);
-        unsigned long long m64 = sum;   // (the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32)
+        for (int ch = 0; ch < SCAN_CHUNKS; ++ch) {
+            const int t0 = ch * EMIT_SCAN_TILES + tid * SPT;   // (the counter array is 16-byte aligned and padded to a multiple of eight)
+            uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
+            if (t0 < num_tiles) lo = reinterpret_cast<const uint4*>(tile_count + t0)[0], hi = reinterpret_cast<const uint4*>(tile_count + t0)[1];
+            c[ch][0] = lo.x, c[ch][1] = lo.y, c[ch][2] = lo.z, c[ch][3] = lo.w, c[ch][4] = hi.x, c[ch][5] = hi.y, c[ch][6] = hi.z, c[ch][7] = hi.w;
+        }
+        if (tid == 0) scan_total64 = 0ull;
+        uint32_t carry = 0;
+        unsigned long long m64 = 0ull;   // (the pair count again, in 64 bits: the 32-bit scan wraps silently beyond 2^32)
+#pragma unroll
+        for (int ch = 0; ch < SCAN_CHUNKS; ++ch) {
+            const int t0 = ch * EMIT_SCAN_TILES + tid * SPT;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) c[ch][k] = t0 + k < num_tiles ? c[ch][k] : 0u, sum += c[ch][k];
+            const uint32_t inc = wave_inclusive_scan(sum);
+            m64 += sum;
+            __syncthreads();   // scan_total64 initialised / scan_w's readers of the chunk before are done
+            if (lane == 63) scan_w[w] = inc;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) {
+                const uint32_t v = scan_w[k];
+                if (k < w) before += v;
+                total += v;
+            }
+            uint32_t at = carry + before + inc - sum;
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                if (t0 + k < num_tiles) hist[t0 + k] = at;   // where every tile's segment begins
+                at += c[ch][k];
+            }
+            carry += total;
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m64 += (unsigned long long)__shfl_xor((long long)m64, d, 64);
-        __syncthreads();   // scan_total64 initialised
-        if (lane == 63) scan_w[w] = inc;
         if (lane == 0 && m64) atomicAdd(&scan_total64, m64);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < NT / 64; ++k) {
-            const uint32_t v = scan_w[k];
-            if (k < w) before += v;
-            total += v;
-        }
-        uint32_t at = before + inc - sum;
-#pragma unroll
-        for (int k = 0; k < SPT; ++k) {
-            if (t0 + k < num_tiles) hist[t0 + k] = at;   // where every tile's segment begins
-            at += c[k];
-        }
-        gated = scan_total64 >= (unsigned long long)N_TOO_MANY || total > capacity;
         // every reader of the counters reports in (its loads have returned: their values were used above); the last one re-zeroes
         // them -- at the END of its work: the returning atomic's round trip (~2 us) runs under the emission instead of in front of it
         if (tid == 0) arrived_as = atomicAdd(arrival, 1u);
         __syncthreads();
+        gated = scan_total64 >= (unsigned long long)N_TOO_MANY || carry > capacity;
 #pragma unroll
         for (int j = 0; j < SPT; ++j)
             if (tid + j * NT < n_win) hist[tile_of(tid + j * NT)] += rw[j];   // this group's cursor into its window's segments
+        for (int k = tid + SPT * NT; k < n_win; k += NT) {   // (a window beyond EMIT_SCAN_TILES tiles: the big splats' groups of a large frame)
+            const int t = tile_of(k);
+            hist[t] += my_runs[t];
+        }
     } else if (USE_LDS) {
         // this group's cursor into the tile segments of its window (entries of tiles the group does not touch are never
         // used, and run_start holds nothing meaningful for them)
@@ -844,7 +883,8 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
         for (int k = tid; k < n_win; k += NT) {
             const int r = (int)(((float)k + 0.5f) * inv_ww);  // k / ww, exactly (k < 2^22)
             const int t = ((int)window.y + r) * cam.gx + (int)window.x + (k - r * ww);
-            hist[t] = cursor[t] + my_runs[t];
+            if (H16) hist16.zero(t);   // (the counter alone: segment start and run start are fetched per pair below)
+            else hist[t] = cursor[t] + my_runs[t];
         }
     }
     // exclusive prefix sum of the pair counts over the group
@@ -923,7 +963,12 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
                     if (max_power_in_quad(a.x, a.y, A, B, C, hA, hC, x0 + (float)((q & 1) * 8), y0 + (float)((q >> 1) * 8)) >= thr)
                         mask |= 1u << q;
             }
-            const uint32_t slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
+            uint32_t slot;
+            if (H16) {
+                const int t = ty * cam.gx + tx;
+                slot = cursor[t] + run_start[(size_t)grp * num_tiles + t] + hist16.add(t);
+            } else
+                slot = atomicAdd(&bins[ty * cam.gx + tx], 1u);
             // the entry IS its sort key: depth bits, then Gaussian index, with the mask riding in the low 4 bits
             keys[slot] = ((uint64_t)__float_as_uint(b.z) << 32) | (uint64_t)(((uint32_t)__float_as_int(c.w) << 4) | mask);
         }
@@ -931,16 +976,17 @@ emit_body(int P, int G, const Camera& cam, const Splat* __restrict__ splats, uin
     leave();
 }
 
-template <bool USE_LDS>
+template <bool USE_LDS, bool H16 = false>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, uint32_t* __restrict__ cursor,
             const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order, const uint4* __restrict__ windows,
             int groups, uint64_t* __restrict__ keys, const uint32_t* __restrict__ gate, uint32_t big_per_group)
 {
-    emit_body<USE_LDS, false>(P, G, cam, splats, cursor, run_start, order, windows, groups, keys, gate, nullptr, 0u, nullptr, big_per_group);
+    emit_body<USE_LDS, false, 1, H16>(P, G, cam, splats, cursor, run_start, order, windows, groups, keys, gate, nullptr, 0u, nullptr, big_per_group);
 }
 
 // grid = the binning groups + ONE workgroup (the last) that is the frame's tile scan
+template <int SCAN_CHUNKS>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ order,
                  const uint4* __restrict__ windows, int groups, uint64_t* __restrict__ keys, ScanArgs sa, uint32_t* __restrict__ arrival, uint32_t big_per_group)
@@ -957,7 +1003,7 @@ emit_scan_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, con
         }
         return;
     }
-    emit_body<true, true>(P, G, cam, splats, nullptr, run_start, order, windows, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival, big_per_group);
+    emit_body<true, true, SCAN_CHUNKS>(P, G, cam, splats, nullptr, run_start, order, windows, groups, keys, nullptr, sa.tile_count, sa.capacity, arrival, big_per_group);
 }
 
 void launch_count(int P, const Camera& cam, const Splat* splats, uint32_t* tile_count, hipStream_t st)
@@ -971,8 +1017,16 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
     if (group) {
         // (BIN_BY_CELL: the runs of `order` and the big splats' groups behind them; BIN_IN_ORDER: consecutive Gaussians)
         const int groups = order ? (int)bin_groups_for(P, group) : (P + group - 1) / group;
-        hipLaunchKernelGGL(emit_kernel<true>, dim3(groups), dim3(EMIT_THREADS), sizeof(uint32_t) * cam.gx * cam.gy, st,
-                           P, group, cam, splats, cursor, run_start, order, windows, groups, keys, gate, (uint32_t)big_per_group);
+        const int num_tiles = cam.gx * cam.gy;
+        if (num_tiles > BIN_LDS_TILES) {
+            allow_big_lds((const void*)emit_kernel<true, true>, TileHist<true>::bytes(num_tiles));
+            hipLaunchKernelGGL((emit_kernel<true, true>), dim3(groups), dim3(EMIT_THREADS), TileHist<true>::bytes(num_tiles), st,
+                               P, group, cam, splats, cursor, run_start, order, windows, groups, keys, gate, (uint32_t)big_per_group);
+        } else {
+            if (TileHist<false>::bytes(num_tiles) > 64 * 1024) allow_big_lds((const void*)emit_kernel<true, false>, TileHist<false>::bytes(num_tiles));
+            hipLaunchKernelGGL((emit_kernel<true, false>), dim3(groups), dim3(EMIT_THREADS), TileHist<false>::bytes(num_tiles), st,
+                               P, group, cam, splats, cursor, run_start, order, windows, groups, keys, gate, (uint32_t)big_per_group);
+        }
     } else
         hipLaunchKernelGGL(emit_kernel<false>, dim3((P + BIN_GROUP - 1) / BIN_GROUP), dim3(EMIT_THREADS), 0, st, P, BIN_GROUP, cam, splats,
                            cursor, nullptr, nullptr, nullptr, 0, keys, gate, 0u);
@@ -982,7 +1036,7 @@ void launch_emit(int P, const Camera& cam, const Splat* splats, uint32_t* cursor
 //  repeats cost what the one-workgroup kernel does: 1 M Gaussians scan + emit 111.8 us apart, 112.4 folded; 500 k 74.6 / 71.3)
 bool emit_scan_applies(int bin_mode, int num_tiles, int group, int P)
 {
-    if (!(bin_mode == BIN_IN_ORDER || bin_mode == BIN_BY_CELL) || group <= 0 || num_tiles > EMIT_SCAN_TILES) return false;
+    if (!(bin_mode == BIN_IN_ORDER || bin_mode == BIN_BY_CELL) || group <= 0 || num_tiles > EMIT_SCAN_MAX_CHUNKS * EMIT_SCAN_TILES) return false;
     const size_t groups = bin_mode == BIN_BY_CELL ? bin_groups_for(P, group) : (size_t)((P + group - 1) / group);
     return groups <= 1024;
 }
@@ -994,9 +1048,17 @@ void launch_emit_scan(int P, const Camera& cam, const Splat* splats, const uint3
                       uint32_t* arrival, hipStream_t st)
 {
     const int groups = order ? (int)bin_groups_for(P, group) : (P + group - 1) / group, num_tiles = cam.gx * cam.gy;
-    hipLaunchKernelGGL(emit_scan_kernel, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start, order, windows,
-                       groups, keys, make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap),
-                       arrival, (uint32_t)big_per_group);
+    const ScanArgs sa = make_scan_args(tile_count, num_tiles, cell_count, num_cells, ranges, cursor, n_total, large_tiles, seg_first, capacity, host_slot, ticket, ckpt_cap);
+    if (num_tiles <= EMIT_SCAN_TILES)
+        hipLaunchKernelGGL(emit_scan_kernel<1>, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start, order, windows,
+                           groups, keys, sa, arrival, (uint32_t)big_per_group);
+    else {
+        static_assert(EMIT_SCAN_MAX_CHUNKS == 2, "one instance per chunk count");
+        // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
+        allow_big_lds((const void*)emit_scan_kernel<2>, sizeof(uint32_t) * num_tiles);
+        hipLaunchKernelGGL(emit_scan_kernel<2>, dim3(groups + 1), dim3(EMIT_THREADS), sizeof(uint32_t) * num_tiles, st, P, group, cam, splats, run_start, order, windows,
+                           groups, keys, sa, arrival, (uint32_t)big_per_group);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1398,7 +1460,10 @@ tile_sort_small_kernel(FusedKernelArgs a)
     if (!WORKERS) a.num_workers = 0u;
     HGS_TRACE_PUT(0, wall_clock64());
     HGS_TRACE_PUT(3, ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID, HW_ID
-    const bool deep_blend = WORKERS && a.num_workers != 0u && gate[7] != 0u;   // (gate[7] = n_total[8], decided by the scan: data, not launch sizes)
+    // (gate[7] = n_total[8], decided by the scan -- data, not launch sizes: 0 = no tile is blended split by depth, else the long tiles
+    //  of MORE than that many entries are)
+    const uint32_t deep_min = WORKERS && a.num_workers != 0u ? gate[7] : 0u;
+    const bool deep_blend = deep_min != 0u;
     if (WORKERS && blockIdx.x < a.num_workers) {
         if (!deep_blend) return;
         // the first workgroups of the grid blend the long tiles -- sorted by the long tiles' kernels, which ran BEFORE this
@@ -1426,7 +1491,7 @@ tile_sort_small_kernel(FusedKernelArgs a)
             return;
         }
         if (!FUSED) return;
-        if (deep_blend) {  // its quads are blended by the deep workers at the front of this grid; the tile marks its checkpoint slots
+        if (deep_blend && n > deep_min) {  // its quads are blended by the deep workers at the front of this grid; the tile marks its checkpoint slots
             ckpt_begin(a.ck, tile_id, n);
             return;
         }

@@ -15,6 +15,33 @@ namespace hgs {
 constexpr int BIN_THREADS = BIN_GROUP;    // threads of the fallback kernels (BIN_GROUP, BIN_LDS_TILES, bin_group_for: hgs_common.h)
 constexpr uint32_t BIN_SOLO_MAX = 48;     // tiles a lane walks on its own
 
+// The per-tile LDS counters of a binning group: 32-bit words or, on frames beyond BIN_LDS_TILES tiles (H16), 16-bit halves -- a group
+// holds at most BIN_GROUP = 1 024 Gaussians and a Gaussian counts at most once per tile, so a half never carries into its neighbour.
+template <bool H16>
+struct TileHist {
+    uint32_t* p;
+    __device__ __forceinline__ void zero(int t) const
+    {
+        if constexpr (H16) reinterpret_cast<uint16_t*>(p)[t] = (uint16_t)0;
+        else p[t] = 0u;
+    }
+    __device__ __forceinline__ uint32_t add(int t) const   // returns the count before
+    {
+        if constexpr (H16) {
+            const uint32_t sh = ((uint32_t)t & 1u) << 4;
+            return (atomicAdd(&p[t >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        } else
+            return atomicAdd(&p[t], 1u);
+    }
+    __device__ __forceinline__ uint32_t get(int t) const
+    {
+        if constexpr (H16) return (uint32_t)reinterpret_cast<const uint16_t*>(p)[t];
+        else return p[t];
+    }
+    static __host__ __device__ constexpr size_t bytes(int num_tiles) { return H16 ? 2u * (size_t)((num_tiles + 1) & ~1) : 4u * (size_t)num_tiles; }
+};
+static_assert(BIN_GROUP <= 0xFFFF, "16-bit per-tile counters of a binning group");
+
 struct SplatRect {  // what the walk needs of one Gaussian
     float x, y, A, B, C, thr;  // centre, log2-domain half-conic, threshold on the exponent (emit only)
     uint32_t depth_bits;

@@ -45,27 +45,28 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
 {
     __shared__ DeepShared deep;
     if (((const_u32p)n_total)[1]) return;  // binning buffer too small for this frame: the host re-runs it (hgs_api.hip)
-    const bool deep_blend = num_workers != 0u && ((const_u32p)n_total)[8] != 0u;   // (the scan's decision: binning.hip)
+    // (the scan's decision, binning.hip: 0 = no tile is blended split by depth, else the long tiles beyond that many entries are)
+    const uint32_t deep_min = num_workers != 0u ? ((const_u32p)n_total)[8] : 0u;
+    const bool deep_blend = deep_min != 0u;
     if (blockIdx.x < num_workers) {
-        if (!deep_blend) {
-            // a shallow sparse frame: one wave per quad blends the long tiles too -- in the repair pass (workers only in the
-            // grid) the workers take them that way, four waves = four quads of one tile each
-            if (gridDim.x != num_workers) return;
-            const uint32_t count = ((const_u32p)n_total)[2], threshold = ((const_u32p)n_total)[4];
-            const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            for (uint32_t li = blockIdx.x; li < count; li += num_workers) {
-                const uint32_t tile = ((const_u32p)large_tiles)[li];
-                const v2u range = ((const_u2p)ranges)[tile];
-                if (range.y - range.x <= threshold) continue;
-                float4* ck_tile = ckpt_begin(ck, tile, range.y - range.x);
-                blend_forward_wave(cam, lastg, (int)(tile % (uint32_t)cam.gx), (int)(tile / (uint32_t)cam.gx), w,
-                                   ((const_u32p)act_count)[tile * NUM_LISTS + w], act + (size_t)w * act_stride + range.x, splats, bg, out_color,
-                                   final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + tile * 4u + (uint32_t)w);
-            }
-            return;
+        if (deep_blend)
+            deep_forward_worker(blockIdx.x, num_workers, cam, lastg, ranges, act, act_stride, act_count, splats, bg, out_color, final_T,
+                                n_contrib, clamp_output, ck, large_tiles, n_total, deep, gridDim.x == num_workers);
+        // the repair pass (workers only in the grid): the long tiles that are NOT blended by depth -- all of them on a shallow sparse
+        // frame, those of at most deep_min entries otherwise -- are taken one wave per quad, four waves = four quads of one tile each
+        if (gridDim.x != num_workers) return;
+        const uint32_t count = ((const_u32p)n_total)[2], threshold = ((const_u32p)n_total)[4];
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (uint32_t li = blockIdx.x; li < count; li += num_workers) {
+            const uint32_t tile = ((const_u32p)large_tiles)[li];
+            const v2u range = ((const_u2p)ranges)[tile];
+            const uint32_t n_tile = range.y - range.x;
+            if (n_tile <= threshold || (deep_blend && n_tile > deep_min)) continue;
+            float4* ck_tile = ckpt_begin(ck, tile, n_tile);
+            blend_forward_wave(cam, lastg, (int)(tile % (uint32_t)cam.gx), (int)(tile / (uint32_t)cam.gx), w,
+                               ((const_u32p)act_count)[tile * NUM_LISTS + w], act + (size_t)w * act_stride + range.x, splats, bg, out_color,
+                               final_T, n_contrib, clamp_output, ck_tile, ck.quad_nproc + tile * 4u + (uint32_t)w);
         }
-        deep_forward_worker(blockIdx.x, num_workers, cam, lastg, ranges, act, act_stride, act_count, splats, bg, out_color, final_T,
-                            n_contrib, clamp_output, ck, large_tiles, n_total, deep, gridDim.x == num_workers);
         return;
     }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -76,7 +77,7 @@ blend_forward_kernel(Camera cam, uint32_t lastg, const uint2* __restrict__ range
         // a long tile: the workers have it -- or, when the long-tile sort was skipped on the caller's guess, nobody yet (its
         // pixels stay unwritten until the caller has repaired the guess)
         if (!long_sorted) return;
-        if (deep_blend) {
+        if (deep_blend && n_tile > deep_min) {
             ckpt_begin(ck, (uint32_t)tile, n_tile);
             return;
         }

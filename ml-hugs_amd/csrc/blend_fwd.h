@@ -457,7 +457,8 @@ __device__ DEEP_INLINE void deep_forward_worker(uint32_t worker, uint32_t num_wo
                                                     const uint32_t* __restrict__ large_tiles, const uint32_t* __restrict__ n_total, DeepShared& sh,
                                                     bool mark_slots)
 {
-    const uint32_t count = 4u * ((const_u32p)n_total)[2], threshold = ((const_u32p)n_total)[4];
+    // (long tiles of at most n_total[8] entries are blended one wave per quad by whoever blends the other tiles)
+    const uint32_t count = 4u * ((const_u32p)n_total)[2], threshold = max(((const_u32p)n_total)[4], ((const_u32p)n_total)[8]);
     for (uint32_t item = worker; item < count; item += num_workers) {
         const uint32_t tile = ((const_u32p)large_tiles)[item >> 2], q = item & 3u;
         const v2u rg = ((const_u2p)ranges)[tile];

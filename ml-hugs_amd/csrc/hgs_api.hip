@@ -58,6 +58,7 @@ std::shared_ptr<const hgs::Switches> read_switches_from_env()
     s->bwd_waves_per_tile = e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0;
     e = getenv("HGS_K8_COOP");
     s->k8_coop = e ? atoi(e) : -1;
+    s->deep_min = std::max(0, num("HGS_DEEP_MIN"));
     e = getenv("HGS_FRAME_KIND");
     s->frame_kind = e && (e[0] == 's' || e[0] == 'd') ? e[0] : 0;
     return s;

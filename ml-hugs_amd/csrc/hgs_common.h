@@ -60,6 +60,10 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // ---- scratch layouts (single source of truth, also served by hgs_scratch_offset) ----
 constexpr int BIN_GROUP = 1024;           // most Gaussians per binning workgroup (one per thread)
 constexpr int BIN_LDS_TILES = 22 * 1024;  // largest tile count whose u32 array fits the 160 KB of LDS next to emit's 68 KB of staging
+// (round 6) ... and up to twice that many tiles -- 3840x2160: 32 400 -- the binning kernels keep their per-tile LDS counters in 16-bit
+// halves (a group holds at most 1 024 Gaussians, each at most once per tile: binning_walk.h TileHist); emit then adds its counter to the
+// segment start + run start it fetches per pair.  Until round 6 such frames counted and emitted on global atomics (a 4K frame: 102 us).
+constexpr int BIN_LDS16_TILES = 44 * 1024;
 inline int num_tiles_of(int H, int W) { return ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE); }
 // Binning cells: BIN_CELL x BIN_CELL tiles.  On large frames the Gaussians are counting-sorted by the cell of their
 // rectangle's first tile, and the binning groups are runs of that order -- neighbours on screen (binning.hip).
@@ -103,7 +107,7 @@ inline int bin_mode_for(int P, int num_tiles, int num_cells, int group, int none
 // global-atomics fallback kernels.
 inline int bin_group_for(int P, int num_tiles)
 {
-    if (num_tiles > BIN_LDS_TILES) return 0;
+    if (num_tiles > BIN_LDS16_TILES) return 0;
     // ~250 groups per "round" of the 256 CUs, and whole rounds: 300 000 Gaussians are 469 groups of 640 (two rounds),
     // not 293 of 1024 (one round and a nearly empty second one that takes just as long)
     const long long rounds = ((long long)P + 250 * BIN_GROUP - 1) / (250 * BIN_GROUP);
@@ -231,6 +235,7 @@ struct Switches {
     bool fused_sort_blend;      // HGS_FUSED_SORT_BLEND=0: separate tile-sort and forward-blend kernels
     int bwd_waves_per_tile;     // HGS_BWD_WAVES_PER_TILE: 0 = by the frame's kind, 1 / 4 = forced (frames without checkpoints)
     int k8_coop;                // HGS_K8_COOP: -1 = default, else coop_mode of the per-Gaussian backward
+    int deep_min;               // HGS_DEEP_MIN: long tiles are blended split by depth only beyond this many entries (0: every long tile)
     int frame_kind;             // HGS_FRAME_KIND: 0 = the scan's rule, 's' = every frame sparse, 'd' = every frame dense (tools/shape_scan.py)
 };
 const Switches& switches();

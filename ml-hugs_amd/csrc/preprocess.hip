@@ -179,7 +179,8 @@ struct FirstAdds {
 // (a plain store where nothing is added: v + 0.0f would turn a -0.0f into +0.0f)
 __device__ __forceinline__ float plus(float v, const float* other, size_t idx) { return other ? v + other[idx] : v; }
 
-template <int MODE, bool STAGE = false>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256; STAGE: at most SH_STAGE_THREADS
+// H16 (BIN_IN_ORDER on frames beyond BIN_LDS_TILES tiles): the per-tile LDS counters are 16-bit halves (binning_walk.h, TileHist)
+template <int MODE, bool STAGE = false, bool H16 = false>  // blockDim.x = bin_group_for() (<= 1024, ~250 workgroups) unless BIN_NONE: 256; STAGE: at most SH_STAGE_THREADS
 __global__ void __launch_bounds__(STAGE ? SH_STAGE_THREADS : MODE != BIN_NONE ? BIN_GROUP : 256)
 preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                   const float* __restrict__ colors_precomp_, const float* __restrict__ opacities_,
@@ -222,7 +223,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         }
     }
     if (MODE != BIN_NONE)
-        for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells + 1 : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
+        for (int c = threadIdx.x; c < (MODE == BIN_BY_CELL ? num_cells + 1 : H16 ? (num_tiles + 1) / 2 : num_tiles); c += NT) bin_lds[c] = 0;  // visible after the barrier below
     // Housekeeping that would otherwise be another launch: when the caller will run backward, its [P,12] gradient
     // accumulator is zeroed here, fully coalesced.
     if (zero_accum) {
@@ -389,12 +390,12 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
         if (i < P) cell_slot[i] = cell >= 0 ? make_uint2((uint32_t)cell, base[cell] + rank) : make_uint2(0xFFFFFFFFu, 0u);
     }
     if (MODE == BIN_IN_ORDER) {
-        uint32_t* hist = bin_lds;
+        const TileHist<H16> hist{bin_lds};
         SplatRect mine;
         mine.x = mine.y = 0.f, mine.A = mine.C = -1.f, mine.B = 0.f, mine.thr = 0.f, mine.depth_bits = 0;
         mine.minx = rect_minx, mine.miny = rect_miny, mine.width = rect_width, mine.cnt = touched;
         __syncthreads();  // hist zeroed
-        for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { atomicAdd(&hist[ty * cam.gx + tx], 1u); });
+        for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { hist.add(ty * cam.gx + tx); });
         __syncthreads();
         // sixteen tiles per thread and round: the returning atomics of a round are all in flight together (the SMPL template's
         // groups are ONE wave each: the 1 024 tiles of a 512x512 frame are one round trip, not two)
@@ -405,7 +406,7 @@ preprocess_kernel(int P, Camera cam, const float* __restrict__ means3D_, const f
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u * NT;
-                c[u] = t < num_tiles ? hist[t] : 0u;
+                c[u] = t < num_tiles ? hist.get(t) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) base[u] = c[u] ? atomicAdd(&counters[t0 + u * NT], c[u]) : 0u;
@@ -451,7 +452,13 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
         // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
         static const bool big_lds_ok = hipFuncSetAttribute((const void*)preprocess_kernel<BIN_IN_ORDER, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                            160 * 1024) == hipSuccess;
-        if (wants_stage && group <= SH_STAGE_THREADS && staged_total <= (big_lds_ok ? 160 * 1024 : 64 * 1024))
+        if (cam.gx * cam.gy > BIN_LDS_TILES) {   // (16-bit counters; the SH staging is not combined with it)
+            if (hipFuncSetAttribute((const void*)preprocess_kernel<BIN_IN_ORDER, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)TileHist<true>::bytes(cam.gx * cam.gy)) != hipSuccess)
+                (void)hipGetLastError();
+            hipLaunchKernelGGL((preprocess_kernel<BIN_IN_ORDER, false, true>), dim3((P + group - 1) / group), dim3(group), TileHist<true>::bytes(cam.gx * cam.gy), st,
+                               HGS_K1_ARGS, counters, nullptr, run_start, (float4*)a.grad_accum_to_zero, big_per_group);
+        } else if (wants_stage && group <= SH_STAGE_THREADS && staged_total <= (big_lds_ok ? 160 * 1024 : 64 * 1024))
             hipLaunchKernelGGL((preprocess_kernel<BIN_IN_ORDER, true>), dim3((P + group - 1) / group), dim3(group), staged_total, st, HGS_K1_ARGS, counters, nullptr,
                                run_start, (float4*)a.grad_accum_to_zero, big_per_group);
         else

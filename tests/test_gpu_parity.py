@@ -898,22 +898,31 @@ def test_largest_frame_of_the_lds_binning_path(device):
     check_image(color.cpu().numpy(), ref["color"], "22k tiles")
 
 
-def test_more_tiles_than_fit_in_lds_use_the_global_atomics_path(device):
-    """A 4096 x 2304 image has 36 864 tiles: the binning kernels cannot keep a per-tile array in LDS and fall back
-    to direct global atomics; results must not change."""
+@pytest.mark.parametrize("size,mode", [((2304, 4096), "order"), ((2304, 4096), "cell"), ((2160, 3840), "by_size"), ((3072, 4096), "by_size")])
+def test_frames_beyond_the_32_bit_lds_counters(size, mode, device, monkeypatch):
+    """4096 x 2304 has 36 864 tiles, 3840 x 2160 has 32 400: more than fit LDS as 32-bit counters next to emit's staging (22 528).  Round 6:
+    up to 45 056 tiles the binning kernels keep 16-bit counters instead (a group holds at most 1 024 Gaussians: binning_walk.h TileHist) --
+    both kinds of binning groups, and a second frame that runs on the first one's hints; 4096 x 3072 = 49 152 tiles still falls back to
+    direct global atomics.  Results must not change."""
     from diff_gaussian_rasterization import _debug_forward_state
-    sc = make_scene(P=3000, H=2304, W=4096, seed=50, D=2, sigma_px=20.0, with_culled=True)
+    if mode in ("order", "cell"):
+        monkeypatch.setenv("HGS_BIN_MODE", mode)
+        reload_switches()
+    H, W = size
+    # (the 4K frame holds enough Gaussians for the by-cell mode to be the library's own choice)
+    sc = make_scene(P=40_000 if size == (2160, 3840) else 3000, H=H, W=W, seed=50, D=2, sigma_px=20.0 if size != (2160, 3840) else 6.0, with_culled=True)
     sc["dL_dpix"] = None
     ref = ho.forward(oracle_inputs(sc))
     t = gpu_tensors(sc, device, grad=False)
-    color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
-                                            scales=t["scales"], rotations=t["rotations"])
-    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
-    assert st["N"] == ref["N"]
-    assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
-    assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
-    assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
-    check_image(color.cpu().numpy(), ref["color"], "36k tiles")
+    for frame in range(2):
+        color, radii, st = _debug_forward_state(t["means3D"], t["opacities"], gpu_settings(sc, device), shs=t["shs"],
+                                                scales=t["scales"], rotations=t["rotations"])
+        assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+        assert st["N"] == ref["N"]
+        assert np.array_equal(st["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+        assert np.array_equal(st["keys"].cpu().numpy().view(np.uint64), ref["keys"])
+        assert np.array_equal(st["values"].cpu().numpy().view(np.uint32), ref["values"])
+        check_image(color.cpu().numpy(), ref["color"], f"{(H // 16) * (W // 16)} tiles, frame {frame}")
 
 
 @pytest.mark.parametrize("binding", ["cpp", "ctypes"])
@@ -1500,7 +1509,7 @@ def test_trained_scene_profile_at_1080p(device):
 
 
 @pytest.mark.parametrize("mode", ["order", "cell"])
-@pytest.mark.parametrize("name", ["basic_d3", "big_splats", "deg1_ragged"])
+@pytest.mark.parametrize("name", ["basic_d3", "big_splats", "deg1_ragged", "two_chunks"])
 def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, mode, device, monkeypatch):
     """Round 5: a frame of few tiles that is enqueued before N is known has no tile scan kernel -- emit's workgroups prefix-sum the
     tile counts themselves and one extra workgroup of that launch writes ranges / N / flags (binning.hip, emit_scan_kernel).  Same N,
@@ -1511,7 +1520,8 @@ def test_tile_scan_folded_into_emit_equals_the_scan_kernel(name, mode, device, m
     _force_ctypes_binding(monkeypatch)      # (the hint is injected through the Python binding's hook)
     monkeypatch.setenv("HGS_BIN_MODE", mode)   # both kinds of binning groups: consecutive Gaussians, runs of the cell order
     reload_switches()
-    sc = make_scene(**CASES[name])
+    # ("two_chunks", round 6: a 2048x1152 frame -- 9 216 tiles, one tile row past what one chunk of the folded scan takes)
+    sc = make_scene(P=6000, H=1152, W=2048, seed=21, D=1, sigma_px=14.0) if name == "two_chunks" else make_scene(**CASES[name])
     t = gpu_tensors(sc, device, grad=False)
     kw = dict(shs=t["shs"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
     key = (torch.device(device).index or 0, sc["means3D"].shape[0], sc["H"], sc["W"])

@@ -67,6 +67,9 @@ VARIANTS = {
     "long_sparse_512_no_deep": ({"HGS_LONG_MIN_SPARSE": "512", "HGS_DEEP_FORWARD": "0"}, True),
     "long_sparse_1024_no_deep": ({"HGS_LONG_MIN_SPARSE": "1024", "HGS_DEEP_FORWARD": "0"}, True),
     "long_sparse_2048_no_deep": ({"HGS_LONG_MIN_SPARSE": "2048", "HGS_DEEP_FORWARD": "0"}, True),
+    "deep_min_1536": ({"HGS_DEEP_MIN": "1536"}, True),
+    "deep_min_2048": ({"HGS_DEEP_MIN": "2048"}, True),
+    "deep_min_3072": ({"HGS_DEEP_MIN": "3072"}, True),
     "long_dense_512": ({"HGS_LONG_MIN_DENSE": "512"}, True),
     "long_dense_768_no_deep": ({"HGS_LONG_MIN_DENSE": "768", "HGS_DEEP_FORWARD": "0"}, True),
     "long_dense_1024": ({"HGS_LONG_MIN_DENSE": "1024"}, True),

@@ -210,6 +210,40 @@ def host_cpu():
     return model, os.cpu_count() or 1
 
 
+def cgroup_cpu_stat(path="/sys/fs/cgroup/cpu.stat"):
+    """{nr_periods, nr_throttled, throttled_usec, usage_usec, ...} of the cgroup this process runs in (cgroup v2); {} if unreadable"""
+    try:
+        return {k: int(v) for k, v in (line.split() for line in open(path).read().splitlines() if len(line.split()) == 2)}
+    except (OSError, ValueError):
+        return {}
+
+
+def thread_cpu_seconds():
+    """{tid: (name, user + system CPU seconds)} of this process's threads (/proc/self/task)"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open(f"/proc/self/task/{tid}/stat").read()
+                name = raw[raw.index("(") + 1:raw.rindex(")")]
+                f = raw[raw.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
+def cgroup_cpu_max(path="/sys/fs/cgroup/cpu.max"):
+    try:
+        q, per = open(path).read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def measured_copy_peak(torch, device, nbytes=1 << 30, reps=10):
     """Device-to-device copy rates (read + write bytes / time) of this GPU, now -- the practical HBM ceiling next to the
     datasheet figure: (the library's float4-per-thread copy kernel -- the shape MI355X_MICROARCH.md measures 6.29 TB/s
@@ -250,6 +284,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.launcher_selftest:
         return launcher_selftest(args, rank, world)
+    # HGS_BENCH_CPUS_TOTAL=n: every rank's affinity is cut to the SAME n CPUs (the first n this process may use) before torch or the GPU
+    # runtime exist in it -- no wrapper process, no exec: how "8 ranks on half the box's CPU quota" is measured
+    cpus_total = int(os.environ.get("HGS_BENCH_CPUS_TOTAL", "0"))
+    if cpus_total > 0:
+        assert "torch" not in sys.modules
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:cpus_total])
 
     import torch
     import torch.distributed as dist
@@ -366,12 +406,19 @@ def main():
     torch.cuda.reset_peak_memory_stats(device)
     fence()
     wait0 = _lib.hgs_debug_stat(b"forward_wait_ns")
+    cpu0, cg0 = time.process_time(), cgroup_cpu_stat()   # (process-wide user + system CPU seconds: every thread of this rank)
+    thr0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         color, radii = step()
     host_issue_s = time.perf_counter() - t0   # (the loop without the final drain)
     fence()
     elapsed = time.perf_counter() - t0
+    cpu_seconds, cg1 = time.process_time() - cpu0, cgroup_cpu_stat()
+    thr1 = thread_cpu_seconds()
+    # which of rank 0's threads the CPU time went to (the main thread issues frames and waits for N; "pt_autograd_*" runs the backward node)
+    threads_cpu = sorted(((n, round(t - thr0.get(tid, (n, 0.0))[1], 3)) for tid, (n, t) in thr1.items()), key=lambda x: -x[1])
+    threads_cpu = [x for x in threads_cpu if x[1] >= 0.01][:8]
     # host busy per frame: the loop's wall time minus what the library spent waiting for N (the host's only idle time inside it)
     host_busy_us = (host_issue_s * 1e9 - (_lib.hgs_debug_stat(b"forward_wait_ns") - wait0)) / (args.steps * KF) * 1e-3
     peak_mem = torch.cuda.max_memory_allocated(device)
@@ -390,7 +437,8 @@ def main():
         from diff_gaussian_rasterization import _debug_forward_state
         N = _debug_forward_state(t["means3D"].detach(), t["opacities"].detach(), settings, shs=t["shs"].detach(),
                                  scales=t["scales"].detach(), rotations=t["rotations"].detach())[2]["N"]
-    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv), float(device.index), 1.0, KF * args.steps / own_elapsed]],
+    frames = sharding.gather_frame_metrics([rank], [[float(N), float(Pv), float(device.index), 1.0, KF * args.steps / own_elapsed, host_busy_us,
+                                                     cpu_seconds, float(len(os.sched_getaffinity(0)))]],
                                            world, device=coll_dev)
     copy_peak, torch_copy_peak = measured_copy_peak(torch, device) if rank == 0 else (None, None)
 
@@ -471,6 +519,16 @@ def main():
                         "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5),
                         "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
         "host_busy_us_per_frame": round(host_busy_us, 1),
+        # the host side of N ranks on one box (every rank's own figures; rank 0 reads the cgroup the ranks share): CPU seconds are process-wide
+        # user + system time over the timed region, `cores_busy` = their sum over the region's wall time -- against the cgroup's quota
+        "ranks_host": {"host_busy_us_per_frame": [round(float(x), 1) for x in frames[:, 5].tolist()],
+                       "cpu_seconds": [round(float(x), 4) for x in frames[:, 6].tolist()],
+                       "cores_busy": round(float(frames[:, 6].sum()) / elapsed, 3), "wall_seconds": round(elapsed, 4),
+                       "rank0_threads_cpu_seconds": threads_cpu,
+                       "affinity_cpus_per_rank": [int(x) for x in frames[:, 7].tolist()], "cpus_total_requested": cpus_total or None,
+                       "cgroup": {"cpu_max": cgroup_cpu_max(), "nr_periods": cg1.get("nr_periods", 0) - cg0.get("nr_periods", 0),
+                                  "nr_throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                                  "throttled_usec": cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)} if cg0 or cg1 else None},
         "memory": {"peak_allocated_MB": round(peak_mem / 2**20, 1), "checkpoint_buffer_MB": None if ckpt_bytes is None else round(ckpt_bytes / 2**20, 1),
                    "checkpoint_slots_used": ckpt_used},
         "pixel_splat_evals_per_s": round(256.0 * N * (1 if args.forward_only else 2) * fps / world, 1),

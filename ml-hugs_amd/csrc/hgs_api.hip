@@ -1,6 +1,7 @@
 // C ABI entry points (include/hgs_rasterizer.h): argument validation, scratch layout, stage sequencing.
 #include <atomic>
 #include <sched.h>
+#include <time.h>
 #include <chrono>
 #include <cstdarg>
 #include <cstdlib>
@@ -213,11 +214,28 @@ int expired()
     return fail(HGS_ERR_EXPIRED, "the deferred frame's result slot was reused by a later frame (more than %u forwards since): run it again", SLOT_RING);
 }
 
-// Spin until the slot carries this call's ticket.  Every so often ask the runtime about the stream: an error there
-// (a faulted kernel) or an idle stream without the ticket means N is never going to arrive.
-int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out, bool* long_out)
+// Wait until the slot carries this call's ticket.  Round 5 spun (a sched_yield now and then): N arrives 30-50 us after the frame's first
+// kernel STARTS, but on a GPU-bound frame loop that kernel waits behind the frame before -- the host sits here for 300 us of a 476 us
+// frame (C2) with nothing urgent to do, the whole frame being enqueued already -- and every rank of a box held a core doing so: two cores
+// per rank with the runtime's event thread (below), 15.6 of a 16-CPU quota at eight ranks.  Round 6: the shape's record remembers how long
+// its last waits were (FrameHistory::wait_ns); a wait expected to last SLEEP_FROM_NS and more is slept through in one nanosleep that ends
+// WAKE_EARLY_NS before the expected arrival (timer slack and wake-up latency are ~60 us), then spun; shorter waits -- the human-only
+// renders, 110-150 us a frame -- spin as before (20 us naps there cost C3 11 %).  A wait that outlasts its expectation by 1 ms goes on in
+// 20 us naps.  HGS_WAIT_SLEEP=0: spin only.
+// Every ~20 ms the runtime is asked about the stream: an error there (a faulted kernel) or an idle stream without the ticket means N is
+// never going to arrive.  (Round 5 asked every 16 384 probes -- once or twice per frame -- and every hipStreamQuery leaves a marker whose
+// completion the runtime's event thread handles: that thread ran at 40-75 % of a core.)
+constexpr uint64_t SLEEP_FROM_NS = 300000ull, WAKE_EARLY_NS = 200000ull;
+int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* sparse_out, bool* long_out, int64_t expected_ns = 0, uint64_t* waited_ns = nullptr)
 {
-    struct WaitTime { uint64_t t0 = now_ns(); ~WaitTime() { g_stat_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed); } } wt;
+    struct WaitTime {
+        uint64_t t0 = now_ns(); uint64_t* out;
+        ~WaitTime() { const uint64_t d = now_ns() - t0; g_stat_wait_ns.fetch_add(d, std::memory_order_relaxed); if (out) *out = d; }
+    } wt;
+    wt.out = waited_ns;
+    static const bool may_sleep = [] { const char* e = getenv("HGS_WAIT_SLEEP"); return !(e && e[0] == '0'); }();
+    uint64_t next_query = wt.t0 + 20000000ull;
+    bool slept = false, napping = false;
     for (unsigned spins = 1;; ++spins) {
         const unsigned long long v = *hs.word;
         const int state = slot_state(v, hs.ticket);
@@ -226,24 +244,42 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
             return HGS_OK;
         }
         if (state < 0) return expired();
-        if ((spins & 0x3FFF) == 0) {
-            const hipError_t q = hipStreamQuery(st);
-            if (q == hipSuccess) {
-                const unsigned long long v2 = *hs.word;
-                const int state2 = slot_state(v2, hs.ticket);
-                if (state2 > 0) {
-                    *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0, *long_out = ((v2 >> 62) & 1u) != 0;
-                    return HGS_OK;
+        if (napping || (spins & 0xFFu) == 0u) {   // (a clock read per nap, or per 256 probes while spinning)
+            const uint64_t now = now_ns(), waited = now - wt.t0;
+            if (now >= next_query) {
+                next_query = now + 20000000ull;
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    const unsigned long long v2 = *hs.word;
+                    const int state2 = slot_state(v2, hs.ticket);
+                    if (state2 > 0) {
+                        *n_out = (uint32_t)v2, *sparse_out = (v2 >> 63) != 0, *long_out = ((v2 >> 62) & 1u) != 0;
+                        return HGS_OK;
+                    }
+                    if (state2 < 0) return expired();
+                    return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
                 }
-                if (state2 < 0) return expired();
-                return fail(HGS_ERR_HIP, "stream went idle without publishing the number of rendered pairs");
+                if (q != hipErrorNotReady) return fail(HGS_ERR_HIP, "HIP error while waiting for tile_scan: %s", hipGetErrorString(q));
             }
-            if (q != hipErrorNotReady) return fail(HGS_ERR_HIP, "HIP error while waiting for tile_scan: %s", hipGetErrorString(q));
+            if (may_sleep && !slept && waited > 20000ull && expected_ns >= (int64_t)SLEEP_FROM_NS && waited + WAKE_EARLY_NS < (uint64_t)expected_ns) {
+                // (the first 20 us are spun: a GPU that was idle delivers N at once)
+                slept = true;
+                const uint64_t d = (uint64_t)expected_ns - WAKE_EARLY_NS - waited;
+                struct timespec ts = {(time_t)(d / 1000000000ull), (long)(d % 1000000000ull)};
+                nanosleep(&ts, nullptr);
+                continue;
+            }
+            // a wait far beyond what the shape's record (or, without one, a millisecond) allows: the GPU is busy with someone else's work
+            if (may_sleep && !napping && waited > (uint64_t)(expected_ns > 0 ? expected_ns : 0) + 1000000ull) napping = true;
         }
-        __builtin_ia32_pause();
-        // (a rank that shares its core -- more ranks than the cgroup's CPU quota leaves cores -- hands it on instead of burning the
-        //  time slice its GPU's scan kernel is waiting behind: after ~50 us of spinning, every 256th probe)
-        if (spins > 8192u && (spins & 0xFFu) == 0u) sched_yield();
+        if (napping) {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        } else {
+            __builtin_ia32_pause();
+            // (spin-only mode: a rank that shares its core hands it on now and then, as round 5 did)
+            if (!may_sleep && spins > 8192u && (spins & 0xFFu) == 0u) sched_yield();
+        }
     }
 }
 
@@ -384,9 +420,15 @@ FrameHistory history_get(const HistKey& k)
     const HistEntry& e = g_hist[hist_slot(k)];
     return e.k == k ? e.h : FrameHistory{};
 }
-void history_put(const HistKey& k, const HostSlot& hs)
+void history_put(const HistKey& k, const HostSlot& hs, uint64_t waited_ns = 0)
 {
     FrameHistory h;
+    {   // (how long the shape's frames wait for N: a running mean, 3 : 1; a deferred frame -- polled long after -- leaves it alone)
+        std::lock_guard<std::mutex> lk(g_hist_mu);
+        const HistEntry& e = g_hist[hist_slot(k)];
+        const int64_t before = e.k == k ? e.h.wait_ns : -1;
+        h.wait_ns = waited_ns == 0 ? before : before < 0 ? (int64_t)waited_ns : (3 * before + (int64_t)waited_ns) / 4;
+    }
     // (written by tile_scan_kernel before the word that carries the ticket)
     h.n_long = (int32_t)hs.word[1], h.n_huge = (int32_t)(hs.word[2] & 0xFFFFFFFFull), h.n_deep = (int32_t)(hs.word[2] >> 32);
     h.sparse = (int32_t)(hs.word[0] >> 63);
@@ -751,8 +793,9 @@ int64_t hgs_rasterize_forward(const hgs_forward_args* args, hgs_alloc_fn alloc, 
     uint32_t n32 = 0;
     bool sparse = false, has_long = false;
     if (a.before_wait) a.before_wait(a.before_wait_ctx);   // (the caller's N-independent host work, under the GPU's way to N)
-    if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long)) return rc;
-    history_put(hkey, slot);
+    uint64_t waited_ns = 0;
+    if (int rc = wait_for_slot(slot, st, &n32, &sparse, &has_long, enqueued ? hist.wait_ns : 0, &waited_ns)) return rc;
+    history_put(hkey, slot, enqueued ? std::max<uint64_t>(waited_ns, 1) : 0);   // (only the waits of frames that were enqueued ahead are of the kind the record predicts)
     hist = history_get(hkey);
     if (n32 == 0xFFFFFFFFu) return too_many_pairs();  // (every kernel behind the scan was gated off)
     const int64_t N = (int64_t)n32;

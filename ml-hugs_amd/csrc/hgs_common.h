@@ -284,6 +284,7 @@ struct FrameHistory {   // -1: unknown
     int32_t n_deep = -1, sparse = -1;   // lists beyond 2 048 entries; whether the frame was sparse
     int32_t n_nonempty = -1;            // tiles with a list
     int32_t deep_blend = -1;            // whether its long tiles were blended split by depth (the scan's n_total[8], 0 without long tiles)
+    int64_t wait_ns = -1;               // how long the shape's frames waited for N lately (hgs_api.hip wait_for_slot sleeps through most of a long one)
     int32_t no_ckpt = -1;               // a sparse frame that left no checkpoints (CKPT_KIND_NONE): the next one is not given a buffer
 };
 void launch_tile_sort(const uint2* ranges, int num_tiles, const uint64_t* keys, uint64_t* list, uint64_t* scratch,

@@ -210,6 +210,16 @@ def host_cpu():
     return model, os.cpu_count() or 1
 
 
+def box_of_this_run():
+    """which machine: CPU model, quota, the GPU's unique id (rocm-smi, a child process), the host's boot id (tools/bench_common.py)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_common
+        return bench_common.box()
+    except Exception as e:   # (never the reason a bench line is lost)
+        return {"error": str(e)[:200]}
+
+
 def cgroup_cpu_stat(path="/sys/fs/cgroup/cpu.stat"):
     """{nr_periods, nr_throttled, throttled_usec, usage_usec, ...} of the cgroup this process runs in (cgroup v2); {} if unreadable"""
     try:
@@ -512,12 +522,13 @@ def main():
                      "avg_launch_note": "HIP events on the launch stream around the kernel, inside the timed region; the event pair "
                                         "itself adds ~1-2 % to the figure (rocprofv3's kernel trace in profiles/ is the event-free one)",
                      "note": "north_star's '>= 60 % of the HBM roofline' is structurally unreachable for the two blend kernels: "
-                             "they do ~256 pixel-splat evaluations per 40-byte list entry and are VALU-issue bound (see "
-                             "valu_issue.busy_frac) with HBM mostly idle; the per-Gaussian kernels (K1, K8) are the ones on the "
+                             "they do ~256 pixel-splat evaluations per 40-byte list entry and are VALU bound (see "
+                             "roofline_valu: pipes saturated at ~0.47 of peak issue, at the floor of their instruction mix) with HBM mostly idle; the per-Gaussian kernels (K1, K8) are the ones on the "
                              "HBM roofline (DESIGN.md section 4)"},
         "whole_frame": {"algorithmic_bytes": int(frame_B), "GB_per_s": round(frame_B * fps / world / 1e9, 2),
                         "frac_of_hbm_peak": round(frame_B * fps / world / 1e9 / HBM_PEAK_GBPS, 5),
                         "frac_of_measured_peak": round(frame_B * fps / world / 1e9 / copy_peak, 5)},
+        "box": box_of_this_run(),
         "host_busy_us_per_frame": round(host_busy_us, 1),
         # the host side of N ranks on one box (every rank's own figures; rank 0 reads the cgroup the ranks share): CPU seconds are process-wide
         # user + system time over the timed region, `cores_busy` = their sum over the region's wall time -- against the cgroup's quota
@@ -571,19 +582,38 @@ def main():
         else:
             out["roofline"]["traffic_note"] = (f"stale or other workload: profiles/{os.path.basename(f)} was taken on csrc "
                                                f"{pmc.get('csrc_sha16')}, this build is {here}")
+    # The bound that holds for the blend kernels is VALU, reported as a roofline of its own:
+    #   achieved_frac  = wave-instructions (PMC) x 2 cycles (the guide's issue rate: one wave64 VALU instruction per SIMD every 2 cycles)
+    #                    / (1 024 SIMDs x kernel cycles)
+    #   mix_floor_frac = wave-instructions x the measured cost of THIS kernel's instruction mix (profiles/*_valu_mix.json: static histogram
+    #                    of its hot loop x profiles/r2_valu_model.txt) / 1 024 SIMDs / kernel time: ~1 = the kernel sits on what its mix allows
+    #   valu_pipe_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles): the pipes never idle -- NOT a fraction of peak issue
+    # Attached only for the workload and the kernel sources the counters were taken on.
     f = newest("*_valu_utilization.json")
     if f:
         vu_all = json.load(open(f))
         vu = vu_all.get("kernels", {}).get(KERNEL_OF[dominant])
-        if vu and vu_all.get("csrc_sha16") == here:
-            out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": vu["valu_busy_frac"],
-                                 "wave_instructions_per_launch": vu["valu_wave_instructions"],
-                                 "source": "profiles/" + os.path.basename(f) + " (PMC: SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
-            if vu_all.get("note"):
-                out["valu_issue"]["note"] = vu_all["note"]
+        wl = vu_all.get("workload", {})
+        same_wl = (wl.get("gaussians"), wl.get("height"), wl.get("width"), wl.get("sh_degree")) == (P, H, W, D) and args.profile == wl.get("profile", "uniform")
+        if vu and vu_all.get("csrc_sha16") == here and same_wl:
+            instr, cycles = float(vu["valu_wave_instructions"]), float(vu["kernel_cycles"])
+            rv = {"bound": "valu", "kernel": KERNEL_OF[dominant], "wave_instructions_per_launch": instr, "kernel_cycles": cycles, "simds": 1024,
+                  "issue_peak": "one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md)",
+                  "achieved_frac": round(instr * 2.0 / (1024.0 * cycles), 4), "valu_pipe_busy_frac": vu["valu_busy_frac"],
+                  "source": "profiles/" + os.path.basename(f) + " (PMC: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE; separate rocprofv3 passes)"}
+            fm = newest("*_valu_mix.json")
+            if fm:
+                mix = json.load(open(fm))
+                mk = mix.get("kernels", {}).get(KERNEL_OF[dominant])
+                if mk and mix.get("csrc_sha16") == here:
+                    rv["mix_ns_per_instruction"] = mk["mix_ns_per_instruction"]
+                    rv["mix_floor_frac"] = round(instr * mk["mix_ns_per_instruction"] * 1e-9 / 1024.0 / (dom_ms * 1e-3), 4)
+                    rv["mix_source"] = "profiles/" + os.path.basename(fm) + f" ({mk['scope']}: " + ", ".join(f"{k} {v['share']:.0%}" for k, v in mk["classes"].items()) + ")"
+            out["roofline_valu"] = rv
         else:
-            out["valu_issue"] = {"kernel": KERNEL_OF[dominant], "busy_frac": None,
-                                 "note": f"stale: profiles/{os.path.basename(f)} was taken on csrc {vu_all.get('csrc_sha16')}, this build is {here}"}
+            out["roofline_valu"] = {"bound": "valu", "kernel": KERNEL_OF[dominant], "achieved_frac": None,
+                                    "note": f"profiles/{os.path.basename(f)} was taken on csrc {vu_all.get('csrc_sha16')} / workload {wl}; this build is {here}, "
+                                            f"this run {P} Gaussians {W}x{H} degree {D} profile {args.profile}"}
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, cam, dL, H, W, D, args.cpu_seconds, not args.forward_only)

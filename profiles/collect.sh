@@ -23,10 +23,11 @@ Wc=$(find "$OUT/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 profiles/pmc_traffic.py "$F" "$Wc" $TAG 200000 1080 1920 3 > "$OUT/${TAG}_pmc_traffic.json"
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_SQ_INSTS_VALU" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set1.txt"
 python3 profiles/pmc_summary.py "$(find "$OUT/pmc_GRBM_GUI_ACTIVE" -name '*counter_collection.csv' | head -1)" blend sort emit count scatter preprocess scan > "$OUT/${TAG}_pmc_sq_set2.txt"
-python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_pmc_sq_set2.txt" > "$OUT/${TAG}_valu_utilization.json"
+python3 profiles/valu_utilization.py "$OUT/${TAG}_pmc_sq_set1.txt" "$OUT/${TAG}_pmc_sq_set2.txt" 200000 1080 1920 3 uniform > "$OUT/${TAG}_valu_utilization.json"
+python3 profiles/valu_mix.py > "$OUT/${TAG}_valu_mix.json" 2> "$OUT/valu_mix.err"   # (static: hipcc -S of the running sources)
 # the bench line LAST, with this build's own PMC summaries in place (bench.py attaches traffic / VALU figures only from
 # summaries whose recorded source hash is the running build's)
-cp "$OUT/${TAG}_pmc_traffic.json" "$OUT/${TAG}_valu_utilization.json" "$ROOT/profiles/"
+cp "$OUT/${TAG}_pmc_traffic.json" "$OUT/${TAG}_valu_utilization.json" "$OUT/${TAG}_valu_mix.json" "$ROOT/profiles/"
 python3 profiles/median_of.py 3 python3 bench.py --no-cpu-baseline --no-two-streams > "$OUT/${TAG}_bench_median_of_3.json" 2> "$OUT/bench3.err"   # (host noise: see median_of.py)
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 find "$OUT" -name "*_agent_info.csv" -delete; find "$OUT" -name "*_kernel_trace.csv" -delete

@@ -10,9 +10,15 @@ import torch
 import diff_gaussian_rasterization as dgr
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md
-KERNEL_OF = {"blend_backward": "blend_backward (segmented / one wave per tile / mixed)", "sort": "tile sort fused with the forward blend (+ long-tile sorts)",
-             "preprocess": "preprocess_kernel", "preprocess_backward": "preprocess_backward_kernel", "scan": "tile_scan_kernel (+ cell scatter / group count)",
-             "emit_keys": "emit_kernel", "blend_forward": "blend_forward_kernel"}
+KERNEL_OF = {"sort": "tile_sort_small_kernel", "preprocess": "preprocess_kernel", "preprocess_backward": "preprocess_backward_kernel",
+             "scan": "tile_scan_kernel", "emit_keys": "emit_scan_kernel", "blend_forward": "blend_forward_kernel"}
+
+
+def backward_kernel(sparse, with_checkpoints):
+    """the kernel of the blend-backward stage by the frame's kind (blend.hip, launch_blend_backward): the name the rocprofv3 summaries carry"""
+    if with_checkpoints:
+        return "blend_backward_segmented_kernel" if sparse else "blend_backward_mixed_kernel"
+    return "blend_backward_kernel"   # (<1>: one wave per quad on a sparse frame, <4>: one wave per tile)
 
 
 def last_frame():
@@ -62,10 +68,35 @@ def roofline(stages_ms, P, Pv, N, H, W, D):
     b = stage_bytes(P, Pv, N, S, T, K)
     dom = max((k for k in stages_ms if k in b), key=lambda k: stages_ms[k])
     gbps = b[dom] / (stages_ms[dom] * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": KERNEL_OF[dom], "stage": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(gbps / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": int(b[dom]), "avg_launch_ms": stages_ms[dom], "traffic": None,
+    kernel = KERNEL_OF.get(dom)
+    if dom == "blend_backward":
+        cpp = dgr._load_cpp()
+        _n, _cap, _long, sparse = last_frame()
+        kernel = backward_kernel(bool(sparse), bool(cpp is not None and cpp.last_ckpt_info()[0] > 0))
+    return {"bound": "hbm", "kernel": kernel, "stage": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": int(b[dom]), "avg_launch_ms": stages_ms[dom],
+            "traffic": None,   # (profiles/collect_workload.sh fills it in from its FETCH_SIZE / WRITE_SIZE passes of this workload)
             "note": "HIP events around every stage in a separate pass (each pair adds a few microseconds); the blend kernels are VALU / "
                     "latency bound, not HBM bound (DESIGN.md section 4)"}
+
+
+_gpu_id = []
+
+
+def gpu_unique_id():
+    """'5ac0998dea87fceb' -- the visible GPU's unique id as rocm-smi reports it, or None"""
+    if not _gpu_id:
+        uid = None
+        try:
+            import re
+            import subprocess
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"Unique ID:\s*0x([0-9a-fA-F]+)", out)
+            uid = m.group(1).lower() if m else None
+        except Exception:
+            pass
+        _gpu_id.append(uid)
+    return _gpu_id[0]
 
 
 def box():
@@ -83,17 +114,10 @@ def box():
         quota = None if q == "max" else round(int(q) / int(per), 1)
     except (OSError, ValueError):
         pass
-    # which machine: the GPU's unique id from the KFD topology and the host's boot id (the boxes share one container hostname)
-    gpu_id, boot = None, None
-    try:
-        import glob
-        for props in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
-            kv = dict(line.split(None, 1) for line in open(props).read().splitlines() if " " in line)
-            if int(kv.get("simd_count", "0")) > 0 and kv.get("unique_id", "0") != "0":
-                gpu_id = "%x" % int(kv["unique_id"])
-                break
-    except (OSError, ValueError):
-        pass
+    # which machine: the GPU's unique id (= its ASIC serial) and the host's boot id (the boxes share one container hostname).  The id comes from
+    # `rocm-smi --showuniqueid` -- a child process, no GPU runtime in this one; the KFD topology in sysfs is not readable for the GPUs of the
+    # host that this container was not given, and lists all of them (round 5 recorded null on every box)
+    gpu_id, boot = gpu_unique_id(), None
     try:
         boot = open("/proc/sys/kernel/random/boot_id").read().strip()[:8]
     except OSError:

@@ -465,17 +465,35 @@ def main():
     # latency-bound binning with another's VALU-bound blending.  `value` above stays the serial number.
     fps_two_streams = None
     if world == 1 and not args.forward_only and not args.no_two_streams:
+        # Every stream renders its OWN copy of the leaves, made on that stream: autograd creates a leaf's AccumulateGrad node on the stream
+        # that is current when the leaf first enters a graph, and warns when a backward then runs on another one (round 5's leg shared the
+        # default stream's leaves between the two side streams: the warning was in every driver run).
         side = [torch.cuda.Stream(device) for _ in range(2)]
+        side_leaves = []
         for st_ in side:
             st_.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(st_):
+                tt = {k: v.detach().clone().requires_grad_(True) for k, v in t.items()}
+                side_leaves.append((tt, torch.zeros(P, 3, device=device, requires_grad=True)))
+
+        def step_on(k):
+            tt, m2 = side_leaves[k]
+            with torch.cuda.stream(side[k]):
+                for st2 in all_settings:
+                    color2, _ = GaussianRasterizer(raster_settings=st2)(means3D=tt["means3D"], means2D=m2, opacities=tt["opacities"], shs=tt["shs"],
+                                                                      scales=tt["scales"], rotations=tt["rotations"])
+                    color2.backward(dLd)
+                    for x in list(tt.values()) + [m2]:
+                        x.grad = None
+
+        for st_ in side:
+            st_.wait_stream(torch.cuda.current_stream(device))   # (dLd and the settings' tensors were made on the caller's stream)
         for k in range(20):
-            with torch.cuda.stream(side[k & 1]):
-                step()
+            step_on(k & 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            with torch.cuda.stream(side[k & 1]):
-                step()
+            step_on(k & 1)
         torch.cuda.synchronize()
         fps_two_streams = args.steps / (time.perf_counter() - t0)
 
@@ -552,9 +570,16 @@ def main():
                             for name, b in (("preprocess", P * (44 + 12 * K) + 8 * P + 67 * Pv),
                                             ("preprocess_backward", Pv * (111 + 12 * K) + P * (40 + 12 * 16)))
                             if stages.get(name) and not (args.forward_only and name == "preprocess_backward")},
+        "stage_rooflines_note": "preprocess also zeroes the backward's [P,12] gradient accumulator (48 B per Gaussian, fused into K1 instead of a memset "
+                                "launch): SURVEY 8d's K1 bytes do not count it -- `with_accumulator_zeroing` does (the WRITE_SIZE counter sees it: 1.9x the 8d writes)",
         "stages_ms_note": "separate untimed pass with an event pair around EVERY stage: each pair costs a few microseconds of GPU "
                           "time, so the sum exceeds ms_per_step",
     }
+    if "preprocess" in out["stage_rooflines"] and not args.forward_only:
+        b = P * (44 + 12 * K) + 8 * P + 67 * Pv + 48 * P
+        gb = b / (stages["preprocess"] * 1e-3) / 1e9
+        out["stage_rooflines"]["preprocess"]["with_accumulator_zeroing"] = {"bytes": int(b), "GB_per_s": round(gb, 1), "frac_of_hbm_peak": round(gb / HBM_PEAK_GBPS, 4),
+                                                                            "frac_of_measured": round(gb / copy_peak, 4)}
     if fps_two_streams is not None:
         out["two_frames_in_flight"] = {"value": round(fps_two_streams, 2), "unit": "frames/s",
                                        "note": "same workload, frames alternate between two HIP streams of one process"}

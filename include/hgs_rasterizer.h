@@ -134,7 +134,7 @@ typedef struct hgs_forward_args {
      * [0, 1] -- exactly `torch.clamp(rendered_image, 0.0, 1.0)` of /root/reference/hugs/renderer/gs_renderer.py:153 and
      * its autograd backward, without the five elementwise passes over the image they cost. */
     int32_t clamp_output;
-    /* !=0: the caller expects no long tile -- a list the scan kernel calls long: on a dense frame more than 768 entries when the frame holds one beyond 2048 (else none), on a sparse frame more than 256 when its lists are deep on average, else more than 1024 -- (its previous frame of this shape had none, see
+    /* !=0: the caller expects no long tile -- a list the scan kernel calls LONG: see the generated table "path selection" at the end of this header -- (its previous frame of this shape had none, see
      * hgs_forward_state.has_long_tiles): the long-tile sort kernel is then not launched with the optimistically enqueued
      * frame.  A wrong guess costs that launch plus a second forward blend; results are identical either way. */
     int32_t expect_no_long_tiles;
@@ -443,6 +443,36 @@ int64_t hgs_debug_stat(const char *name);
 /* The library reads its A/B switches (HGS_BIN_MODE, HGS_BWD_TWO_LAUNCHES, HGS_DEEP_FORWARD, HGS_LONG_MIN_SPARSE, HGS_LONG_MIN_DENSE, HGS_EMIT_SCAN, HGS_K1_STAGE_SH, HGS_BIG_PER_GROUP)
  * from the environment once, at its first frame; a test or A/B tool that changes them inside one process calls this afterwards. */
 void hgs_reload_switches(void);
+
+/* How the library chooses its path for a frame.  Every decision is taken from the frame's own numbers (non-empty tiles, list lengths) or,
+ * where the host has to decide before the first kernel, from the record of the shape's last frame -- which only ever sizes launches and
+ * buffers or picks between two forms with identical results (gradients: up to fp32 summation order).  Images, radii and lists never depend on
+ * history.  The numbers below are read out of the kernels' sources:
+ *
+ * BEGIN GENERATED: path selection (tools/gen_thresholds.py: do not edit by hand)
+ * - frame kind: DENSE (one backward wave per tile) or SPARSE (a wave per 8x8 quad; from the forward's checkpoints: per 32-entry segment):
+ *     n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= 4 096: dense unless E > 760.  1 536 <= n < 4 096: dense while E <= min(1 200, 0.45 (n - 800)) -- up to 1 600 on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < 1 536: sparse
+ *     [DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)]
+ * - checkpoints for the depth-segmented backward (when the caller offers a buffer):
+ *     sparse frame: every tile -- none when n >= 4 096 and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= 512 entries, and only when the shape's last frame held a list beyond 2 048 entries (host, from the shape's record)
+ *     [CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = 32 entries per segment (hgs_common.h)]
+ * - LONG lists (sorted ahead of the fused kernel by the long tiles' kernels):
+ *     sparse frame: beyond 256 entries when mean >= 200 and 16 .. 512 lists are that long; else beyond 1 024 when 16 .. 512 lists are; with more than 512 lists beyond 1 024: beyond 1 024 if the longest list is <= 4 096 (flat), else beyond 2 048.  dense frame: beyond 768 when the frame holds a list beyond 2 048, else none
+ *     [LONG_MIN_SPARSE, DEEP_MEAN_MIN, LONG_MIN_SPARSE_TILES, LONG_ONE_ROUND, LONG_MIN_SPARSE_SHALLOW, LONG_MIN_DENSE, SORT_CAP_SMALL, SORT_CAP_MID (binning.hip, tile_scan_body)]
+ * - long tiles blended split by depth (four waves per quad: the deep workers):
+ *     dense frames; sparse frames with mean >= 200 -- except more than 512 long lists none of which is beyond 4 096 entries (flat: one wave per quad)
+ *     [n_total[8] (binning.hip); HGS_DEEP_FORWARD=0 / HGS_DEEP_MIN override]
+ * - per-tile sort inside the fused kernel:
+ *     <= 256 entries: bitonic network in registers; <= 1 024: bucket sort in LDS; <= 2 048: bitonic network, eight keys per thread; long tiles' kernel: one workgroup per list of <= 4 096 entries, longer lists split by depth into parts of 3 072 .. 4 096
+ *     [SORT_CAP_SMALL, SORT_CAP_MID, PLAN_PART (binning.hip)]
+ * - binning groups (host, before the first kernel):
+ *     by screen cell (two more launches) when P >= 32 768, tiles >= 4 096, cells <= 2 048 and the shape's last frame covered at least half the tiles; else in storage order.  Per-tile LDS counters: 32-bit up to 22 528 tiles, 16-bit up to 45 056, global atomics beyond.  Splats of more than 256 tiles: groups of their own, 24 each
+ *     [bin_mode_for, BIN_LDS_TILES, BIN_LDS16_TILES, BIN_SPREAD_MIN, BIG_PER_GROUP (hgs_common.h)]
+ * - tile scan folded into the emit launch (host):
+ *     frames enqueued on a capacity guess with <= 8 192 x 2 tiles and <= 1 024 binning groups
+ *     [EMIT_SCAN_TILES, EMIT_SCAN_MAX_CHUNKS (binning.hip)]
+ * END GENERATED: path selection
+ */
 
 #ifdef __cplusplus
 }

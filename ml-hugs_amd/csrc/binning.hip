@@ -664,8 +664,29 @@ group_count_kernel(int P, int G, Camera cam, const Splat* __restrict__ splats, c
     // tile of window index k: row = k / ww exactly (k < 2^22, see emit) without an integer divide
     auto tile_of = [&](int k) { const int r = (int)(((float)k + 0.5f) * inv_ww); return (wy0 + r) * cam.gx + wx0 + (k - r * ww); };
     for (int k = tid; k < n_win; k += NT) hist.zero(tile_of(k));
+    // (round 6) a group of BIG splats (the padded groups behind the regular ones: at most B <= 64 members of 256 .. all tiles each) deals
+    // every member's tiles over the WHOLE workgroup, as emit does: walked by the wave that holds it, 64 tiles a step, a 8 160-tile splat was
+    // 128 steps of one wave while the other waves of the group had long finished theirs
+    __shared__ int4 big_rect[64];
+    __shared__ uint32_t n_big_members;
+    const bool dealt = tot.z != 0u && B != 0u && first >= tot.y && (first - tot.y) / (uint32_t)G < (uint32_t)BIG_GROUPS_CAP && B <= 64u;   // (uniform)
+    if (dealt && tid == 0) n_big_members = 0u;
     __syncthreads();
-    for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { hist.add(ty * cam.gx + tx); });
+    if (!dealt)
+        for_each_pair(mine, [&](int, int tx, int ty, const SplatRect&) { hist.add(ty * cam.gx + tx); });
+    else {
+        if (mine.cnt) big_rect[atomicAdd(&n_big_members, 1u)] = make_int4(mine.minx, mine.miny, mine.width, (int)mine.cnt);
+        __syncthreads();
+        const uint32_t members = n_big_members;
+        for (uint32_t m = 0; m < members; ++m) {
+            const int4 r = big_rect[m];
+            const float inv_w = 1.0f / (float)r.z;
+            for (int k = tid; k < r.w; k += NT) {
+                const int ry = (int)(((float)k + 0.5f) * inv_w);   // k / width, exactly (k < 2^22)
+                hist.add((r.y + ry) * cam.gx + r.x + (k - ry * r.z));
+            }
+        }
+    }
     __syncthreads();
     // eight tiles per thread and round: the returning atomics of a round are all in flight together
     uint32_t* my_runs = run_start + (size_t)grp * (size_t)(cam.gx * cam.gy);

@@ -102,13 +102,30 @@ template <int K>
 __device__ __forceinline__ void sh_backward_rows(const float (&B)[16], const float* sh, float* dsh,  // (sh may BE dsh: an LDS row)
                                                  float dr0, float dr1, float dr2, float (&shw)[16])
 {
-    float c[K][3];
+    // (round 6, measured and closed) all 48 coefficients of degree 3 in flight at once, next to the 16 basis values and the 16 dot products,
+    // are what holds the kernel at 128 VGPRs = four waves per SIMD.  Fetched eight (four) at a time -- -DHGS_K8_SH_CHUNK=8 -DHGS_K8_WAVES=5
+    // -- it fits 96 VGPRs with 8 (4) spilled and runs SLOWER: C2 29.5 -> 33-35 us, 1 M Gaussians 114 -> 128-132 us (six waves: 44 / 166 us).
+    // The kernel is a chain of dependent round trips; what hides them is the loads a THREAD has in flight, not a fifth wave
+    // (DESIGN_HISTORY.md, round 6).  16 = one pass.
+#ifndef HGS_K8_SH_CHUNK
+#define HGS_K8_SH_CHUNK 16
+#endif
+    constexpr int CH = HGS_K8_SH_CHUNK;
 #pragma unroll
-    for (int k = 0; k < K; ++k) c[k][0] = sh[3 * k], c[k][1] = sh[3 * k + 1], c[k][2] = sh[3 * k + 2];
+    for (int k0 = 0; k0 < K; k0 += CH) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        float c[CH][3];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        shw[k] = c[k][0] * dr0 + c[k][1] * dr1 + c[k][2] * dr2;
-        dsh[3 * k] = B[k] * dr0, dsh[3 * k + 1] = B[k] * dr1, dsh[3 * k + 2] = B[k] * dr2;
+        for (int k = 0; k < CH; ++k)
+            if (k0 + k < K) c[k][0] = sh[3 * (k0 + k)], c[k][1] = sh[3 * (k0 + k) + 1], c[k][2] = sh[3 * (k0 + k) + 2];
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k0 + k < K) {
+                shw[k0 + k] = c[k][0] * dr0 + c[k][1] * dr1 + c[k][2] * dr2;
+                dsh[3 * (k0 + k)] = B[k0 + k] * dr0, dsh[3 * (k0 + k) + 1] = B[k0 + k] * dr1, dsh[3 * (k0 + k) + 2] = B[k0 + k] * dr2;
+            }
+        if (k0 + CH < K) __builtin_amdgcn_sched_barrier(0);   // (the next chunk's loads stay behind this one's use)
     }
 #pragma unroll
     for (int k = K; k < 16; ++k) shw[k] = 0.0f;
@@ -483,8 +500,11 @@ void launch_preprocess(const hgs_forward_args& a, const Camera& cam, Splat* spla
 // are written as zeros straight from registers.  Waves whose rows are not one block of one array (M != 16, a wave that
 // straddles the two segments) keep the per-thread path.
 constexpr int SH_ROW_F4 = 12;  // float4 per row at M = 16
-template <bool ADD>   // ADD: the first set's gradients are added to another render's (FirstAdds); else this is round 4's kernel, instruction for instruction
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))   // (<= 128 VGPRs: four waves per SIMD hold 262 144 Gaussians at once)
+#ifndef HGS_K8_WAVES   // (A/B builds: tools/ab_build.sh name "-DHGS_K8_WAVES=5 -DHGS_K8_SH_CHUNK=8")
+#define HGS_K8_WAVES 4
+#endif
+template <bool ADD>   // ADD: the first set's gradients are added to another render's (FirstAdds)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_K8_WAVES)))   // (4: <= 128 VGPRs; 5: <= 96)
 preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_, const float* __restrict__ shs_,
                            const float* __restrict__ opacities_, const float* __restrict__ scales_, const float* __restrict__ rots_,
                            const float* __restrict__ cov3D_precomp_, SecondInputs in2, const float* __restrict__ V,
@@ -619,77 +639,9 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
     const uint32_t clamped = __float_as_uint(tail.w);
 
     const float x = in_x, y = in_y, z = in_z;
-    float pv[3];
-    pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
-    pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
-    pv[2] = V[2] * x + V[6] * y + V[10] * z + V[14];
-    float S[6];
-    if (cov3D_precomp) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) S[k] = in_S[k];
-    } else {
-        cov3d_from_scale_rot(in_sc, cam.mod, in_q, S);
-    }
-    Ewa e;
-    ewa_project(pv, cam, V, S, e);
-    const float a = e.a, b = e.b, c = e.c;
-    const float gxx = acc0.z, gxy = acc0.w, gyy = acc1.x;
-    const float denom = a * c - b * b;
-    const float d2inv = 1.0f / (denom * denom + 0.0000001f);
-    float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
-    float dS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (d2inv != 0.0f) {
-        dL_da = d2inv * (-c * c * gxx + 2.0f * b * c * gxy + (denom - a * c) * gyy);
-        dL_dc = d2inv * (-a * a * gyy + 2.0f * a * b * gxy + (denom - a * c) * gxx);
-        dL_db = d2inv * 2.0f * (b * c * gxx - (denom + 2.0f * b * b) * gxy + a * b * gyy);
-        dS[0] = e.T00 * e.T00 * dL_da + e.T00 * e.T10 * dL_db + e.T10 * e.T10 * dL_dc;
-        dS[3] = e.T01 * e.T01 * dL_da + e.T01 * e.T11 * dL_db + e.T11 * e.T11 * dL_dc;
-        dS[5] = e.T02 * e.T02 * dL_da + e.T02 * e.T12 * dL_db + e.T12 * e.T12 * dL_dc;
-        dS[1] = 2.0f * e.T00 * e.T01 * dL_da + (e.T00 * e.T11 + e.T01 * e.T10) * dL_db + 2.0f * e.T10 * e.T11 * dL_dc;
-        dS[2] = 2.0f * e.T00 * e.T02 * dL_da + (e.T00 * e.T12 + e.T02 * e.T10) * dL_db + 2.0f * e.T10 * e.T12 * dL_dc;
-        dS[4] = 2.0f * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2.0f * e.T11 * e.T12 * dL_dc;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = plus(dS[k], ad_cov3D, 6 * j + k);
-
-    // dL/dT (2x3) -> dL/dJ -> dL/dt (view-space mean), with the frustum-clamp masks (A.6 quirk 2)
-    float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
-    float u01 = S[1] * e.T00 + S[3] * e.T01 + S[4] * e.T02;
-    float u02 = S[2] * e.T00 + S[4] * e.T01 + S[5] * e.T02;
-    float u10 = S[0] * e.T10 + S[1] * e.T11 + S[2] * e.T12;
-    float u11 = S[1] * e.T10 + S[3] * e.T11 + S[4] * e.T12;
-    float u12 = S[2] * e.T10 + S[4] * e.T11 + S[5] * e.T12;
-    float dT00 = 2.0f * u00 * dL_da + u10 * dL_db, dT01 = 2.0f * u01 * dL_da + u11 * dL_db;
-    float dT02 = 2.0f * u02 * dL_da + u12 * dL_db;
-    float dT10 = 2.0f * u10 * dL_dc + u00 * dL_db, dT11 = 2.0f * u11 * dL_dc + u01 * dL_db;
-    float dT12 = 2.0f * u12 * dL_dc + u02 * dL_db;
-    float dJ00 = V[0] * dT00 + V[4] * dT01 + V[8] * dT02;
-    float dJ02 = V[2] * dT00 + V[6] * dT01 + V[10] * dT02;
-    float dJ11 = V[1] * dT10 + V[5] * dT11 + V[9] * dT12;
-    float dJ12 = V[2] * dT10 + V[6] * dT11 + V[10] * dT12;
-    float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-    float dtx = (e.x_in ? 1.0f : 0.0f) * (-cam.fx * tz2 * dJ02);
-    float dty = (e.y_in ? 1.0f : 0.0f) * (-cam.fy * tz2 * dJ12);
-    float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.0f * cam.fx * e.tx) * tz3 * dJ02 +
-                (2.0f * cam.fy * e.ty) * tz3 * dJ12;
-    float dm0 = V[0] * dtx + V[1] * dty + V[2] * dtz;
-    float dm1 = V[4] * dtx + V[5] * dty + V[6] * dtz;
-    float dm2 = V[8] * dtx + V[9] * dty + V[10] * dtz;
-
-    // mean2D (NDC-scaled) -> mean
-    {
-        float hx = F[0] * x + F[4] * y + F[8] * z + F[12];
-        float hy = F[1] * x + F[5] * y + F[9] * z + F[13];
-        float hw = F[3] * x + F[7] * y + F[11] * z + F[15];
-        float mw = 1.0f / (hw + 0.0000001f);
-        float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-        float g2x = acc0.x, g2y = acc0.y;
-        dm0 += (F[0] * mw - F[3] * mul1) * g2x + (F[1] * mw - F[3] * mul2) * g2y;
-        dm1 += (F[4] * mw - F[7] * mul1) * g2x + (F[5] * mw - F[7] * mul2) * g2y;
-        dm2 += (F[8] * mw - F[11] * mul1) * g2x + (F[9] * mw - F[11] * mul2) * g2y;
-    }
-
-    // SH backward
+    // SH backward first (round 6): its 48 coefficients, 16 basis values and 16 dot products are dead before the covariance chain's
+    // intermediates come alive (the register allocation did not change for it: the chunked fetch above is what moves it)
+    float sh_dm0 = 0.0f, sh_dm1 = 0.0f, sh_dm2 = 0.0f;
     if (shs) {
         float dr0 = (clamped & 1u) ? 0.0f : acc1.z;
         float dr1 = (clamped & 2u) ? 0.0f : acc1.w;
@@ -766,10 +718,82 @@ preprocess_backward_kernel(int P, Camera cam, const float* __restrict__ means3D_
 #undef SHW
         float s2 = vx * vx + vy * vy + vz * vz;
         float inv32 = 1.0f / sqrtf(s2 * s2 * s2);
-        dm0 += ((s2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
-        dm1 += (-vx * vy * ddx + (s2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
-        dm2 += (-vx * vz * ddx - vy * vz * ddy + (s2 - vz * vz) * ddz) * inv32;
+        sh_dm0 = ((s2 - vx * vx) * ddx - vy * vx * ddy - vz * vx * ddz) * inv32;
+        sh_dm1 = (-vx * vy * ddx + (s2 - vy * vy) * ddy - vz * vy * ddz) * inv32;
+        sh_dm2 = (-vx * vz * ddx - vy * vz * ddy + (s2 - vz * vz) * ddz) * inv32;
     }
+    float pv[3];
+    pv[0] = V[0] * x + V[4] * y + V[8] * z + V[12];
+    pv[1] = V[1] * x + V[5] * y + V[9] * z + V[13];
+    pv[2] = V[2] * x + V[6] * y + V[10] * z + V[14];
+    float S[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = in_S[k];
+    } else {
+        cov3d_from_scale_rot(in_sc, cam.mod, in_q, S);
+    }
+    Ewa e;
+    ewa_project(pv, cam, V, S, e);
+    const float a = e.a, b = e.b, c = e.c;
+    const float gxx = acc0.z, gxy = acc0.w, gyy = acc1.x;
+    const float denom = a * c - b * b;
+    const float d2inv = 1.0f / (denom * denom + 0.0000001f);
+    float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
+    float dS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (d2inv != 0.0f) {
+        dL_da = d2inv * (-c * c * gxx + 2.0f * b * c * gxy + (denom - a * c) * gyy);
+        dL_dc = d2inv * (-a * a * gyy + 2.0f * a * b * gxy + (denom - a * c) * gxx);
+        dL_db = d2inv * 2.0f * (b * c * gxx - (denom + 2.0f * b * b) * gxy + a * b * gyy);
+        dS[0] = e.T00 * e.T00 * dL_da + e.T00 * e.T10 * dL_db + e.T10 * e.T10 * dL_dc;
+        dS[3] = e.T01 * e.T01 * dL_da + e.T01 * e.T11 * dL_db + e.T11 * e.T11 * dL_dc;
+        dS[5] = e.T02 * e.T02 * dL_da + e.T02 * e.T12 * dL_db + e.T12 * e.T12 * dL_dc;
+        dS[1] = 2.0f * e.T00 * e.T01 * dL_da + (e.T00 * e.T11 + e.T01 * e.T10) * dL_db + 2.0f * e.T10 * e.T11 * dL_dc;
+        dS[2] = 2.0f * e.T00 * e.T02 * dL_da + (e.T00 * e.T12 + e.T02 * e.T10) * dL_db + 2.0f * e.T10 * e.T12 * dL_dc;
+        dS[4] = 2.0f * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2.0f * e.T11 * e.T12 * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * j + k] = plus(dS[k], ad_cov3D, 6 * j + k);
+
+    // dL/dT (2x3) -> dL/dJ -> dL/dt (view-space mean), with the frustum-clamp masks (A.6 quirk 2)
+    float u00 = S[0] * e.T00 + S[1] * e.T01 + S[2] * e.T02;
+    float u01 = S[1] * e.T00 + S[3] * e.T01 + S[4] * e.T02;
+    float u02 = S[2] * e.T00 + S[4] * e.T01 + S[5] * e.T02;
+    float u10 = S[0] * e.T10 + S[1] * e.T11 + S[2] * e.T12;
+    float u11 = S[1] * e.T10 + S[3] * e.T11 + S[4] * e.T12;
+    float u12 = S[2] * e.T10 + S[4] * e.T11 + S[5] * e.T12;
+    float dT00 = 2.0f * u00 * dL_da + u10 * dL_db, dT01 = 2.0f * u01 * dL_da + u11 * dL_db;
+    float dT02 = 2.0f * u02 * dL_da + u12 * dL_db;
+    float dT10 = 2.0f * u10 * dL_dc + u00 * dL_db, dT11 = 2.0f * u11 * dL_dc + u01 * dL_db;
+    float dT12 = 2.0f * u12 * dL_dc + u02 * dL_db;
+    float dJ00 = V[0] * dT00 + V[4] * dT01 + V[8] * dT02;
+    float dJ02 = V[2] * dT00 + V[6] * dT01 + V[10] * dT02;
+    float dJ11 = V[1] * dT10 + V[5] * dT11 + V[9] * dT12;
+    float dJ12 = V[2] * dT10 + V[6] * dT11 + V[10] * dT12;
+    float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dtx = (e.x_in ? 1.0f : 0.0f) * (-cam.fx * tz2 * dJ02);
+    float dty = (e.y_in ? 1.0f : 0.0f) * (-cam.fy * tz2 * dJ12);
+    float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.0f * cam.fx * e.tx) * tz3 * dJ02 +
+                (2.0f * cam.fy * e.ty) * tz3 * dJ12;
+    float dm0 = V[0] * dtx + V[1] * dty + V[2] * dtz;
+    float dm1 = V[4] * dtx + V[5] * dty + V[6] * dtz;
+    float dm2 = V[8] * dtx + V[9] * dty + V[10] * dtz;
+
+    // mean2D (NDC-scaled) -> mean
+    {
+        float hx = F[0] * x + F[4] * y + F[8] * z + F[12];
+        float hy = F[1] * x + F[5] * y + F[9] * z + F[13];
+        float hw = F[3] * x + F[7] * y + F[11] * z + F[15];
+        float mw = 1.0f / (hw + 0.0000001f);
+        float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+        float g2x = acc0.x, g2y = acc0.y;
+        dm0 += (F[0] * mw - F[3] * mul1) * g2x + (F[1] * mw - F[3] * mul2) * g2y;
+        dm1 += (F[4] * mw - F[7] * mul1) * g2x + (F[5] * mw - F[7] * mul2) * g2y;
+        dm2 += (F[8] * mw - F[11] * mul1) * g2x + (F[9] * mw - F[11] * mul2) * g2y;
+    }
+
+    // (the SH block ran first: its part of dL/dmean is added here, in the order it always was)
+    dm0 += sh_dm0, dm1 += sh_dm1, dm2 += sh_dm2;
     dL_dmeans3D[3 * j] = plus(dm0, ad_means3D, 3 * j);
     dL_dmeans3D[3 * j + 1] = plus(dm1, ad_means3D, 3 * j + 1);
     dL_dmeans3D[3 * j + 2] = plus(dm2, ad_means3D, 3 * j + 2);

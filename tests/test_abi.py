@@ -151,3 +151,13 @@ def test_widening_rows_reject_bad_arguments_through_the_c_abi():
     lib.hgs_knn_workspace.restype = C.c_size_t
     lib.hgs_knn_workspace.argtypes = [C.c_int32, C.c_int32]
     assert lib.hgs_knn_workspace(110_210, 6890) > 0 and lib.hgs_knn_workspace(1000, 6890) == 0 and lib.hgs_knn_workspace(10_000, 100) == 0
+
+
+def test_the_path_selection_tables_are_generated_from_the_sources():
+    """include/hgs_rasterizer.h and INTEGRATION.md carry ONE table of the library's thresholds, generated from the constants in
+    csrc/hgs_common.h and csrc/binning.hip (tools/gen_thresholds.py): a constant changed without regenerating fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_thresholds.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

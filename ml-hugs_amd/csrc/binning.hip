@@ -117,7 +117,7 @@ struct ScanArgs {
 // (tools/shape_scan.py, profiles/r6*_shape_scan*.json: 2 040 non-empty tiles: dense up to E ~ 580, 3 600: up to ~1 200; a covered
 // 1280x720 frame of 100 000 Gaussians, E = 445: 0.370 -> 0.339 ms; a trained one, E = 638: 0.489 -> 0.395), never under 1 536 tiles
 // (a 512x512 frame, any human-only render: the depth-segmented backward from the forward's checkpoints wins at every depth).
-constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760;
+constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340;
 __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigned long long total, unsigned long long sum_sq, uint32_t longest, uint32_t force_kind)
 {
     if (force_kind) return force_kind == 1u ? 1u : 0u;
@@ -125,7 +125,12 @@ __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigne
     // at 1080p and above (E = 851 .. 953), a 524 288-Gaussian person at 1080p (E = 1 376).  The wave that walks a whole tile goes as far back
     // as the LAST of its 256 pixels composited, a wave per quad as far as the last of its 64, and in deep lists most quads are done long
     // before their tile is: one wave per quad 8-16 % faster there, 10-45 % slower on every shallower frame of the scan (E <= 705).
-    if (n_nonempty >= DENSE_ALWAYS_TILES) return sum_sq > (unsigned long long)DENSE_ALWAYS_E_MAX * total ? 1u : 0u;
+    // (the bound rises towards fewer tiles -- + DENSE_ALWAYS_E_RISE from 8 192 tiles down to 4 096: a 1600x900 frame, 5 700 tiles, is 8-22 %
+    //  faster dense at E = 785 where 8 160 tiles break even)
+    if (n_nonempty >= DENSE_ALWAYS_TILES) {
+        const unsigned long long rise = n_nonempty < 2u * DENSE_ALWAYS_TILES ? (unsigned long long)(2u * DENSE_ALWAYS_TILES - n_nonempty) * DENSE_ALWAYS_E_RISE / DENSE_ALWAYS_TILES : 0ull;
+        return sum_sq > ((unsigned long long)DENSE_ALWAYS_E_MAX + rise) * total ? 1u : 0u;
+    }
     if (n_nonempty < DENSE_MIN_TILES) return 1u;
     unsigned long long e_max = min((unsigned long long)DENSE_E_MAX, (unsigned long long)(n_nonempty - DENSE_E_ORIGIN) * 9ull / 20ull);
     // (a FLAT frame -- its longest list within a quarter of E: a covered frame of uniform depth -- has no tile chain that outlasts the

@@ -210,7 +210,7 @@ def test_empty_input_gives_zero_image_not_background(device):
         means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
         rotations=t["rotations"])
     assert color.shape == (3, 32, 48) and radii.shape == (0,) and radii.dtype == torch.int32
-    assert float(color.abs().max()) == 0.0  # A.6 quirk 8: zeros, NOT the (white) background
+    assert float(color.detach().abs().max()) == 0.0  # A.6 quirk 8: zeros, NOT the (white) background
     color.sum().backward()
     assert t["means3D"].grad.shape == (0, 3)
 

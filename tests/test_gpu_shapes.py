@@ -34,10 +34,14 @@ def _frame(kind, H, W, P):
             cam = syn.camera_from_w2c(np.ascontiguousarray(cam["world_view_transform"].T), 0.4, 2.0 * math.atan(math.tan(0.2) * H / W), H, W)
         return cam, _human(P)
     cam = syn.pinhole_camera(H, W)
+    if kind == "human_z4":       # a person 4 units in front of a pinhole camera
+        g = _human(P, seed=7)
+        g["means3D"] = (g["means3D"] + np.array([0.0, 0.0, 4.0], np.float32)).astype(np.float32)
+        return cam, g
     if kind == "trained":
         Ph = min(110_210, P // 2)
         return cam, syn.trained_scene_gaussians(P - Ph, cam, seed=0, human=Ph)
-    return cam, syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+    return cam, syn.scene_gaussians(P, cam, seed=0, sigma_px=7.0 if kind == "uniform7" else 4.0)
 
 
 # name -> (kind, H, W, P, SH degree, what the scan must decide: sparse frame?, long lists?, checkpoint kind (0 deep tiles / 1 all / 2 none), blended by depth?)
@@ -49,12 +53,18 @@ FRAMES = {
     "covered_720p_shallow": ("uniform", 720, 1280, 30_000, 3, False, False, 0, None),
     # ... and with a person in it: dense, its deep tiles through the checkpointed walk (lists beyond 2 048 entries)
     "covered_720p_trained": ("trained", 720, 1280, 100_000, 0, False, True, 0, True),
-    # a person alone at the capture's size: 3 000 of 8 160 tiles, a heavy tail (E = 2.8 x the mean): sparse
-    "human_110210_at_1080p": ("human", 1080, 1920, 110_210, 0, True, True, 1, None),
+    # a person alone at the capture's size (the human-only render of a training step, tools/bench_c4.py's second frame): 3 064 of 8 160 tiles,
+    # a heavy tail (E = 855 = 2.8 x the mean): sparse, its lists from 1 024 entries on long
+    "human_110210_at_1080p": ("human_z4", 1080, 1920, 110_210, 0, True, True, 1, None),
+    # ... and filling most of a 1080p frame (the canonical rig's field of view): 5 254 tiles, E = 908 under the bound there (1 004): dense
+    "human_110210_filling_1080p": ("human", 1080, 1920, 110_210, 0, False, False, 0, None),
     # more lists beyond 1 024 entries than one round of the long tiles' kernel, all of them flat: long from 1 024 on, blended one wave per quad
     "flat_long_512": ("uniform", 512, 512, 300_000, 0, True, True, 1, False),
-    # 4 096 non-empty tiles, deep flat lists (E ~ 800 > 760): sparse WITHOUT checkpoints
-    "deep_covered_1024": ("uniform", 1024, 1024, 900_000, 0, True, False, 2, None),
+    # 6 144 non-empty tiles, deep flat lists (E ~ 1 100 > 930, the bound at that many tiles): sparse WITHOUT checkpoints; most lists beyond 1 024
+    # entries and none beyond 4 096: long, blended one wave per quad
+    "deep_covered_1536x1024": ("uniform7", 1024, 1536, 1_000_000, 0, True, True, 2, False),
+    # ... and 4 096 tiles at E ~ 840: under the bound there (1 100): dense
+    "covered_1024_dense": ("uniform", 1024, 1024, 900_000, 0, False, False, 0, None),
 }
 
 

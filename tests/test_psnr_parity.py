@@ -160,3 +160,13 @@ def test_fits_through_the_hip_path_end_at_the_psnr_of_the_same_fit_through_the_o
     assert min(n for _, n in hip) > P_MODEL * 0.5 and oracle_n != P_MODEL, f"the densification round did nothing: {report}"
     # the criterion: within 0.1 dB at the end; the HIP runs' own spread is the resolution it can be stated with
     assert abs(finals.mean() - oracle_curve[-1]) <= 0.1, report
+    # ... and no single run hides behind the mean: up to the densification round the fit is deterministic up to the order of the float
+    # atomics, so EVERY run's checkpoints there are within 0.1 dB of the oracle's; afterwards (one Gaussian more or less cloned moves the curve)
+    # every run stays within 0.25 dB of it, and the runs within 0.2 dB of each other
+    before = [k for k in range(len(oracle_curve)) if k * CHECK_EVERY <= DENSIFY_AT]
+    for c, _ in hip:
+        for k in before:
+            assert abs(c[k] - oracle_curve[k]) <= 0.1, f"checkpoint at step {k * CHECK_EVERY} (before the densification round): {report}"
+        for k in range(len(oracle_curve)):
+            assert abs(c[k] - oracle_curve[k]) <= 0.25, f"checkpoint at step {k * CHECK_EVERY}: {report}"
+    assert finals.max() - finals.min() <= 0.2, f"spread of the HIP runs: {report}"

@@ -210,8 +210,18 @@ def host_cpu():
     return model, os.cpu_count() or 1
 
 
+_box = []
+
+
 def box_of_this_run():
     """which machine: CPU model, quota, the GPU's unique id (rocm-smi, a child process), the host's boot id (tools/bench_common.py)"""
+    if _box:
+        return _box[0]
+    _box.append(_box_of_this_run())
+    return _box[0]
+
+
+def _box_of_this_run():
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_common
@@ -304,6 +314,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if rank == 0:
+        box_of_this_run()   # (asks rocm-smi for the GPU's id NOW: a child process, which must not be started once this process has touched the GPU)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # HGS_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (several

@@ -10,6 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_8ranks
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+# (the GPU's unique id, asked here -- no GPU process exists yet --: the python tools must not start rocm-smi once they have touched the GPU)
+export HGS_GPU_UNIQUE_ID=${HGS_GPU_UNIQUE_ID:-$(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | sed -n 's/.*Unique ID: *0x\([0-9a-fA-F]*\).*/\1/p' | head -1)}
 COMMON="--gaussians 300000 --steps 400 --warmup 30 --no-cpu-baseline --no-two-streams"
 python3 bench.py $COMMON > "$OUT/ranks1.json" 2> "$OUT/ranks1.err"
 for n in 2 4 8; do

@@ -8,6 +8,7 @@ set -u
 TAG=${1:?tag}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
+export HGS_GPU_UNIQUE_ID=${HGS_GPU_UNIQUE_ID:-$(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | sed -n 's/.*Unique ID: *0x\([0-9a-fA-F]*\).*/\1/p' | head -1)}
 bash profiles/collect.sh $TAG > /dev/null 2>&1
 bash profiles/collect_workload.sh ${TAG}_c3_110210 tools/bench_c3.py > /dev/null 2>&1
 bash profiles/collect_workload.sh ${TAG}_c3_6890 tools/bench_c3.py 6890 > /dev/null 2>&1

@@ -14,6 +14,17 @@ KERNEL_OF = {"sort": "tile_sort_small_kernel", "preprocess": "preprocess_kernel"
              "scan": "tile_scan_kernel", "emit_keys": "emit_scan_kernel", "blend_forward": "blend_forward_kernel"}
 
 
+def kernel_of(stage, sparse=None, with_checkpoints=None):
+    """the kernel of a stage as the rocprofv3 summaries name it; the blend backward's depends on the frame (last frame of this thread when not given)"""
+    if stage != "blend_backward":
+        return KERNEL_OF.get(stage)
+    if sparse is None:
+        cpp = dgr._load_cpp()
+        _n, _cap, _long, sparse = last_frame()
+        with_checkpoints = bool(cpp is not None and cpp.last_ckpt_info()[0] > 0)
+    return backward_kernel(bool(sparse), bool(with_checkpoints))
+
+
 def backward_kernel(sparse, with_checkpoints):
     """the kernel of the blend-backward stage by the frame's kind (blend.hip, launch_blend_backward): the name the rocprofv3 summaries carry"""
     if with_checkpoints:
@@ -68,11 +79,7 @@ def roofline(stages_ms, P, Pv, N, H, W, D):
     b = stage_bytes(P, Pv, N, S, T, K)
     dom = max((k for k in stages_ms if k in b), key=lambda k: stages_ms[k])
     gbps = b[dom] / (stages_ms[dom] * 1e-3) / 1e9
-    kernel = KERNEL_OF.get(dom)
-    if dom == "blend_backward":
-        cpp = dgr._load_cpp()
-        _n, _cap, _long, sparse = last_frame()
-        kernel = backward_kernel(bool(sparse), bool(cpp is not None and cpp.last_ckpt_info()[0] > 0))
+    kernel = kernel_of(dom)
     return {"bound": "hbm", "kernel": kernel, "stage": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(gbps / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": int(b[dom]), "avg_launch_ms": stages_ms[dom],
             "traffic": None,   # (profiles/collect_workload.sh fills it in from its FETCH_SIZE / WRITE_SIZE passes of this workload)
@@ -84,18 +91,23 @@ _gpu_id = []
 
 
 def gpu_unique_id():
-    """'5ac0998dea87fceb' -- the visible GPU's unique id as rocm-smi reports it, or None"""
+    """'5ac0998dea87fceb' -- the visible GPU's unique id, or None.  From the environment when the caller provides it (HGS_GPU_UNIQUE_ID: the
+    collection scripts ask `rocm-smi --showuniqueid` in the shell, before any GPU process exists); else from rocm-smi as a child process -- but ONLY
+    while this process has not touched the GPU: rocm-smi is a python script, starting it is an exec, and an exec out of a process that has initialised
+    the GPU runtime (torch.cuda.*, or rocprofv3's preloaded library) is what this pool's boxes refuse (round 6's first collection: ten refusals)."""
     if not _gpu_id:
-        uid = None
-        try:
-            import re
-            import subprocess
-            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
-            m = re.search(r"Unique ID:\s*0x([0-9a-fA-F]+)", out)
-            uid = m.group(1).lower() if m else None
-        except Exception:
-            pass
-        _gpu_id.append(uid)
+        uid = os.environ.get("HGS_GPU_UNIQUE_ID") or None
+        under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if uid is None and not torch.cuda.is_initialized() and not under_profiler:
+            try:
+                import re
+                import subprocess
+                out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+                m = re.search(r"Unique ID:\s*0x([0-9a-fA-F]+)", out)
+                uid = m.group(1).lower() if m else None
+            except Exception:
+                pass
+        _gpu_id.append(uid.lower().removeprefix("0x") if uid else None)
     return _gpu_id[0]
 
 

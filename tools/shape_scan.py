@@ -284,6 +284,7 @@ def main():
     if args.sizes == [(0, 0)]:
         args.sizes = []
     variants = ["default"] + [v for v in (args.variants.split(",") if args.variants else VARIANTS) if v != "default"]
+    bc.gpu_unique_id()   # (asked before this process touches the GPU: bench_common.py)
     dev = torch.device("cuda:0")
     pts = points(args)
     t_start = time.perf_counter()

@@ -90,6 +90,7 @@ constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at lea
 // after round, in front of its fused kernel: sort + forward 214 us against 107 with the threshold at 1 024; 20 000 Gaussians at
 // 540 x 960: 125 against 60 us (end of round 5, `HGS_LONG_MIN_SPARSE` sweep; C3's frames have 276 / 346 such lists and keep 256).
 constexpr uint32_t LONG_ONE_ROUND = 512;
+constexpr uint32_t DENSE_LONG_MANY = 832;   // a dense frame with more lists than this beyond long_min_dense takes LONG_MIN_SPARSE_SHALLOW (tile_scan_body)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
 constexpr uint32_t N_TOO_MANY = 0xFFFFFFF0u;  // pair counts from here on are reported as "too many" (32-bit list positions)
@@ -117,7 +118,7 @@ struct ScanArgs {
 // (tools/shape_scan.py, profiles/r6*_shape_scan*.json: 2 040 non-empty tiles: dense up to E ~ 580, 3 600: up to ~1 200; a covered
 // 1280x720 frame of 100 000 Gaussians, E = 445: 0.370 -> 0.339 ms; a trained one, E = 638: 0.489 -> 0.395), never under 1 536 tiles
 // (a 512x512 frame, any human-only render: the depth-segmented backward from the forward's checkpoints wins at every depth).
-constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340;
+constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340, DENSE_ALWAYS_TAIL = 3;
 __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigned long long total, unsigned long long sum_sq, uint32_t longest, uint32_t force_kind)
 {
     if (force_kind) return force_kind == 1u ? 1u : 0u;
@@ -127,9 +128,15 @@ __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigne
     // before their tile is: one wave per quad 8-16 % faster there, 10-45 % slower on every shallower frame of the scan (E <= 705).
     // (the bound rises towards fewer tiles -- + DENSE_ALWAYS_E_RISE from 8 192 tiles down to 4 096: a 1600x900 frame, 5 700 tiles, is 8-22 %
     //  faster dense at E = 785 where 8 160 tiles break even)
+    // ... and only where the depth is the FRAME's, not a tail's: E <= DENSE_ALWAYS_TAIL x the mean list.  A person on a body surface in
+    // front of a covered 1080p scene (tools/bench_step.py's joint render: mean 392, E = 2 141, 286 lists beyond 2 048 entries, the longest
+    // 10 751) is one wave per tile over 7 800 shallow lists plus the checkpointed walk of the few deep ones -- a dense frame with deep
+    // tiles, 16-21 % faster than a wave per quad everywhere (the person grid of the scan, E / mean 3.6 .. 21); the frames one wave per quad
+    // wins hold E / mean <= 2.4.
     if (n_nonempty >= DENSE_ALWAYS_TILES) {
         const unsigned long long rise = n_nonempty < 2u * DENSE_ALWAYS_TILES ? (unsigned long long)(2u * DENSE_ALWAYS_TILES - n_nonempty) * DENSE_ALWAYS_E_RISE / DENSE_ALWAYS_TILES : 0ull;
-        return sum_sq > ((unsigned long long)DENSE_ALWAYS_E_MAX + rise) * total ? 1u : 0u;
+        if (sum_sq <= ((unsigned long long)DENSE_ALWAYS_E_MAX + rise) * total) return 0u;
+        return (float)sum_sq * (float)n_nonempty <= (float)DENSE_ALWAYS_TAIL * (float)total * (float)total ? 1u : 0u;
     }
     if (n_nonempty < DENSE_MIN_TILES) return 1u;
     unsigned long long e_max = min((unsigned long long)DENSE_E_MAX, (unsigned long long)(n_nonempty - DENSE_E_ORIGIN) * 9ull / 20ull);
@@ -381,9 +388,13 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     // are merely long (C4's joint render: 1 900) is throughput-bound in that kernel, and the detour cost it 40 us (mid sort 27 + a
     // slower fused kernel, `profiles/r3j_c4_serial_timeline.txt` against round 4's first collection)
     const bool dense_long = very_deep != 0u || dense_unconditional != 0u;
-    const uint32_t dense_min = dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
+    // (round 6) ... and from LONG_MIN_SPARSE_SHALLOW on where more lists than DENSE_LONG_MANY lie beyond long_min_dense (a second round of
+    // the long tiles' kernel in front of the fused one): trained frames with 885 .. 1 262 such lists +0.5 .. 2.7 %, with 265 .. 694 of them
+    // -0.2 .. -5.4 %; a person in front of a 600 000-Gaussian scene at 1280x720 (mean list 838: most of 3 600 lists) sort + forward 283 -> 216 us
+    const bool dense_many = dense_long && !dense_unconditional && n_large_dense > DENSE_LONG_MANY && long_min_dense < (uint32_t)LONG_MIN_SPARSE_SHALLOW;
+    const uint32_t dense_min = dense_many ? (uint32_t)LONG_MIN_SPARSE_SHALLOW : dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
     const uint32_t threshold = use_sparse ? sparse_min : dense_min;
-    const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_long ? n_large_dense : 0u)) ? 1u : 0u;
+    const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_many ? n_large_shallow : dense_long ? n_large_dense : 0u)) ? 1u : 0u;
     const uint32_t deep_flag = ((!sparse || deep_lists) && !many_flat_long) ? 1u : 0u;
     // Which tiles leave checkpoints for the backward (hgs_common.h, CKPT_KIND_*): every tile of a sparse frame -- except (round 6) on a
     // sparse frame of 4 096 non-empty tiles and more WITHOUT a heavy tail (E < 1.6 x the mean list: the trained 2 097 152-Gaussian scenes):

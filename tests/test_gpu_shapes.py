@@ -38,6 +38,12 @@ def _frame(kind, H, W, P):
         g = _human(P, seed=7)
         g["means3D"] = (g["means3D"] + np.array([0.0, 0.0, 4.0], np.float32)).astype(np.float32)
         return cam, g
+    if kind.startswith("person"):   # a compact person (0.6 of the blob) 4 units in front of a covered scene: kind = "person<count of the person>"
+        Ph = int(kind[6:])
+        h, sc = _human(Ph, seed=7), syn.scene_gaussians(P - Ph, cam, seed=8, sigma_px=4.0)
+        h["means3D"] = (0.6 * h["means3D"] + np.array([0.0, 0.0, 4.0], np.float32)).astype(np.float32)
+        h["scales"] = (0.012 * h["scales"] / np.exp(np.mean(np.log(h["scales"])))).astype(np.float32)
+        return cam, {k: np.concatenate([h[k], sc[k]], 0) for k in h}
     if kind == "trained":
         Ph = min(110_210, P // 2)
         return cam, syn.trained_scene_gaussians(P - Ph, cam, seed=0, human=Ph)
@@ -65,7 +71,13 @@ FRAMES = {
     "deep_covered_1536x1024": ("uniform7", 1024, 1536, 1_000_000, 0, True, True, 2, False),
     # ... and 4 096 tiles at E ~ 840: under the bound there (1 100): dense
     "covered_1024_dense": ("uniform", 1024, 1024, 900_000, 0, False, False, 0, None),
+    # a covered frame with a heavy TAIL (tools/bench_step.py's joint render: 8 160 shallow lists and a person's few hundred deep ones, E several
+    # times the mean): dense -- one wave per tile, the deep tiles through the checkpointed walk -- whatever E is
+    "person_in_covered_1080p": ("person110210", 1080, 1920, 310_210, 0, False, True, 0, True),
+    # ... and at 1280x720 in front of 600 000 Gaussians (mean list ~800: most of the 3 600 lists lie beyond 768 entries): dense, long from 1 024 on
+    "person_in_dense_720p": ("person30000", 720, 1280, 630_000, 0, False, True, 0, True),
 }
+LONG_FROM = {"person_in_dense_720p": 1024, "covered_720p_trained": 768}   # n_total[4]: the frame's long-list threshold
 
 
 @pytest.mark.parametrize("name", list(FRAMES))
@@ -107,6 +119,8 @@ def test_frames_off_the_tracked_shapes(name, device):
     assert st["sparse_frame"] == want_sparse, f"{name}: sparse_frame = {st['sparse_frame']}"
     assert st["has_long_tiles"] == want_long, f"{name}: has_long_tiles = {st['has_long_tiles']}"
     assert int(nt[3]) == want_ckpt_kind, f"{name}: checkpoint kind {int(nt[3])}"
+    if name in LONG_FROM:
+        assert int(nt[4]) == LONG_FROM[name], f"{name}: lists are long from {int(nt[4])} entries on"
     if want_deep is not None:
         assert bool(nt[8]) == want_deep, f"{name}: long tiles blended by depth = {bool(nt[8])}"
     if want_ckpt_kind == 2:

@@ -119,9 +119,21 @@ def points(args):
         # (tools/bench_c4.py: the joint render and the human-only render at 1080p), the trained-scene profile, C3's two sizes
         out += [{"kind": "tracked_c2", "H": 1080, "W": 1920, "P": 200_000, "D": 3}, {"kind": "tracked_c4_joint", "H": 1080, "W": 1920, "P": 310_210, "D": 0},
                 {"kind": "tracked_c4_human", "H": 1080, "W": 1920, "P": 110_210, "D": 0}, {"kind": "tracked_trained", "H": 1080, "W": 1920, "P": 310_210, "D": 0},
-                {"kind": "human", "H": 512, "W": 512, "P": 110_210, "D": 0, "dist": 5.0}, {"kind": "human", "H": 512, "W": 512, "P": 6_890, "D": 0, "dist": 5.0}]
+                {"kind": "human", "H": 512, "W": 512, "P": 110_210, "D": 0, "dist": 5.0}, {"kind": "human", "H": 512, "W": 512, "P": 6_890, "D": 0, "dist": 5.0},
+                # the two renders of tools/bench_step.py (a body SURFACE of 110 210 splats of ~5 pixels, 4 units away: hundreds of lists beyond 2 048 entries)
+                {"kind": "tracked_step_joint", "H": 1080, "W": 1920, "P": 310_210, "D": 0}, {"kind": "tracked_step_human", "H": 1080, "W": 1920, "P": 110_210, "D": 0}]
+    if args.person_grid:
+        # a person on a body surface in front of a covered scene, nearer / farther and denser / sparser: the heavy-tailed frames between
+        # a scene render and a human-only one (the depth of the person's lists against the scene's mean)
+        for (H, W) in ((1080, 1920), (900, 1600), (720, 1280)):
+            for Ps in (200_000, 600_000):
+                for Ph in (30_000, 110_210, 300_000):
+                    for dist in (3.0, 4.0, 6.0, 9.0):
+                        out.append({"kind": "tracked_step_joint", "H": H, "W": W, "P": Ph + Ps, "D": 0, "Ph": Ph, "Ps": Ps, "dist": dist})
     if args.only:
         out = [p for p in out if args.only in p["kind"]]
+    if args.where:   # e.g. --where "H==720 and P==630000 and dist==4.0"
+        out = [p for p in out if eval(args.where, {}, dict({"dist": None, "Ph": None, "Ps": None}, **p))]
     return out
 
 
@@ -132,10 +144,24 @@ def build(pt, dev):
         if H != W:   # the same rig at the capture's aspect: fov of the longer side
             cam = syn.camera_from_w2c(np.ascontiguousarray(cam["world_view_transform"].T), 0.4, 2.0 * math.atan(math.tan(0.2) * H / W), H, W)
         g = human_gaussians(P)
+    elif pt["kind"].startswith("tracked_step"):
+        from bench_knn import body_surface
+        cam = syn.pinhole_camera(H, W)
+        r = np.random.default_rng(3)
+        Ph, Ps, dist = pt.get("Ph", 110_210), pt.get("Ps", 200_000), pt.get("dist", 4.0)
+        body_surface(6890, r)   # (tools/bench_step.py draws the template first: the same body)
+        canon = body_surface(Ph, r, noise=0.004) * 0.6
+        q = r.standard_normal((Ph, 4))
+        g = {"means3D": (canon + np.array([0.0, 0.0, dist])).astype(np.float32), "rotations": (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32),
+             "scales": (0.012 * np.exp(0.3 * r.standard_normal((Ph, 3)))).astype(np.float32), "shs": (0.3 * r.standard_normal((Ph, 16, 3))).astype(np.float32),
+             "opacities": r.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
+        if pt["kind"] == "tracked_step_joint":
+            sg = syn.scene_gaussians(Ps, cam, seed=8, sigma_px=4.0)
+            g = {k: np.concatenate([g[k], sg[k]], 0) for k in g}
     elif pt["kind"].startswith("tracked_c4"):
         cam = syn.pinhole_camera(H, W)
         rng = np.random.default_rng(7)
-        Ph, Ps = 110_210, 200_000
+        Ph, Ps, dist = pt.get("Ph", 110_210), pt.get("Ps", 200_000), pt.get("dist", 4.0)
         hm = {"means3D": (rng.standard_normal((Ph, 3)) * np.array([0.22, 0.55, 0.14]) + np.array([0, 0, 4.0])).astype(np.float32),
               "scales": (0.035 / math.sqrt(Ph / 6890.0) * np.exp(0.3 * rng.standard_normal((Ph, 3)))).astype(np.float32),
               "shs": (0.3 * rng.standard_normal((Ph, 16, 3))).astype(np.float32), "opacities": rng.uniform(0.05, 1.0, (Ph, 1)).astype(np.float32)}
@@ -271,6 +297,8 @@ def main():
     ap.add_argument("--warm", type=int, default=6)
     ap.add_argument("--budget-s", type=float, default=1e9, help="stop opening new points after this many seconds")
     ap.add_argument("--tracked", action="store_true", help="add the tracked workloads (C2, C4's two frames, the trained profile, C3) as points")
+    ap.add_argument("--person-grid", action="store_true", help="add a grid of person-in-front-of-a-scene frames (body surface, tools/bench_step.py's geometry)")
+    ap.add_argument("--where", default=None, help="a Python expression over a point's fields that selects points")
     ap.add_argument("--list-stats", action="store_true", help="record what the scan kernel sees of each frame (non-empty tiles, longest list, ...)")
     ap.add_argument("--stages-of", default="", help="comma-separated prefixes of forced alternatives whose per-stage times are recorded too")
     args = ap.parse_args()
@@ -301,7 +329,7 @@ def main():
             set_variant("default")
         rows.append(row)
         g = row.get("gain_of_best_forced")
-        print(f"[{k + 1}/{len(pts)}] {pt['kind']:8s} {pt['W']}x{pt['H']} P={pt['P']} D={pt['D']}" + (f" dist={pt['dist']}" if "dist" in pt else "") +
+        print(f"[{k + 1}/{len(pts)}] {pt['kind']:8s} {pt['W']}x{pt['H']} P={pt['P']} D={pt['D']}" + (f" dist={pt['dist']}" if "dist" in pt else "") + (f" Ph={pt['Ph']}" if "Ph" in pt else "") +
               (f": default {row['default_ms']:.4f} ms, best forced {row['best_forced']} {row['best_forced_ms']:.4f} ms ({100 * g:+.1f} %)"
                f" sparse={row['sparse_frame']} long={row['has_long_tiles']} N={row['num_rendered_N']}" if g is not None else f": {row.get('error')}"),
               file=sys.stderr, flush=True)

@@ -452,7 +452,7 @@ void hgs_reload_switches(void);
  * BEGIN GENERATED: path selection (tools/gen_thresholds.py: do not edit by hand)
  * - frame kind: DENSE (one backward wave per tile) or SPARSE (a wave per 8x8 quad; from the forward's checkpoints: per 32-entry segment):
  *     n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= 4 096: dense unless E > 760 (+ up to 340 more below 8 192 tiles, linearly: 760 + 340 at 4 096).  1 536 <= n < 4 096: dense while E <= min(1 200, 0.45 (n - 800)) -- up to 1 600 on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < 1 536: sparse
- *     [DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)]
+ *     [DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL_X10, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)]
  * - checkpoints for the depth-segmented backward (when the caller offers a buffer):
  *     sparse frame: every tile -- none when n >= 4 096 and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= 512 entries, and only when the shape's last frame held a list beyond 2 048 entries (host, from the shape's record)
  *     [CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = 32 entries per segment (hgs_common.h)]

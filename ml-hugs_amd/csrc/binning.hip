@@ -118,7 +118,7 @@ struct ScanArgs {
 // (tools/shape_scan.py, profiles/r6*_shape_scan*.json: 2 040 non-empty tiles: dense up to E ~ 580, 3 600: up to ~1 200; a covered
 // 1280x720 frame of 100 000 Gaussians, E = 445: 0.370 -> 0.339 ms; a trained one, E = 638: 0.489 -> 0.395), never under 1 536 tiles
 // (a 512x512 frame, any human-only render: the depth-segmented backward from the forward's checkpoints wins at every depth).
-constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340, DENSE_ALWAYS_TAIL = 3;
+constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340, DENSE_ALWAYS_TAIL_X10 = 26;
 __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigned long long total, unsigned long long sum_sq, uint32_t longest, uint32_t force_kind)
 {
     if (force_kind) return force_kind == 1u ? 1u : 0u;
@@ -128,15 +128,15 @@ __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigne
     // before their tile is: one wave per quad 8-16 % faster there, 10-45 % slower on every shallower frame of the scan (E <= 705).
     // (the bound rises towards fewer tiles -- + DENSE_ALWAYS_E_RISE from 8 192 tiles down to 4 096: a 1600x900 frame, 5 700 tiles, is 8-22 %
     //  faster dense at E = 785 where 8 160 tiles break even)
-    // ... and only where the depth is the FRAME's, not a tail's: E <= DENSE_ALWAYS_TAIL x the mean list.  A person on a body surface in
+    // ... and only where the depth is the FRAME's, not a tail's: E <= DENSE_ALWAYS_TAIL_X10 / 10 = 2.6 x the mean list.  A person on a body surface in
     // front of a covered 1080p scene (tools/bench_step.py's joint render: mean 392, E = 2 141, 286 lists beyond 2 048 entries, the longest
     // 10 751) is one wave per tile over 7 800 shallow lists plus the checkpointed walk of the few deep ones -- a dense frame with deep
-    // tiles, 16-21 % faster than a wave per quad everywhere (the person grid of the scan, E / mean 3.6 .. 21); the frames one wave per quad
-    // wins hold E / mean <= 2.4.
+    // tiles, 6-21 % faster than a wave per quad everywhere (the person grid of the scan, E / mean 2.8 .. 21: the 1600x900 frames at 2.8 by
+    // 7-9 %); the frames one wave per quad wins hold E / mean <= 2.35 (a 524 288-Gaussian person alone at 1080p; the trained 2 M scenes 1.27).
     if (n_nonempty >= DENSE_ALWAYS_TILES) {
         const unsigned long long rise = n_nonempty < 2u * DENSE_ALWAYS_TILES ? (unsigned long long)(2u * DENSE_ALWAYS_TILES - n_nonempty) * DENSE_ALWAYS_E_RISE / DENSE_ALWAYS_TILES : 0ull;
         if (sum_sq <= ((unsigned long long)DENSE_ALWAYS_E_MAX + rise) * total) return 0u;
-        return (float)sum_sq * (float)n_nonempty <= (float)DENSE_ALWAYS_TAIL * (float)total * (float)total ? 1u : 0u;
+        return 10.0f * (float)sum_sq * (float)n_nonempty <= (float)DENSE_ALWAYS_TAIL_X10 * (float)total * (float)total ? 1u : 0u;
     }
     if (n_nonempty < DENSE_MIN_TILES) return 1u;
     unsigned long long e_max = min((unsigned long long)DENSE_E_MAX, (unsigned long long)(n_nonempty - DENSE_E_ORIGIN) * 9ull / 20ull);

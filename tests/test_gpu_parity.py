@@ -456,7 +456,7 @@ def test_renderer_adapter_contract(device):
     assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "human_img",
                         "human_visibility_filter", "human_radii", "scene_visibility_filter", "scene_radii"}
     assert pkg["render"].shape == (3, 64, 64) and pkg["render"].dtype == torch.float32
-    assert float(pkg["render"].min()) >= 0.0 and float(pkg["render"].max()) <= 1.0
+    assert float(pkg["render"].detach().min()) >= 0.0 and float(pkg["render"].detach().max()) <= 1.0
     assert pkg["viewspace_points"].shape == (120, 3) and pkg["radii"].dtype == torch.int32
     assert pkg["visibility_filter"].dtype == torch.bool and pkg["visibility_filter"].shape == (120,)
     assert pkg["human_radii"].shape == (70,) and pkg["scene_radii"].shape == (50,)

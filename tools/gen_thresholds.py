@@ -40,7 +40,7 @@ ROWS = [
     ("frame kind: DENSE (one backward wave per tile) or SPARSE (a wave per 8x8 quad; from the forward's checkpoints: per 32-entry segment)",
      "n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= {DENSE_ALWAYS_TILES}: dense unless E > {DENSE_ALWAYS_E_MAX} (+ up to {DENSE_ALWAYS_E_RISE} more below 8 192 tiles, linearly: {DENSE_ALWAYS_E_MAX} + {DENSE_ALWAYS_E_RISE} at {DENSE_ALWAYS_TILES}).  "
      "{DENSE_MIN_TILES} <= n < {DENSE_ALWAYS_TILES}: dense while E <= min({DENSE_E_MAX}, 0.45 (n - {DENSE_E_ORIGIN})) -- up to {DENSE_E_FLAT_MAX} on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < {DENSE_MIN_TILES}: sparse",
-     "DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)"),
+     "DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL_X10, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)"),
     ("checkpoints for the depth-segmented backward (when the caller offers a buffer)",
      "sparse frame: every tile -- none when n >= {DENSE_ALWAYS_TILES} and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= {HGS_CKPT_DEEP_MIN} entries, "
      "and only when the shape's last frame held a list beyond {HGS_DEEP_BWD_MIN} entries (host, from the shape's record)",

@@ -519,6 +519,16 @@ def main():
     S, T = H * W, ((H + 15) // 16) * ((W + 15) // 16)
     frame_B, bwd_B, fwd_B = alg_bytes(P, Pv, N, S, T, K)
     dom_ms = prof[dominant][0] / prof[dominant][1]
+    # the blend backward's kernel depends on the frame (a dense frame with deep tiles -- the trained profile -- runs the one-launch mixed
+    # kernel, a sparse one the segmented kernel): the name the rocprofv3 summaries of this workload carry, from this thread's last frame
+    KERNEL_OF = dict(globals()["KERNEL_OF"])
+    if dominant == "blend_backward":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_common
+            KERNEL_OF["blend_backward"] = bench_common.kernel_of("blend_backward")
+        except Exception:
+            pass
     dom_B = fwd_B + 28 * N if args.forward_only else bwd_B   # fused tile sort + forward blend: + keys in, list and compacted lists out
     achieved = dom_B / (dom_ms * 1e-3) / 1e9
     fps = world * KF * args.steps / elapsed

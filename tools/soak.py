@@ -42,6 +42,10 @@ def scene(P, H, W):
 
 cpp = dgr._load_cpp()
 streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+# (the soak moves the SAME leaves from stream to stream on purpose: torch's AccumulateGrad stream-mismatch warning is about exactly that,
+#  and this is the switch it names for an intentional mismatch)
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 budget = float(os.environ.get("SOAK_SECONDS", "40"))
 t0 = time.time()
 n = n_batch = 0

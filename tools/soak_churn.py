@@ -34,6 +34,10 @@ for H, W in shapes:
     pools[(H, W)] = ({k: d(g[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")},
                      {k: (d(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}, cam, Pmax)
 streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+# (the soak moves the SAME leaves from stream to stream on purpose: torch's AccumulateGrad stream-mismatch warning is about exactly that,
+#  and this is the switch it names for an intentional mismatch)
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 budget = float(os.environ.get("SOAK_SECONDS", "60"))
 t0 = time.time()
 seen, n, n_batch, n_pair = set(), 0, 0, 0

@@ -460,8 +460,8 @@ void hgs_reload_switches(void);
  *     sparse frame: beyond 256 entries when mean >= 200 and 16 .. 512 lists are that long; else beyond 1 024 when 16 .. 512 lists are; with more than 512 lists beyond 1 024: beyond 1 024 if the longest list is <= 4 096 (flat), else beyond 2 048.  dense frame: none unless the frame holds a list beyond 2 048; then beyond 768, or beyond 1 024 when more than 832 lists lie beyond 768
  *     [LONG_MIN_SPARSE, DEEP_MEAN_MIN, LONG_MIN_SPARSE_TILES, LONG_ONE_ROUND, LONG_MIN_SPARSE_SHALLOW, LONG_MIN_DENSE, DENSE_LONG_MANY, SORT_CAP_SMALL, SORT_CAP_MID (binning.hip, tile_scan_body)]
  * - long tiles blended split by depth (four waves per quad: the deep workers):
- *     dense frames; sparse frames with mean >= 200 -- except more than 512 long lists none of which is beyond 4 096 entries (flat: one wave per quad)
- *     [n_total[8] (binning.hip); HGS_DEEP_FORWARD=0 / HGS_DEEP_MIN override]
+ *     dense frames; sparse frames with mean >= 200 -- except more than 512 long lists none of which is beyond 4 096 entries (flat: one wave per quad), and except sparse frames of >= 1 000 non-empty tiles whose longest list is <= 18 / 10 E (full and even: a person filling the frame)
+ *     [n_total[8], DEEP_EVEN_TILES, DEEP_EVEN_L_X10 (binning.hip); HGS_DEEP_FORWARD=0 / HGS_DEEP_MIN override]
  * - per-tile sort inside the fused kernel:
  *     <= 256 entries: bitonic network in registers; <= 1 024: bucket sort in LDS; <= 2 048: bitonic network, eight keys per thread; long tiles' kernel: one workgroup per list of <= 4 096 entries, longer lists split by depth into parts of 3 072 .. 4 096
  *     [SORT_CAP_SMALL, SORT_CAP_MID, PLAN_PART (binning.hip)]

@@ -90,6 +90,7 @@ constexpr uint32_t LONG_MIN_SPARSE_TILES = 16;  // ... when the frame has at lea
 // after round, in front of its fused kernel: sort + forward 214 us against 107 with the threshold at 1 024; 20 000 Gaussians at
 // 540 x 960: 125 against 60 us (end of round 5, `HGS_LONG_MIN_SPARSE` sweep; C3's frames have 276 / 346 such lists and keep 256).
 constexpr uint32_t LONG_ONE_ROUND = 512;
+constexpr uint32_t DEEP_EVEN_TILES = 1000, DEEP_EVEN_L_X10 = 18;   // sparse frames this full and this even blend their long lists one wave per quad (tile_scan_body)
 constexpr uint32_t DENSE_LONG_MANY = 832;   // a dense frame with more lists than this beyond long_min_dense takes LONG_MIN_SPARSE_SHALLOW (tile_scan_body)
 
 constexpr int SCAN_ITEMS = 8;  // consecutive tiles per thread and pass: 8 192 tiles per pass of the 1024 threads
@@ -395,7 +396,15 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
     const uint32_t dense_min = dense_many ? (uint32_t)LONG_MIN_SPARSE_SHALLOW : dense_long ? long_min_dense : max(long_min_dense, (uint32_t)SORT_CAP_SMALL);
     const uint32_t threshold = use_sparse ? sparse_min : dense_min;
     const uint32_t any_long = (use_sparse ? n_sparse_long : (dense_many ? n_large_shallow : dense_long ? n_large_dense : 0u)) ? 1u : 0u;
-    const uint32_t deep_flag = ((!sparse || deep_lists) && !many_flat_long) ? 1u : 0u;
+    // (round 6, last scan) ... nor on a sparse frame that already fills the SIMDs with its own quads and has no list that outlasts the
+    // others: >= DEEP_EVEN_TILES non-empty tiles (4 000 quad waves for 1 024 SIMDs) and the longest list within DEEP_EVEN_L_X10 / 10 = 1.8 x E.
+    // That is a person filling a 512x512 frame (3 units away instead of the canonical rig's 5: 1 020 of 1 024 tiles, longest / E = 1.7) or
+    // standing alone in a 1280x720 one: 5-11 % faster one wave per quad on every such point of the scans; the canonical rig (346-739 tiles,
+    // 1.9), every trained frame (2.5-3.5) and every person in front of a scene (3-10) keep the workers, which are worth 10-57 % there;
+    // uniform frames (1.1) do not care (+-0.6 %).
+    const bool even_and_full = sparse && n_nonempty >= DEEP_EVEN_TILES && !sparse_unconditional && sa.deep_min == 0u &&
+                               10ull * longest * total64 <= (unsigned long long)DEEP_EVEN_L_X10 * sumsq64;
+    const uint32_t deep_flag = ((!sparse || deep_lists) && !many_flat_long && !even_and_full) ? 1u : 0u;
     // Which tiles leave checkpoints for the backward (hgs_common.h, CKPT_KIND_*): every tile of a sparse frame -- except (round 6) on a
     // sparse frame of 4 096 non-empty tiles and more WITHOUT a heavy tail (E < 1.6 x the mean list: the trained 2 097 152-Gaussian scenes):
     // 16 384 quad waves and more fill the SIMDs from the end of the lists, and 800 MB of checkpoints cost more than the segmented walk

@@ -51,8 +51,8 @@ ROWS = [
      "dense frame: none unless the frame holds a list beyond {SORT_CAP_SMALL}; then beyond {LONG_MIN_DENSE}, or beyond {LONG_MIN_SPARSE_SHALLOW} when more than {DENSE_LONG_MANY} lists lie beyond {LONG_MIN_DENSE}",
      "LONG_MIN_SPARSE, DEEP_MEAN_MIN, LONG_MIN_SPARSE_TILES, LONG_ONE_ROUND, LONG_MIN_SPARSE_SHALLOW, LONG_MIN_DENSE, DENSE_LONG_MANY, SORT_CAP_SMALL, SORT_CAP_MID (binning.hip, tile_scan_body)"),
     ("long tiles blended split by depth (four waves per quad: the deep workers)",
-     "dense frames; sparse frames with mean >= {HGS_DEEP_MEAN_MIN} -- except more than {LONG_ONE_ROUND} long lists none of which is beyond {SORT_CAP_MID} entries (flat: one wave per quad)",
-     "n_total[8] (binning.hip); HGS_DEEP_FORWARD=0 / HGS_DEEP_MIN override"),
+     "dense frames; sparse frames with mean >= {HGS_DEEP_MEAN_MIN} -- except more than {LONG_ONE_ROUND} long lists none of which is beyond {SORT_CAP_MID} entries (flat: one wave per quad), and except sparse frames of >= {DEEP_EVEN_TILES} non-empty tiles whose longest list is <= {DEEP_EVEN_L_X10} / 10 E (full and even: a person filling the frame)",
+     "n_total[8], DEEP_EVEN_TILES, DEEP_EVEN_L_X10 (binning.hip); HGS_DEEP_FORWARD=0 / HGS_DEEP_MIN override"),
     ("per-tile sort inside the fused kernel", "<= 256 entries: bitonic network in registers; <= 1 024: bucket sort in LDS; <= {SORT_CAP_SMALL}: bitonic network, eight keys per thread; "
      "long tiles' kernel: one workgroup per list of <= {SORT_CAP_MID} entries, longer lists split by depth into parts of {PLAN_PART} .. {SORT_CAP_MID}", "SORT_CAP_SMALL, SORT_CAP_MID, PLAN_PART (binning.hip)"),
     ("binning groups (host, before the first kernel)",

@@ -28,8 +28,8 @@ def _human(P, seed=5):
 
 def _frame(kind, H, W, P):
     from hugs_amd import synthetic as syn
-    if kind == "human":          # the canonical rig (dist 5, fov 0.4) at the frame's size
-        cam = syn.rotating_camera(3, 10, dist=5.0, fov=0.4, img_size=max(H, W))
+    if kind in ("human", "human_d3"):   # the canonical rig (dist 5, fov 0.4) at the frame's size; "human_d3": 3 units away, the person fills the frame
+        cam = syn.rotating_camera(3, 10, dist=3.0 if kind == "human_d3" else 5.0, fov=0.4, img_size=max(H, W))
         if H != W:
             cam = syn.camera_from_w2c(np.ascontiguousarray(cam["world_view_transform"].T), 0.4, 2.0 * math.atan(math.tan(0.2) * H / W), H, W)
         return cam, _human(P)
@@ -71,6 +71,9 @@ FRAMES = {
     "deep_covered_1536x1024": ("uniform7", 1024, 1536, 1_000_000, 0, True, True, 2, False),
     # ... and 4 096 tiles at E ~ 840: under the bound there (1 100): dense
     "covered_1024_dense": ("uniform", 1024, 1024, 900_000, 0, False, False, 0, None),
+    # a person FILLING a 512x512 frame (3 units away): sparse, 1 020 of 1 024 tiles non-empty and the longest list 1.7 x E -- its own quads fill
+    # the SIMDs and no list outlasts the others: long lists blended one wave per quad (the canonical rig above, 700 tiles, keeps the workers)
+    "human_110210_filling_512": ("human_d3", 512, 512, 110_210, 0, True, True, 1, False),
     # a covered frame with a heavy TAIL (tools/bench_step.py's joint render: 8 160 shallow lists and a person's few hundred deep ones, E several
     # times the mean): dense -- one wave per tile, the deep tiles through the checkpointed walk -- whatever E is
     "person_in_covered_1080p": ("person110210", 1080, 1920, 310_210, 0, False, True, 0, True),

@@ -614,11 +614,24 @@ def main():
     from build_id import csrc_sha16
     here = csrc_sha16()
 
-    def newest(pattern):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))  # named per round: r1p < r2a < r2b
+    def newest(pattern, fits=None):
+        """the newest file of the pattern (named per round: r1p < r2a < r2b) -- with `fits`, the newest whose contents are of THIS workload (a
+        collection leaves one file per tracked workload: r6u_pmc_traffic.json, r6u_trained_pmc_traffic.json, ...), else the newest at all"""
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        if fits:
+            for cand in reversed(files):
+                try:
+                    if fits(json.load(open(cand))):
+                        return cand
+                except Exception:
+                    pass
         return files[-1] if files else None
 
-    f = newest("*_pmc_traffic.json")
+    def of_this_workload(doc):
+        w = doc.get("workload") or {}
+        return (w.get("gaussians"), w.get("height"), w.get("width"), w.get("sh_degree")) == (P, H, W, D) and args.profile == w.get("profile", "uniform")
+
+    f = newest("*_pmc_traffic.json", of_this_workload)
     if f:
         pmc = json.load(open(f))
         wl = pmc.get("workload", {})
@@ -636,7 +649,7 @@ def main():
     #                    of its hot loop x profiles/r2_valu_model.txt) / 1 024 SIMDs / kernel time: ~1 = the kernel sits on what its mix allows
     #   valu_pipe_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles): the pipes never idle -- NOT a fraction of peak issue
     # Attached only for the workload and the kernel sources the counters were taken on.
-    f = newest("*_valu_utilization.json")
+    f = newest("*_valu_utilization.json", of_this_workload)
     if f:
         vu_all = json.load(open(f))
         vu = vu_all.get("kernels", {}).get(KERNEL_OF[dominant])

@@ -282,3 +282,25 @@ def test_rccl_branch_of_the_bench_runs_as_a_process_group_of_one(device):
     assert out["backend"].startswith("nccl") and out["ranks_seen"] == 1 and out["expected_ranks"] == 1
     assert out["per_rank_N"] == out["config"]["N_per_frame_all_ranks"] and out["per_rank_N"][0] > 0 and out["value"] > 100.0
     assert "world_size 1 (nccl" in r.stderr
+
+
+@pytest.mark.gpu
+def test_the_wait_for_n_survives_sleeps_that_overshoot(device):
+    """The library sleeps through a wait for N that the shape's record expects to be long (one rank = half a core instead of two: DESIGN 4.1 / 6).
+    On a box whose sleeps overshoot (a loaded host: round 6's last 8-rank run) a fixed wake-up margin made every frame late AND taught the
+    record a longer wait, which lengthened the next sleep: 400 us of overshoot took the bench workload from 2 000 to 77 frames/s.  The margin
+    now follows the overshoot and an overslept wait is recorded as the time the sleep was MEANT to end.  HGS_WAIT_TEST_OVERSLEEP_US injects the
+    overshoot; the frame rate must not care (a loose bound: boxes differ)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HGS_WAIT_SLEEP")}
+    fps = {}
+    for inject in ("0", "400"):
+        env = dict(base, HGS_WAIT_TEST_OVERSLEEP_US=inject)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "300", "--warmup", "30", "--no-cpu-baseline", "--no-two-streams"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        fps[inject] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["value"]
+    assert fps["400"] >= 0.8 * fps["0"], fps

@@ -235,7 +235,7 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
     wt.out = waited_ns;
     static const bool may_sleep = [] { const char* e = getenv("HGS_WAIT_SLEEP"); return !(e && e[0] == '0'); }();
     uint64_t next_query = wt.t0 + 20000000ull;
-    bool slept = false, napping = false, just_woke = false;
+    bool slept = false, napping = false, just_woke = false, decayed = false;
     // How early the sleep ends: WAKE_EARLY_NS, or three times what this process's sleeps have been overshooting by (a running mean; ~60 us of
     // timer slack + wake-up latency on a quiet box, several hundred on a loaded one -- where the margin then outgrows the waits and the
     // frames are spun for again).  Round 6's last 8-rank run met such a box: 300 000 Gaussians 1 790 -> 1 499 FPS with the fixed margin,
@@ -293,6 +293,14 @@ int wait_for_slot(const HostSlot& hs, hipStream_t st, uint32_t* n_out, bool* spa
                 just_woke = true;
                 continue;
             }
+#ifndef HGS_WAIT_FIXED_MARGIN
+            // (a wait the minimum margin would have slept through and the adapted one does not: the overshoot estimate only learns from sleeps,
+            //  so it is let go of slowly -- after ~80 such frames one sleep probes the host again; one late frame in 80 if it still overshoots)
+            else if (may_sleep && !slept && !decayed && waited > 20000ull && expected_ns >= (int64_t)SLEEP_FROM_NS && waited + WAKE_EARLY_NS < (uint64_t)expected_ns) {
+                decayed = true;
+                oversleep_ns.store(oversleep_ns.load(std::memory_order_relaxed) * 63ull / 64ull, std::memory_order_relaxed);
+            }
+#endif
             // a wait far beyond what the shape's record (or, without one, a millisecond) allows: the GPU is busy with someone else's work
             if (may_sleep && !napping && waited > (uint64_t)(expected_ns > 0 ? expected_ns : 0) + 1000000ull) napping = true;
         }

@@ -616,7 +616,7 @@ def main():
 
     def newest(pattern, fits=None):
         """the newest file of the pattern (named per round: r1p < r2a < r2b) -- with `fits`, the newest whose contents are of THIS workload (a
-        collection leaves one file per tracked workload: r6u_pmc_traffic.json, r6u_trained_pmc_traffic.json, ...), else the newest at all"""
+        collection leaves one file per tracked workload: r6w_pmc_traffic.json, r6w_trained_pmc_traffic.json, ...), else the newest at all"""
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
         if fits:
             for cand in reversed(files):

@@ -443,8 +443,8 @@ blend_backward_segmented_kernel(Camera cam, uint32_t lastg, const uint2* __restr
 // stream the second waited for the first's last wave; both add into the same accumulator, so nothing orders them.  The long
 // one-wave-per-tile walks start first and the short segment walks fill the SIMDs their tail leaves.
 // (round 6) NO occupancy attribute: rounds 4-5 asked for amdgpu_waves_per_eu(8), which caps the kernel at 80 SGPRs -- the segment walk
-// alone holds 77, the two forms together 99 -- and the compiler spilled 46 of them to VGPR lanes inside the segment walk's loop
-// (v_writelane / v_readlane per entry).  A frame whose deep tiles are most of its work paid for it: a person in front of a
+// alone holds 77, the two forms together 98 -- and the compiler spilled 21 of them to VGPR lanes (46 without -fno-slp-vectorize), with
+// 9 v_writelane and 51 v_readlane inside the walks' loops (profiles/r6p_mixed_kernel_resource_usage.txt).  A frame whose deep tiles are most of its work paid for it: a person in front of a
 // 600 000-Gaussian scene at 1280x720 -- every tile beyond CKPT_DEEP_MIN, the whole backward in this kernel's segment half -- 404 us
 // against 339 for the stand-alone segmented kernel on the same slots; without the attribute 360 (trained-scene profile 0.636 -> 0.617 ms,
 // the step's joint render 0.681 -> 0.665; C4's joint render, no deep tiles, unchanged).  -DHGS_MIXED_ATTR=... for A/B builds.

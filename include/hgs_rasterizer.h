@@ -194,7 +194,7 @@ typedef struct hgs_forward_state {
     int64_t ckpt_slots;       /* slots the checkpoint buffer was laid out for (0: none) */
     int64_t ckpt_slots_used;  /* slots the frame's checkpoints need: (N >> 5) + tiles on a sparse frame, the deep tiles' packed count on a
                                  dense one (0 when it left none); feeds the next frame's ckpt_slots_hint.  -1: a sparse frame that
-                                 leaves none BY RULE (4 096 non-empty tiles and more, no heavy tail: its backward runs one wave per quad
+                                 leaves none BY RULE (7 168 non-empty tiles and more, no heavy tail: its backward runs one wave per quad
                                  without them) -- the caller need not offer this shape's next frame a buffer */
 } hgs_forward_state;
 
@@ -451,11 +451,11 @@ void hgs_reload_switches(void);
  *
  * BEGIN GENERATED: path selection (tools/gen_thresholds.py: do not edit by hand)
  * - frame kind: DENSE (one backward wave per tile) or SPARSE (a wave per 8x8 quad; from the forward's checkpoints: per 32-entry segment):
- *     n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= 4 096: dense unless E > 760 (+ up to 340 more below 8 192 tiles, linearly: 760 + 340 at 4 096).  1 536 <= n < 4 096: dense while E <= min(1 200, 0.45 (n - 800)) -- up to 1 600 on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < 1 536: sparse
+ *     n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= 4 096: dense unless E > 830 (+ up to 680 more below 8 192 tiles, linearly: 830 + 680 at 4 096) AND the depth is the frame's own: E <= 26 / 10 mean (a heavy tail on a covered frame -- a person in front of a scene -- stays dense: its deep tiles take the checkpointed walk) and the frame is not flat (longest list <= 1.25 E, E <= 1 600: dense).  1 536 <= n < 4 096: dense while E <= min(1 200, 0.45 (n - 800)) -- up to 1 600 on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < 1 536: sparse
  *     [DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL_X10, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)]
  * - checkpoints for the depth-segmented backward (when the caller offers a buffer):
- *     sparse frame: every tile -- none when n >= 4 096 and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= 512 entries, and only when the shape's last frame held a list beyond 2 048 entries (host, from the shape's record)
- *     [CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = 32 entries per segment (hgs_common.h)]
+ *     sparse frame: every tile -- none when n >= 7 168 and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= 512 entries, and only when the shape's last frame held a list beyond 2 048 entries (host, from the shape's record)
+ *     [CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = 32 entries per segment (hgs_common.h), NO_CKPT_MIN_TILES (binning.hip)]
  * - LONG lists (sorted ahead of the fused kernel by the long tiles' kernels):
  *     sparse frame: beyond 256 entries when mean >= 200 and 16 .. 512 lists are that long; else beyond 1 024 when 16 .. 512 lists are; with more than 512 lists beyond 1 024: beyond 1 024 if the longest list is <= 4 096 (flat), else beyond 2 048.  dense frame: none unless the frame holds a list beyond 2 048; then beyond 768, or beyond 1 024 when more than 832 lists lie beyond 768
  *     [LONG_MIN_SPARSE, DEEP_MEAN_MIN, LONG_MIN_SPARSE_TILES, LONG_ONE_ROUND, LONG_MIN_SPARSE_SHALLOW, LONG_MIN_DENSE, DENSE_LONG_MANY, SORT_CAP_SMALL, SORT_CAP_MID (binning.hip, tile_scan_body)]

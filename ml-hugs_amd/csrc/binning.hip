@@ -119,7 +119,7 @@ struct ScanArgs {
 // (tools/shape_scan.py, profiles/r6*_shape_scan*.json: 2 040 non-empty tiles: dense up to E ~ 580, 3 600: up to ~1 200; a covered
 // 1280x720 frame of 100 000 Gaussians, E = 445: 0.370 -> 0.339 ms; a trained one, E = 638: 0.489 -> 0.395), never under 1 536 tiles
 // (a 512x512 frame, any human-only render: the depth-segmented backward from the forward's checkpoints wins at every depth).
-constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 760, DENSE_ALWAYS_E_RISE = 340, DENSE_ALWAYS_TAIL_X10 = 26;
+constexpr uint32_t DENSE_ALWAYS_TILES = 4096, DENSE_MIN_TILES = 1536, DENSE_E_ORIGIN = 800, DENSE_E_MAX = 1200, DENSE_E_FLAT_MAX = 1600, DENSE_ALWAYS_E_MAX = 830, DENSE_ALWAYS_E_RISE = 680, DENSE_ALWAYS_TAIL_X10 = 26, NO_CKPT_MIN_TILES = 7168;
 __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigned long long total, unsigned long long sum_sq, uint32_t longest, uint32_t force_kind)
 {
     if (force_kind) return force_kind == 1u ? 1u : 0u;
@@ -128,7 +128,11 @@ __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigne
     // as the LAST of its 256 pixels composited, a wave per quad as far as the last of its 64, and in deep lists most quads are done long
     // before their tile is: one wave per quad 8-16 % faster there, 10-45 % slower on every shallower frame of the scan (E <= 705).
     // (the bound rises towards fewer tiles -- + DENSE_ALWAYS_E_RISE from 8 192 tiles down to 4 096: a 1600x900 frame, 5 700 tiles, is 8-22 %
-    //  faster dense at E = 785 where 8 160 tiles break even)
+    //  faster dense at E = 785 where 8 160 tiles break even, and 5 % at E = 1 120; 800 000 Gaussians of a trained scene at 1024x1024 and
+    //  1366x768 -- 4 096 / 4 128 tiles, E = 1 191 / 1 163, frames of a second holdout grid the first fit (a rise of 340) had not seen --
+    //  19-24 % faster dense than one wave per quad without checkpoints: the rise is 680, i.e. 1 510 at 4 096 tiles, 1 240 at 5 700; and
+    //  DENSE_ALWAYS_E_MAX itself is 830, not the first fit's 760: 1 500 000 Gaussians of a trained scene at 1080p, E = 812, are 11 % faster
+    //  dense, 2 097 152 at 2048x1152, E = 851, 23 % faster a wave per quad)
     // ... and only where the depth is the FRAME's, not a tail's: E <= DENSE_ALWAYS_TAIL_X10 / 10 = 2.6 x the mean list.  A person on a body surface in
     // front of a covered 1080p scene (tools/bench_step.py's joint render: mean 392, E = 2 141, 286 lists beyond 2 048 entries, the longest
     // 10 751) is one wave per tile over 7 800 shallow lists plus the checkpointed walk of the few deep ones -- a dense frame with deep
@@ -137,6 +141,9 @@ __device__ __forceinline__ uint32_t frame_is_sparse(uint32_t n_nonempty, unsigne
     if (n_nonempty >= DENSE_ALWAYS_TILES) {
         const unsigned long long rise = n_nonempty < 2u * DENSE_ALWAYS_TILES ? (unsigned long long)(2u * DENSE_ALWAYS_TILES - n_nonempty) * DENSE_ALWAYS_E_RISE / DENSE_ALWAYS_TILES : 0ull;
         if (sum_sq <= ((unsigned long long)DENSE_ALWAYS_E_MAX + rise) * total) return 0u;
+        // (... nor a FLAT frame's, as under 4 096 tiles: the longest list within a quarter of E -- 7-pixel splats covering a 1080p frame, every
+        //  list 840-1 130 entries: 10-14 % faster dense; what a wave per quad wins on is the trained scenes' spread, longest ~ 3.5 E)
+        if (4ull * longest * total <= 5ull * sum_sq && sum_sq <= (unsigned long long)DENSE_E_FLAT_MAX * total) return 0u;
         return 10.0f * (float)sum_sq * (float)n_nonempty <= (float)DENSE_ALWAYS_TAIL_X10 * (float)total * (float)total ? 1u : 0u;
     }
     if (n_nonempty < DENSE_MIN_TILES) return 1u;
@@ -406,10 +413,11 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs& sa)
                                10ull * longest * total64 <= (unsigned long long)DEEP_EVEN_L_X10 * sumsq64;
     const uint32_t deep_flag = ((!sparse || deep_lists) && !many_flat_long && !even_and_full) ? 1u : 0u;
     // Which tiles leave checkpoints for the backward (hgs_common.h, CKPT_KIND_*): every tile of a sparse frame -- except (round 6) on a
-    // sparse frame of 4 096 non-empty tiles and more WITHOUT a heavy tail (E < 1.6 x the mean list: the trained 2 097 152-Gaussian scenes):
-    // 16 384 quad waves and more fill the SIMDs from the end of the lists, and 800 MB of checkpoints cost more than the segmented walk
-    // saves (8-16 % of the frame); with a tail (a person in front of an empty background at 1080p) the segmented walk stays.
-    const bool sparse_no_ckpt = sparse && !force_kind_set && n_nonempty >= DENSE_ALWAYS_TILES &&
+    // sparse frame of NO_CKPT_MIN_TILES non-empty tiles and more WITHOUT a heavy tail (E < 1.6 x the mean list: the trained 2 097 152-Gaussian
+    // scenes at 1080p and above): 28 000 quad waves and more fill the SIMDs from the end of the lists, and 800 MB of checkpoints cost more
+    // than the segmented walk saves (6-16 % of the frame); with a tail (a person in front of an empty background at 1080p) the segmented
+    // walk stays, and so it does under NO_CKPT_MIN_TILES (5 700 tiles, 1 500 000 Gaussians: 3 % faster WITH checkpoints; 4 096 tiles: 32 %).
+    const bool sparse_no_ckpt = sparse && !force_kind_set && n_nonempty >= NO_CKPT_MIN_TILES &&
                                 (float)sumsq64 * (float)n_nonempty < 1.6f * (float)total64 * (float)total64;
     const uint32_t ckpt_kind = !sparse ? (uint32_t)CKPT_KIND_DEEP : sparse_no_ckpt ? (uint32_t)CKPT_KIND_NONE : (uint32_t)CKPT_KIND_ALL;
     if (threadIdx.x == 0) {

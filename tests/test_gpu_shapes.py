@@ -67,10 +67,12 @@ FRAMES = {
     "human_110210_filling_1080p": ("human", 1080, 1920, 110_210, 0, False, False, 0, None),
     # more lists beyond 1 024 entries than one round of the long tiles' kernel, all of them flat: long from 1 024 on, blended one wave per quad
     "flat_long_512": ("uniform", 512, 512, 300_000, 0, True, True, 1, False),
-    # 6 144 non-empty tiles, deep flat lists (E ~ 1 100 > 930, the bound at that many tiles): sparse WITHOUT checkpoints; most lists beyond 1 024
-    # entries and none beyond 4 096: long, blended one wave per quad
-    "deep_covered_1536x1024": ("uniform7", 1024, 1536, 1_000_000, 0, True, True, 2, False),
-    # ... and 4 096 tiles at E ~ 840: under the bound there (1 100): dense
+    # 8 160 non-empty tiles, lists as deep as they get (2 097 152 Gaussians of a trained scene at 1080p: mean 750, E ~ 950 > 835, the bound at
+    # that many tiles, 1.27 x the mean, the longest 3.5 E): sparse WITHOUT checkpoints (only from 7 168 tiles on)
+    "trained_2097152_at_1080p": ("trained", 1080, 1920, 2_097_152, 0, True, True, 2, None),
+    # ... the same depth in FLAT lists (7-pixel splats, every list 900-1 080 entries): dense, as any flat frame
+    "flat_deep_covered_1080p": ("uniform7", 1080, 1920, 1_300_000, 0, False, False, 0, None),
+    # ... and 4 096 tiles at E ~ 840: under the bound there (1 510): dense
     "covered_1024_dense": ("uniform", 1024, 1024, 900_000, 0, False, False, 0, None),
     # a person FILLING a 512x512 frame (3 units away): sparse, 1 020 of 1 024 tiles non-empty and the longest list 1.7 x E -- its own quads fill
     # the SIMDs and no list outlasts the others: long lists blended one wave per quad (the canonical rig above, 700 tiles, keeps the workers)

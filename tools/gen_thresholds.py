@@ -38,13 +38,13 @@ def constants():
 ROWS = [
     ("decision", "rule (the frame's own numbers, taken by the tile scan unless said otherwise)", "constants"),
     ("frame kind: DENSE (one backward wave per tile) or SPARSE (a wave per 8x8 quad; from the forward's checkpoints: per 32-entry segment)",
-     "n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= {DENSE_ALWAYS_TILES}: dense unless E > {DENSE_ALWAYS_E_MAX} (+ up to {DENSE_ALWAYS_E_RISE} more below 8 192 tiles, linearly: {DENSE_ALWAYS_E_MAX} + {DENSE_ALWAYS_E_RISE} at {DENSE_ALWAYS_TILES}).  "
+     "n = non-empty tiles, E = sum(len^2) / N (the list length a random entry sits in), mean = N / n.  n >= {DENSE_ALWAYS_TILES}: dense unless E > {DENSE_ALWAYS_E_MAX} (+ up to {DENSE_ALWAYS_E_RISE} more below 8 192 tiles, linearly: {DENSE_ALWAYS_E_MAX} + {DENSE_ALWAYS_E_RISE} at {DENSE_ALWAYS_TILES}) AND the depth is the frame's own: E <= {DENSE_ALWAYS_TAIL_X10} / 10 mean (a heavy tail on a covered frame -- a person in front of a scene -- stays dense: its deep tiles take the checkpointed walk) and the frame is not flat (longest list <= 1.25 E, E <= {DENSE_E_FLAT_MAX}: dense).  "
      "{DENSE_MIN_TILES} <= n < {DENSE_ALWAYS_TILES}: dense while E <= min({DENSE_E_MAX}, 0.45 (n - {DENSE_E_ORIGIN})) -- up to {DENSE_E_FLAT_MAX} on a flat frame (longest list <= 1.25 E) -- and E <= 2.5 mean.  n < {DENSE_MIN_TILES}: sparse",
      "DENSE_ALWAYS_TILES, DENSE_ALWAYS_E_MAX, DENSE_ALWAYS_E_RISE, DENSE_ALWAYS_TAIL_X10, DENSE_MIN_TILES, DENSE_E_MAX, DENSE_E_ORIGIN, DENSE_E_FLAT_MAX (binning.hip, frame_is_sparse)"),
     ("checkpoints for the depth-segmented backward (when the caller offers a buffer)",
-     "sparse frame: every tile -- none when n >= {DENSE_ALWAYS_TILES} and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= {HGS_CKPT_DEEP_MIN} entries, "
+     "sparse frame: every tile -- none when n >= {NO_CKPT_MIN_TILES} and E < 1.6 mean (hgs_forward_state.ckpt_slots_used = -1).  dense frame: its tiles of >= {HGS_CKPT_DEEP_MIN} entries, "
      "and only when the shape's last frame held a list beyond {HGS_DEEP_BWD_MIN} entries (host, from the shape's record)",
-     "CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = {CKPT_SEG} entries per segment (hgs_common.h)"),
+     "CKPT_DEEP_MIN, DEEP_BWD_MIN, CKPT_SEG = {CKPT_SEG} entries per segment (hgs_common.h), NO_CKPT_MIN_TILES (binning.hip)"),
     ("LONG lists (sorted ahead of the fused kernel by the long tiles' kernels)",
      "sparse frame: beyond {LONG_MIN_SPARSE} entries when mean >= {HGS_DEEP_MEAN_MIN} and {LONG_MIN_SPARSE_TILES} .. {LONG_ONE_ROUND} lists are that long; else beyond {LONG_MIN_SPARSE_SHALLOW} when "
      "{LONG_MIN_SPARSE_TILES} .. {LONG_ONE_ROUND} lists are; with more than {LONG_ONE_ROUND} lists beyond {LONG_MIN_SPARSE_SHALLOW}: beyond {LONG_MIN_SPARSE_SHALLOW} if the longest list is <= {SORT_CAP_MID} (flat), else beyond {SORT_CAP_SMALL}.  "

@@ -130,6 +130,10 @@ def points(args):
                 for Ph in (30_000, 110_210, 300_000):
                     for dist in (3.0, 4.0, 6.0, 9.0):
                         out.append({"kind": "tracked_step_joint", "H": H, "W": W, "P": Ph + Ps, "D": 0, "Ph": Ph, "Ps": Ps, "dist": dist})
+    if args.flat_deep:
+        # covered frames of 7-pixel splats: flat lists as deep as a trained scene's (E = the mean, 800 .. 1 700)
+        for (H, W, P) in ((1080, 1920, 1_000_000), (1080, 1920, 1_300_000), (1080, 1920, 2_097_152), (1024, 1536, 1_000_000), (1152, 2048, 1_500_000), (900, 1600, 1_000_000)):
+            out.append({"kind": "uniform7", "H": H, "W": W, "P": P, "D": 0})
     if args.only:
         out = [p for p in out if args.only in p["kind"]]
     if args.where:   # e.g. --where "H==720 and P==630000 and dist==4.0"
@@ -179,7 +183,7 @@ def build(pt, dev):
             Ph = min(110_210, P // 2)
             g = syn.trained_scene_gaussians(P - Ph, cam, seed=0, human=Ph)
         else:
-            g = syn.scene_gaussians(P, cam, seed=0, sigma_px=4.0)
+            g = syn.scene_gaussians(P, cam, seed=0, sigma_px=7.0 if pt["kind"] == "uniform7" else 4.0)   # ("uniform7": 7-pixel splats, deep flat lists)
     t = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)
     tens = {k: t(g[k], True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     st = GaussianRasterizationSettings(H, W, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), torch.ones(3, device=dev), 1.0,
@@ -298,6 +302,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=1e9, help="stop opening new points after this many seconds")
     ap.add_argument("--tracked", action="store_true", help="add the tracked workloads (C2, C4's two frames, the trained profile, C3) as points")
     ap.add_argument("--person-grid", action="store_true", help="add a grid of person-in-front-of-a-scene frames (body surface, tools/bench_step.py's geometry)")
+    ap.add_argument("--flat-deep", action="store_true", help="add covered frames of 7-pixel splats (flat lists of 800 .. 1 700 entries)")
     ap.add_argument("--where", default=None, help="a Python expression over a point's fields that selects points")
     ap.add_argument("--list-stats", action="store_true", help="record what the scan kernel sees of each frame (non-empty tiles, longest list, ...)")
     ap.add_argument("--stages-of", default="", help="comma-separated prefixes of forced alternatives whose per-stage times are recorded too")

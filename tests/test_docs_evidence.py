@@ -34,7 +34,7 @@ def test_every_profile_a_current_document_cites_is_tracked():
 
 def test_the_shape_scans_say_what_the_documents_say_about_them():
     want = {"r6z_shape_scan.json": (194, 1), "r6z_shape_scan_holdout.json": (60, 2), "r6z_shape_scan_person_grid.json": (72, 0),
-            "r6z_shape_scan_holdout2.json": (36, 2), "r6a_shape_scan_before.json": (186, 37)}
+            "r6z_shape_scan_holdout2.json": (36, 2), "r6z_shape_scan_holdout3.json": (36, 1), "r6a_shape_scan_before.json": (186, 37)}
     for name, (points, wins) in want.items():
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert d["n_points"] == points and d["n_points_where_forced_wins_by_5pct"] == wins, (name, d["n_points"], d["n_points_where_forced_wins_by_5pct"])

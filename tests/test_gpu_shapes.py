@@ -167,8 +167,14 @@ def test_the_default_path_is_not_far_from_the_better_frame_kind(device):
               {"kind": "tracked_trained", "H": 1080, "W": 1920, "P": 310_210, "D": 0}]      # the trained profile: dense with deep tiles
     try:
         for pt in frames:
-            row = ss.scan_point(pt, args, device, ["default", "kind_dense", "kind_sparse"])
-            best = min(v for v in row["forced_ms"].values() if v is not None)
-            assert row["default_ms"] <= 1.12 * best, (pt, row["default_ms"], row["forced_ms"])
+            seen = []
+            for attempt in range(2):   # (a loaded host can disturb one measurement of a 0.15 ms frame: a misjudged family fails both)
+                row = ss.scan_point(pt, args, device, ["default", "kind_dense", "kind_sparse"])
+                best = min(v for v in row["forced_ms"].values() if v is not None)
+                seen.append((row["default_ms"], row["forced_ms"]))
+                if row["default_ms"] <= 1.12 * best:
+                    break
+            else:
+                raise AssertionError((pt, seen))
     finally:
         ss.set_variant("default")
